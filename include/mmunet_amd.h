@@ -1,0 +1,173 @@
+/*
+ * mmunet_amd.h -- C-ABI of libmmunet_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the MM-UNet hot path.  Each entry point replaces one
+ * pybind11 function of the reference's two CUDA torch-extensions; the
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ *   mmu_selective_scan_fwd   <- selective_scan_cuda.fwd
+ *        requirements/Mamba/mamba/csrc/selective_scan/selective_scan.cpp:226-336,495
+ *   mmu_selective_scan_bwd   <- selective_scan_cuda.bwd
+ *        requirements/Mamba/mamba/csrc/selective_scan/selective_scan.cpp:338-492,496
+ *   mmu_causal_conv1d_fwd    <- causal_conv1d_cuda.causal_conv1d_fwd
+ *        requirements/Mamba/causal-conv1d/csrc/causal_conv1d.cpp:130-189,330
+ *   mmu_causal_conv1d_bwd    <- causal_conv1d_cuda.causal_conv1d_bwd
+ *        requirements/Mamba/causal-conv1d/csrc/causal_conv1d.cpp:191-268,331
+ *   mmu_causal_conv1d_update <- causal_conv1d_cuda.causal_conv1d_update
+ *        requirements/Mamba/causal-conv1d/csrc/causal_conv1d.cpp:270-327,332
+ *
+ * Conventions (same as the reference's):
+ *   - stateless; every launch goes to the hipStream_t passed in (`stream`,
+ *     a `hipStream_t` cast to void*; NULL = the null stream); no host threads,
+ *     no allocation, no synchronisation inside -> graph-capturable;
+ *   - all pointers are DEVICE pointers; outputs and workspaces are allocated
+ *     by the caller (the reference allocates them inside the pybind function;
+ *     here that moved to the host shim so the ABI carries no torch types);
+ *   - strides are in ELEMENTS; the sequence (L) stride of every [.,.,L]
+ *     tensor must be 1 (selective_scan.cpp:252-253);
+ *   - return value 0 = ok; non-zero = rejected/failed, message available via
+ *     mmu_last_error() (thread-local).  The host shim turns it into the
+ *     RuntimeError the reference's TORCH_CHECKs raise.
+ *
+ * dtype codes: 0 = float32, 1 = bfloat16 (I/O tensors u, delta, z, B, C, out,
+ * dout, du, ddelta, dz / x, out, dout, dx).  A, D, delta_bias, conv weights,
+ * chunk states and every gradient accumulated across batch (dA, dB, dC, dD,
+ * ddelta_bias, dweight, dbias) are always float32.
+ */
+#ifndef MMUNET_AMD_H
+#define MMUNET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMU_DTYPE_F32 0
+#define MMU_DTYPE_BF16 1
+
+/* ---- library info ------------------------------------------------------ */
+int mmu_abi_version(void);
+const char *mmu_last_error(void);
+
+/* Chunk length (tokens) the scan kernels use for a given dstate and dtype.  The
+ * chunk-state tensor `x` has shape [batch, dim, n_chunks, 2*dstate] float32 with
+ * n_chunks = ceil(seqlen / chunk_len).  (The reference hard-codes 2048,
+ * selective_scan.cpp:307; here it is smaller because chunks are what run in
+ * parallel.)  x[b,d,c,2n+1] = state h_n at the END of chunk c, so
+ * x[:, :, -1, 1::2] is the last state exactly as in
+ * selective_scan_interface.py:40.  x[b,d,c,2n] = product of a_t over chunk c. */
+int mmu_scan_chunk_len(int dstate, int dtype);
+
+/* Bytes of float32 workspace mmu_selective_scan_bwd needs. */
+size_t mmu_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int dtype, int have_x);
+
+/* ---- selective scan ------------------------------------------------------ */
+typedef struct {
+    int32_t batch, dim, seqlen, dstate, ngroups;
+    int32_t dtype;           /* MMU_DTYPE_* of u, delta, z, B, C, out, out_z */
+    int32_t delta_softplus;  /* bool */
+    int32_t n_chunks;        /* must be ceil(seqlen / mmu_scan_chunk_len(dstate, dtype)) */
+    const void *u;           /* [batch, dim, L]   strides (u_bs, u_ds, 1) */
+    const void *delta;       /* [batch, dim, L] */
+    const float *A;          /* [dim, dstate]     strides (A_ds, A_ns), real */
+    const void *B;           /* [batch, G, dstate, L] strides (B_bs, B_gs, B_ns, 1) */
+    const void *C;           /* same */
+    const float *D;          /* [dim] or NULL */
+    const void *z;           /* [batch, dim, L] or NULL */
+    const float *delta_bias; /* [dim] or NULL */
+    void *out;               /* [batch, dim, L] or NULL (y before gating) */
+    void *out_z;             /* [batch, dim, L]; required iff z != NULL */
+    float *x;                /* [batch, dim, n_chunks, 2*dstate] contiguous; required */
+    int64_t u_bs, u_ds, delta_bs, delta_ds, z_bs, z_ds;
+    int64_t out_bs, out_ds, out_z_bs, out_z_ds;
+    int64_t A_ds, A_ns;
+    int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns;
+} mmu_scan_fwd_params;
+
+int mmu_selective_scan_fwd(const mmu_scan_fwd_params *p, void *stream);
+
+typedef struct {
+    int32_t batch, dim, seqlen, dstate, ngroups;
+    int32_t dtype;
+    int32_t delta_softplus;
+    int32_t n_chunks;
+    const void *u, *delta;
+    const float *A;
+    const void *B, *C;
+    const float *D;          /* or NULL */
+    const void *z;           /* or NULL */
+    const float *delta_bias; /* or NULL */
+    const void *dout;        /* [batch, dim, L] */
+    const float *x;          /* chunk states from the forward, or NULL (recomputed) */
+    void *du, *ddelta;       /* [batch, dim, L], I/O dtype */
+    float *dA;               /* [dim, dstate] contiguous, OVERWRITTEN (not accumulated) */
+    float *dB, *dC;          /* [batch, G, dstate, L] contiguous float32, overwritten */
+    float *dD;               /* [dim] or NULL */
+    float *ddelta_bias;      /* [dim] or NULL */
+    void *dz;                /* [batch, dim, L] (may be a strided view); required iff z */
+    void *out_z;             /* optional: recomputed gated output (recompute_out_z) */
+    float *workspace;        /* mmu_scan_bwd_workspace_bytes(...) bytes */
+    int64_t u_bs, u_ds, delta_bs, delta_ds, z_bs, z_ds, dout_bs, dout_ds;
+    int64_t du_bs, du_ds, ddelta_bs, ddelta_ds, dz_bs, dz_ds, out_z_bs, out_z_ds;
+    int64_t A_ds, A_ns;
+    int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns;
+} mmu_scan_bwd_params;
+
+int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream);
+
+/* ---- depthwise causal conv1d (channel-first, unit L stride) ------------- */
+typedef struct {
+    int32_t batch, dim, seqlen, width; /* width in 2..4 */
+    int32_t dtype;                     /* of x / out */
+    int32_t silu;                      /* bool */
+    const void *x;                     /* [batch, dim, L] strides (x_bs, x_ds, 1) */
+    const float *weight;               /* [dim, width] strides (w_ds, w_ws) */
+    const float *bias;                 /* [dim] or NULL */
+    void *out;                         /* [batch, dim, L] strides (out_bs, out_ds, 1) */
+    int64_t x_bs, x_ds, out_bs, out_ds, w_ds, w_ws;
+} mmu_conv1d_fwd_params;
+
+int mmu_causal_conv1d_fwd(const mmu_conv1d_fwd_params *p, void *stream);
+
+typedef struct {
+    int32_t batch, dim, seqlen, width;
+    int32_t dtype;
+    int32_t silu;
+    const void *x;
+    const float *weight;
+    const float *bias;  /* or NULL */
+    const void *dout;   /* [batch, dim, L] strides (dout_bs, dout_ds, 1) */
+    void *dx;           /* [batch, dim, L] strides (dx_bs, dx_ds, 1); may be a view */
+    float *dweight;     /* [dim, width] contiguous float32, must be ZEROED by the caller (atomics) */
+    float *dbias;       /* [dim] float32 zeroed, or NULL */
+    int64_t x_bs, x_ds, dout_bs, dout_ds, dx_bs, dx_ds, w_ds, w_ws;
+} mmu_conv1d_bwd_params;
+
+int mmu_causal_conv1d_bwd(const mmu_conv1d_bwd_params *p, void *stream);
+
+typedef struct {
+    int32_t batch, dim, width;
+    int32_t dtype;
+    int32_t silu;
+    const void *x;       /* [batch, dim] strides (x_bs, x_ds) */
+    void *conv_state;    /* [batch, dim, width] strides (cs_bs, cs_ds, cs_ws), updated in place */
+    const float *weight; /* [dim, width] */
+    const float *bias;   /* or NULL */
+    void *out;           /* [batch, dim] strides (out_bs, out_ds) */
+    int64_t x_bs, x_ds, cs_bs, cs_ds, cs_ws, out_bs, out_ds, w_ds, w_ws;
+} mmu_conv1d_update_params;
+
+int mmu_causal_conv1d_update(const mmu_conv1d_update_params *p, void *stream);
+
+/* ---- test hooks (exercise the wave-level primitives on the GPU) -------- */
+/* Runs the in-wave affine-pair scan on n_waves*64 (P,S) pairs, one wave per 64.
+ * reverse=0: forward inclusive; reverse=1: reverse inclusive.  variant 0 = DPP, 1 = shuffle. */
+int mmu_debug_wave_scan(const float *P, const float *S, float *outP, float *outS, int n_waves,
+                        int reverse, int variant, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMUNET_AMD_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of libmmunet_hip.so (the C-ABI declared in include/mmunet_amd.h).
+
+The product path has NO fallback: if the library is missing or cannot be loaded,
+every op raises ``RuntimeError`` -- it never routes to a CPU implementation.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmunet_hip.so")
+
+MMU_DTYPE_F32 = 0
+MMU_DTYPE_BF16 = 1
+
+_i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+
+
+class ScanFwdParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "seqlen", "dstate", "ngroups", "dtype", "delta_softplus", "n_chunks")]
+        + [(n, _vp) for n in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias", "out", "out_z", "x")]
+        + [(n, _i64) for n in ("u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "out_bs", "out_ds",
+                               "out_z_bs", "out_z_ds", "A_ds", "A_ns", "B_bs", "B_gs", "B_ns", "C_bs", "C_gs",
+                               "C_ns")]
+    )
+
+
+class ScanBwdParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "seqlen", "dstate", "ngroups", "dtype", "delta_softplus", "n_chunks")]
+        + [(n, _vp) for n in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias", "dout", "x", "du", "ddelta",
+                              "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z", "workspace")]
+        + [(n, _i64) for n in ("u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "dout_bs", "dout_ds",
+                               "du_bs", "du_ds", "ddelta_bs", "ddelta_ds", "dz_bs", "dz_ds", "out_z_bs",
+                               "out_z_ds", "A_ds", "A_ns", "B_bs", "B_gs", "B_ns", "C_bs", "C_gs", "C_ns")]
+    )
+
+
+class Conv1dFwdParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "seqlen", "width", "dtype", "silu")]
+        + [(n, _vp) for n in ("x", "weight", "bias", "out")]
+        + [(n, _i64) for n in ("x_bs", "x_ds", "out_bs", "out_ds", "w_ds", "w_ws")]
+    )
+
+
+class Conv1dBwdParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "seqlen", "width", "dtype", "silu")]
+        + [(n, _vp) for n in ("x", "weight", "bias", "dout", "dx", "dweight", "dbias")]
+        + [(n, _i64) for n in ("x_bs", "x_ds", "dout_bs", "dout_ds", "dx_bs", "dx_ds", "w_ds", "w_ws")]
+    )
+
+
+class Conv1dUpdateParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "width", "dtype", "silu")]
+        + [(n, _vp) for n in ("x", "conv_state", "weight", "bias", "out")]
+        + [(n, _i64) for n in ("x_bs", "x_ds", "cs_bs", "cs_ds", "cs_ws", "out_bs", "out_ds", "w_ds", "w_ws")]
+    )
+
+
+# every symbol include/mmunet_amd.h declares (tests check that the library exports all of them)
+EXPORTS = (
+    "mmu_abi_version", "mmu_last_error", "mmu_scan_chunk_len", "mmu_scan_bwd_workspace_bytes",
+    "mmu_selective_scan_fwd", "mmu_selective_scan_bwd", "mmu_causal_conv1d_fwd", "mmu_causal_conv1d_bwd",
+    "mmu_causal_conv1d_update", "mmu_debug_wave_scan",
+)
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises RuntimeError (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"mm-unet_amd: HIP library not built ({LIB_PATH}); run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or mm-unet_amd/csrc/build.sh.  There is no CPU fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. no ROCm runtime on this host
+        raise RuntimeError(f"mm-unet_amd: cannot load {LIB_PATH}: {e}.  There is no CPU fallback.") from e
+    L.mmu_abi_version.restype = ctypes.c_int
+    L.mmu_last_error.restype = ctypes.c_char_p
+    L.mmu_scan_chunk_len.restype = ctypes.c_int
+    L.mmu_scan_chunk_len.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mmu_scan_bwd_workspace_bytes.restype = ctypes.c_size_t
+    L.mmu_scan_bwd_workspace_bytes.argtypes = [ctypes.c_int] * 6
+    for name, st in (("mmu_selective_scan_fwd", ScanFwdParams), ("mmu_selective_scan_bwd", ScanBwdParams),
+                     ("mmu_causal_conv1d_fwd", Conv1dFwdParams), ("mmu_causal_conv1d_bwd", Conv1dBwdParams),
+                     ("mmu_causal_conv1d_update", Conv1dUpdateParams)):
+        fn = getattr(L, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(st), _vp]
+    L.mmu_debug_wave_scan.restype = ctypes.c_int
+    L.mmu_debug_wave_scan.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError(lib().mmu_last_error().decode())
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return MMU_DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return MMU_DTYPE_BF16
+    raise RuntimeError(f"mm-unet_amd kernels support float32 and bfloat16 I/O, got {t.dtype}")
+
+
+def stream_of(t):
+    """Current HIP stream of the tensor's device (the reference launches on the current stream
+    after a device guard, selective_scan.cpp:326-327)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mm-unet_amd: expected a GPU (HIP) tensor; there is no CPU path in this package")

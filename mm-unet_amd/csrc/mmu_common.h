@@ -1,0 +1,195 @@
+// mmu_common.h -- shared device/host helpers for libmmunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define MMU_WAVE 64
+#define MMU_LOG2E 1.4426950408889634f
+#define MMU_LN2 0.6931471805599453f
+
+// ---------------------------------------------------------------------------
+// host-side error reporting (thread-local, read through mmu_last_error())
+// ---------------------------------------------------------------------------
+extern thread_local char g_mmu_err[512];
+int mmu_fail(const char *fmt, ...);
+
+#define MMU_CHECK(cond, ...)                       \
+    do {                                           \
+        if (!(cond)) return mmu_fail(__VA_ARGS__); \
+    } while (0)
+
+#define MMU_HIP_LAUNCH_CHECK(what)                                                        \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess) return mmu_fail("%s: %s", what, hipGetErrorString(e__));   \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// I/O element types
+// ---------------------------------------------------------------------------
+struct bf16_t {
+    uint16_t bits;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v.bits) << 16); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float f);
+template <>
+__device__ __forceinline__ float from_f32<float>(float f) { return f; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {
+    // plain cast -> v_cvt_pk_bf16_f32 (RNE, keeps NaN a NaN)
+    __bf16 h = (__bf16)f;
+    bf16_t r;
+    r.bits = __builtin_bit_cast(uint16_t, h);
+    return r;
+}
+
+template <typename T, int K>
+struct alignas(sizeof(T) * K) Pack {
+    T e[K];
+};
+
+// Loads K consecutive items at p (items beyond nvalid read as 0).  `vec` = the
+// host verified that every such K-group is naturally aligned.
+template <typename T, int K>
+__device__ __forceinline__ void load_k(const T *__restrict__ p, int nvalid, bool vec, float (&o)[K]) {
+    if (vec && nvalid >= K) {
+        Pack<T, K> v = *reinterpret_cast<const Pack<T, K> *>(p);
+#pragma unroll
+        for (int i = 0; i < K; ++i) o[i] = to_f32(v.e[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) o[i] = (i < nvalid) ? to_f32(p[i]) : 0.f;
+    }
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void store_k(T *__restrict__ p, int nvalid, bool vec, const float (&v)[K]) {
+    if (vec && nvalid >= K) {
+        Pack<T, K> o;
+#pragma unroll
+        for (int i = 0; i < K; ++i) o.e[i] = from_f32<T>(v[i]);
+        *reinterpret_cast<Pack<T, K> *>(p) = o;
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (i < nvalid) p[i] = from_f32<T>(v[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+// softplus with the reference kernel's threshold (selective_scan_fwd_kernel.cuh:153-156)
+__device__ __forceinline__ float softplus_thr(float x) { return x <= 20.f ? log1pf(expf(x)) : x; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---------------------------------------------------------------------------
+// wave64 cross-lane primitives (DPP: row_shr 1/2/4/8, row_bcast15, row_bcast31)
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                           ROW_MASK, 0xf, false));
+}
+
+#define MMU_DPP_ROW_SHR(n) (0x110 + (n))
+#define MMU_DPP_WAVE_SHR1 0x138
+#define MMU_DPP_ROW_BCAST15 0x142
+#define MMU_DPP_ROW_BCAST31 0x143
+
+// Inclusive scan over the 64 lanes of affine pairs f(h) = P*h + S, composition
+// "earlier lane first": (P0,S0) then (P1,S1) -> (P1*P0, P1*S0 + S1)
+// (the reference's SSMScanOp, selective_scan_common.h:110-115).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_step_dpp(float &P, float &S) {
+    const float Pp = dpp_mov<CTRL, ROW_MASK>(1.0f, P);
+    const float Sp = dpp_mov<CTRL, ROW_MASK>(0.0f, S);
+    S = fmaf(P, Sp, S);
+    P = P * Pp;
+}
+
+__device__ __forceinline__ void wave_scan_affine_dpp(float &P, float &S) {
+    scan_step_dpp<MMU_DPP_ROW_SHR(1), 0xf>(P, S);
+    scan_step_dpp<MMU_DPP_ROW_SHR(2), 0xf>(P, S);
+    scan_step_dpp<MMU_DPP_ROW_SHR(4), 0xf>(P, S);
+    scan_step_dpp<MMU_DPP_ROW_SHR(8), 0xf>(P, S);
+    scan_step_dpp<MMU_DPP_ROW_BCAST15, 0xa>(P, S);
+    scan_step_dpp<MMU_DPP_ROW_BCAST31, 0xc>(P, S);
+}
+
+__device__ __forceinline__ void wave_scan_affine_shfl(float &P, float &S) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float Pp = __shfl_up(P, off, 64);
+        const float Sp = __shfl_up(S, off, 64);
+        if (lane >= off) {
+            S = fmaf(P, Sp, S);
+            P = P * Pp;
+        }
+    }
+}
+
+#ifndef MMU_SCAN_USE_SHFL
+#define MMU_SCAN_USE_SHFL 0
+#endif
+
+__device__ __forceinline__ void wave_scan_affine(float &P, float &S) {
+#if MMU_SCAN_USE_SHFL
+    wave_scan_affine_shfl(P, S);
+#else
+    wave_scan_affine_dpp(P, S);
+#endif
+}
+
+// value of lane (l-1); lane 0 gets `fill`
+__device__ __forceinline__ float wave_shift_up1(float v, float fill) {
+#if MMU_SCAN_USE_SHFL
+    const float r = __shfl_up(v, 1, 64);
+    return (threadIdx.x & 63) == 0 ? fill : r;
+#else
+    return dpp_mov<MMU_DPP_WAVE_SHR1, 0xf>(fill, v);
+#endif
+}
+
+// lane l <-> lane 63-l
+__device__ __forceinline__ float wave_reverse(float v) {
+    const int lane = threadIdx.x & 63;
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((63 - lane) << 2, __builtin_bit_cast(int, v)));
+}
+
+// inclusive prefix sum over lanes
+__device__ __forceinline__ float wave_scan_add(float v) {
+#if MMU_SCAN_USE_SHFL
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+#else
+    v += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_BCAST15, 0xa>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_BCAST31, 0xc>(0.f, v);
+    return v;
+#endif
+}
+
+__device__ __forceinline__ float wave_bcast_last(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// sum over the 64 lanes, result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) { return wave_bcast_last(wave_scan_add(v)); }

@@ -1,0 +1,160 @@
+"""``selective_scan_hip`` -- the module that stands where the reference's pybind extension
+``selective_scan_cuda`` stands (requirements/Mamba/mamba/csrc/selective_scan/selective_scan.cpp:494-497).
+
+Same function names, positional arguments, return lists and error behaviour
+(``RuntimeError`` for what the reference rejects with ``TORCH_CHECK``); the work is done by
+the hand-written gfx950 kernels behind the C-ABI (include/mmunet_amd.h).  Tensor allocation
+that the reference does inside the pybind function happens here, so the ABI carries raw
+pointers only.
+
+Differences a caller can observe:
+  * the chunk-state tensor ``x`` is ``(batch, dim, n_chunks, 2*dstate)`` with
+    ``n_chunks = ceil(seqlen / chunk_len(dstate))`` (chunk_len 256 for dstate<=32) instead of
+    the reference's fixed 2048; ``x[:, :, -1, 1::2]`` is still the last state
+    (selective_scan_interface.py:40);
+  * real ``A`` and input-dependent (``dim() >= 3``) ``B``/``C`` only -- the only variant
+    MM-UNet uses; complex ``A`` / constant ``B``,``C`` raise ``RuntimeError``;
+  * float32 and bfloat16 I/O (no float16); dstate <= 128.
+"""
+import torch
+
+from . import _lib
+
+
+def _check(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def chunk_len(dstate, dtype=torch.float32):
+    code = _lib.MMU_DTYPE_F32 if dtype == torch.float32 else _lib.MMU_DTYPE_BF16
+    n = _lib.lib().mmu_scan_chunk_len(int(dstate), code)
+    _check(n > 0, f"selective_scan only supports state dimension <= 128 (got {dstate})")
+    return n
+
+
+def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
+    _lib.require_gpu(u, delta, A, B, C, D_, z_, delta_bias_)
+    _check(u.dtype in (torch.float32, torch.bfloat16), f"selective_scan: unsupported input dtype {u.dtype}")
+    _check(A.dtype == torch.float32, "selective_scan: A must be float32 (complex A is not on the MM-UNet path)")
+    _check(B.dim() == 4 and C.dim() == 4,
+           "selective_scan: only input-dependent B and C of shape (batch, groups, dstate, seqlen) are supported")
+    _check(delta.dtype == u.dtype and B.dtype == u.dtype and C.dtype == u.dtype,
+           "selective_scan: delta, B, C must have the dtype of u")
+    _check(u.dim() == 3, "selective_scan: u must be (batch, dim, seqlen)")
+    batch, dim, seqlen = u.shape
+    dstate = A.shape[1]
+    g = B.shape[1]
+    _check(u.stride(-1) == 1 and delta.stride(-1) == 1, "selective_scan: u and delta need unit stride in seqlen")
+    _check(tuple(delta.shape) == (batch, dim, seqlen), "selective_scan: delta has the wrong shape")
+    _check(tuple(A.shape) == (dim, dstate), "selective_scan: A has the wrong shape")
+    _check(tuple(B.shape) == (batch, g, dstate, seqlen) and B.stride(-1) == 1, "selective_scan: B has the wrong shape/stride")
+    _check(tuple(C.shape) == (batch, g, dstate, seqlen) and C.stride(-1) == 1, "selective_scan: C has the wrong shape/stride")
+    _check(dim % g == 0, "selective_scan: dim must be divisible by the number of groups")
+    for name, t in (("D", D_), ("delta_bias", delta_bias_)):
+        if t is not None:
+            _check(t.dtype == torch.float32 and tuple(t.shape) == (dim,) and t.stride(-1) == 1,
+                   f"selective_scan: {name} must be a contiguous float32 (dim,) tensor")
+    if z_ is not None:
+        _check(z_.dtype == u.dtype and tuple(z_.shape) == (batch, dim, seqlen) and z_.stride(-1) == 1,
+               "selective_scan: z has the wrong dtype/shape/stride")
+    return batch, dim, seqlen, dstate, g
+
+
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
+    """selective_scan_cuda.fwd: returns ``[out, x]`` or ``[out, x, out_z]`` (selective_scan.cpp:226-336)."""
+    batch, dim, seqlen, dstate, g = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
+    T = chunk_len(dstate, u.dtype)
+    n_chunks = (seqlen + T - 1) // T
+    out = torch.empty_like(delta)
+    out_z = torch.empty_like(z_) if z_ is not None else None
+    x = torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device, dtype=torch.float32)
+    p = _lib.ScanFwdParams()
+    p.batch, p.dim, p.seqlen, p.dstate, p.ngroups = batch, dim, seqlen, dstate, g
+    p.dtype = _lib.dtype_code(u)
+    p.delta_softplus = int(bool(delta_softplus))
+    p.n_chunks = n_chunks
+    p.u, p.delta, p.A, p.B, p.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
+    p.D, p.z, p.delta_bias = _lib.ptr(D_), _lib.ptr(z_), _lib.ptr(delta_bias_)
+    p.out, p.out_z, p.x = out.data_ptr(), _lib.ptr(out_z), x.data_ptr()
+    p.u_bs, p.u_ds = u.stride(0), u.stride(1)
+    p.delta_bs, p.delta_ds = delta.stride(0), delta.stride(1)
+    p.out_bs, p.out_ds = out.stride(0), out.stride(1)
+    if z_ is not None:
+        p.z_bs, p.z_ds = z_.stride(0), z_.stride(1)
+        p.out_z_bs, p.out_z_ds = out_z.stride(0), out_z.stride(1)
+    p.A_ds, p.A_ns = A.stride(0), A.stride(1)
+    p.B_bs, p.B_gs, p.B_ns = B.stride(0), B.stride(1), B.stride(2)
+    p.C_bs, p.C_gs, p.C_ns = C.stride(0), C.stride(1), C.stride(2)
+    with torch.cuda.device(u.device):
+        _lib.check(_lib.lib().mmu_selective_scan_fwd(p, _lib.stream_of(u)))
+    return [out, x, out_z] if z_ is not None else [out, x]
+
+
+def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z):
+    """selective_scan_cuda.bwd: returns ``[du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]``
+    (selective_scan.cpp:338-492).  ``out_`` is accepted for signature parity and not read: y is
+    recomputed from the states the kernel rebuilds anyway."""
+    batch, dim, seqlen, dstate, g = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
+    _lib.require_gpu(dout, x_, dz_)
+    _check(dout.dtype == u.dtype and tuple(dout.shape) == (batch, dim, seqlen) and dout.stride(-1) == 1,
+           "selective_scan_bwd: dout has the wrong dtype/shape/stride")
+    T = chunk_len(dstate, u.dtype)
+    n_chunks = (seqlen + T - 1) // T
+    if x_ is not None:
+        _check(x_.dtype == torch.float32 and x_.is_contiguous() and
+               tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate),
+               "selective_scan_bwd: x must be the contiguous float32 chunk-state tensor returned by fwd")
+    has_z = z_ is not None
+    dz = out_z = None
+    if has_z:
+        if dz_ is not None:
+            _check(dz_.dtype == u.dtype and tuple(dz_.shape) == (batch, dim, seqlen) and dz_.stride(-1) == 1,
+                   "selective_scan_bwd: dz has the wrong dtype/shape/stride")
+            dz = dz_
+        else:
+            dz = torch.empty_like(z_)
+        if recompute_out_z:
+            out_z = torch.empty_like(out_) if out_ is not None else torch.empty_like(delta)
+    du = torch.empty_like(u)
+    ddelta = torch.empty_like(delta)
+    dA = torch.empty((dim, dstate), device=u.device, dtype=torch.float32)
+    dB = torch.empty((batch, g, dstate, seqlen), device=u.device, dtype=torch.float32)
+    dC = torch.empty((batch, g, dstate, seqlen), device=u.device, dtype=torch.float32)
+    dD = torch.empty_like(D_) if D_ is not None else None
+    ddelta_bias = torch.empty_like(delta_bias_) if delta_bias_ is not None else None
+    L = _lib.lib()
+    ws_bytes = L.mmu_scan_bwd_workspace_bytes(batch, dim, seqlen, dstate, _lib.dtype_code(u), int(x_ is not None))
+    ws = torch.empty(ws_bytes // 4, device=u.device, dtype=torch.float32)
+    p = _lib.ScanBwdParams()
+    p.batch, p.dim, p.seqlen, p.dstate, p.ngroups = batch, dim, seqlen, dstate, g
+    p.dtype = _lib.dtype_code(u)
+    p.delta_softplus = int(bool(delta_softplus))
+    p.n_chunks = n_chunks
+    p.u, p.delta, p.A, p.B, p.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
+    p.D, p.z, p.delta_bias = _lib.ptr(D_), _lib.ptr(z_), _lib.ptr(delta_bias_)
+    p.dout, p.x = dout.data_ptr(), _lib.ptr(x_)
+    p.du, p.ddelta, p.dA, p.dB, p.dC = du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
+    p.dD, p.ddelta_bias, p.dz, p.out_z = _lib.ptr(dD), _lib.ptr(ddelta_bias), _lib.ptr(dz), _lib.ptr(out_z)
+    p.workspace = ws.data_ptr()
+    p.u_bs, p.u_ds = u.stride(0), u.stride(1)
+    p.delta_bs, p.delta_ds = delta.stride(0), delta.stride(1)
+    p.dout_bs, p.dout_ds = dout.stride(0), dout.stride(1)
+    p.du_bs, p.du_ds = du.stride(0), du.stride(1)
+    p.ddelta_bs, p.ddelta_ds = ddelta.stride(0), ddelta.stride(1)
+    if has_z:
+        p.z_bs, p.z_ds = z_.stride(0), z_.stride(1)
+        p.dz_bs, p.dz_ds = dz.stride(0), dz.stride(1)
+        if out_z is not None:
+            p.out_z_bs, p.out_z_ds = out_z.stride(0), out_z.stride(1)
+    p.A_ds, p.A_ns = A.stride(0), A.stride(1)
+    p.B_bs, p.B_gs, p.B_ns = B.stride(0), B.stride(1), B.stride(2)
+    p.C_bs, p.C_gs, p.C_ns = C.stride(0), C.stride(1), C.stride(2)
+    with torch.cuda.device(u.device):
+        _lib.check(L.mmu_selective_scan_bwd(p, _lib.stream_of(u)))
+    result = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
+    if has_z:
+        result.append(dz)
+    if recompute_out_z:
+        result.append(out_z)
+    return result

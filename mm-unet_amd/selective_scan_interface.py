@@ -1,0 +1,335 @@
+"""Autograd layer over the HIP selective-scan / causal-conv1d kernels.
+
+Public surface = that of the reference's ``mamba_ssm/ops/selective_scan_interface.py``
+(names, positional order, defaults, return values):
+
+    selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None,
+                      delta_softplus=False, return_last_state=False)        (:77-83)
+    mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                   out_proj_weight, out_proj_bias, A, B=None, C=None, D=None, delta_bias=None,
+                   B_proj_bias=None, C_proj_bias=None, delta_softplus=True)  (:606-614)
+    mamba_inner_fn_no_out_proj(... same without out_proj ...)               (:627-633)
+    bimamba_inner_fn(..., A, A_b, ...)                                      (:616-624)
+    classes SelectiveScanFn, MambaInnerFn, MambaInnerFnNoOutProj, BiMambaInnerFn
+
+What each fused function computes (forward, reference lines :159-224 / :296-365):
+    x, z      = xz.chunk(2, dim=1)
+    conv_out  = silu(causal_conv1d(x))                       -> HIP kernel
+    x_dbl     = conv_out^T @ x_proj_weight^T                 (B*L, r+2N)  GEMM (hipBLASLt via ATen)
+    delta     = delta_proj_weight @ x_dbl[:, :r]^T           (D, B*L) viewed (B, D, L)
+    B, C      = x_dbl slices -> (B, 1, N, L)
+    out_z     = selective_scan(conv_out, delta, A, B, C, D, z, delta_bias, softplus)  -> HIP kernels
+    [out      = out_z^T @ out_proj_weight^T + out_proj_bias]
+Backward recomputes conv_out and delta (the reference's checkpoint_lvl=1, :218-219,238-241) and
+writes dx / dz straight into the two halves of one dxz buffer (:244-245).
+
+No CPU path: tensors must live on the GPU, the HIP library must be present.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import causal_conv1d_hip, selective_scan_hip
+
+try:  # torch >= 2.4
+    from torch.amp import custom_bwd as _custom_bwd, custom_fwd as _custom_fwd
+
+    def custom_fwd(fn):
+        return _custom_fwd(fn, device_type="cuda")
+
+    def custom_bwd(fn):
+        return _custom_bwd(fn, device_type="cuda")
+except ImportError:  # pragma: no cover
+    from torch.cuda.amp import custom_bwd, custom_fwd
+
+
+def _autocast_dtype():
+    if torch.is_autocast_enabled():
+        try:
+            return torch.get_autocast_dtype("cuda")
+        except AttributeError:  # pragma: no cover
+            return torch.get_autocast_gpu_dtype()
+    return None
+
+
+def _unit_l(t):
+    return t if t is None or t.stride(-1) == 1 else t.contiguous()
+
+
+def _as_bnl4(t):
+    """(batch, dstate, L) -> (batch, 1, dstate, L); returns (tensor, squeezed?)."""
+    if t.dim() == 3:
+        return t.unsqueeze(1), True
+    return t, False
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    """selective_scan_interface.py:14-74."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False):
+        u, delta, B, C, z = _unit_l(u), _unit_l(delta), _unit_l(B), _unit_l(C), _unit_l(z)
+        if D is not None:
+            D = D.contiguous()
+        B, ctx.squeeze_B = _as_bnl4(B)
+        C, ctx.squeeze_C = _as_bnl4(C)
+        out, x, *rest = selective_scan_hip.fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus)
+        ctx.delta_softplus = delta_softplus
+        ctx.has_z = z is not None
+        last_state = x[:, :, -1, 1::2]  # (batch, dim, dstate)
+        if not ctx.has_z:
+            ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x)
+            return out if not return_last_state else (out, last_state)
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, x, out)
+        out_z = rest[0]
+        return out_z if not return_last_state else (out_z, last_state)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        if not ctx.has_z:
+            u, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
+            z = out = None
+        else:
+            u, delta, A, B, C, D, z, delta_bias, x, out = ctx.saved_tensors
+        dout = _unit_l(dout)
+        du, ddelta, dA, dB, dC, dD, ddelta_bias, *rest = selective_scan_hip.bwd(
+            u, delta, A, B, C, D, z, delta_bias, dout, x, out, None, ctx.delta_softplus, False)
+        dz = rest[0] if ctx.has_z else None
+        dB = dB.squeeze(1) if ctx.squeeze_B else dB
+        dC = dC.squeeze(1) if ctx.squeeze_C else dC
+        return (du, ddelta, dA, dB, dC, dD if D is not None else None, dz,
+                ddelta_bias if delta_bias is not None else None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """If return_last_state is True returns (out, last_state); last_state is (batch, dim, dstate) and
+    carries no gradient (selective_scan_interface.py:77-83)."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused inner function
+# ---------------------------------------------------------------------------------------------
+def _dbl_view(t):
+    """(B, D, L) -> (D, B*L) matrix (a view when t is laid out [D][B][L], as inside mamba_inner)."""
+    b, d, l = t.shape
+    return t.permute(1, 0, 2).reshape(d, b * l)
+
+
+def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias):
+    """x_dbl, delta, B, C from the conv output (selective_scan_interface.py:181-210)."""
+    batch, dim, L = conv1d_out.shape
+    r = delta_proj_weight.shape[1]
+    x_dbl = F.linear(_dbl_view(conv1d_out).t(), x_proj_weight)  # (B*L, r + 2N)
+    delta = (delta_proj_weight @ x_dbl[:, :r].t()).view(dim, batch, L).permute(1, 0, 2)
+    if B is None:
+        Bv = x_dbl[:, r:r + d_state]
+        if B_proj_bias is not None:
+            Bv = Bv + B_proj_bias.to(dtype=Bv.dtype)
+        B = Bv.reshape(batch, L, d_state).permute(0, 2, 1).unsqueeze(1).contiguous()
+    else:
+        B = _unit_l(B)
+    if C is None:
+        Cv = x_dbl[:, -d_state:]
+        if C_proj_bias is not None:
+            Cv = Cv + C_proj_bias.to(dtype=Cv.dtype)
+        C = Cv.reshape(batch, L, d_state).permute(0, 2, 1).unsqueeze(1).contiguous()
+    else:
+        C = _unit_l(C)
+    return x_dbl, delta, B, C
+
+
+def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                   out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, checkpoint_lvl,
+                   with_out_proj):
+    assert checkpoint_lvl in (0, 1)
+    if A.is_complex():
+        raise RuntimeError("mamba_inner_fn: complex A is not supported (not on the MM-UNet path)")
+    d_state = A.shape[-1]
+    ac = _autocast_dtype()
+    if ac is not None:  # :169-171, :307-312
+        x_proj_weight = x_proj_weight.to(dtype=ac)
+        delta_proj_weight = delta_proj_weight.to(dtype=ac)
+        if with_out_proj:
+            out_proj_weight = out_proj_weight.to(dtype=ac)
+            out_proj_bias = out_proj_bias.to(dtype=ac) if out_proj_bias is not None else None
+    xz = _unit_l(xz)
+    conv1d_weight = conv1d_weight.view(conv1d_weight.shape[0], conv1d_weight.shape[-1])  # "d 1 w -> d w"
+    x, z = xz.chunk(2, dim=1)
+    conv1d_bias = conv1d_bias.contiguous() if conv1d_bias is not None else None
+    conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
+    ctx.is_variable_B = B is None
+    ctx.is_variable_C = C is None
+    ctx.B_proj_bias_is_None = B_proj_bias is None
+    ctx.C_proj_bias_is_None = C_proj_bias is None
+    x_dbl, delta, B, C = _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias,
+                                  C_proj_bias)
+    if D is not None:
+        D = D.contiguous()
+    out, scan_intermediates, out_z = selective_scan_hip.fwd(conv1d_out, delta, A, B, C, D, z, delta_bias,
+                                                            delta_softplus)
+    ctx.delta_softplus = delta_softplus
+    ctx.checkpoint_lvl = checkpoint_lvl
+    ctx.with_out_proj = with_out_proj
+    ctx.out_proj_bias_is_None = out_proj_bias is None
+    if checkpoint_lvl >= 1:  # recomputed in the backward pass
+        conv1d_out, delta = None, None
+    ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight,
+                          out_proj_weight if with_out_proj else None, conv1d_out, delta, A, B, C, D, delta_bias,
+                          scan_intermediates)
+    if not with_out_proj:
+        return out_z
+    return F.linear(out_z.permute(0, 2, 1), out_proj_weight, out_proj_bias)  # (B, L, d_model)
+
+
+def _inner_backward(ctx, dout):
+    (xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv1d_out, delta,
+     A, B, C, D, delta_bias, scan_intermediates) = ctx.saved_tensors
+    batch, _, L = xz.shape
+    r = delta_proj_weight.shape[1]
+    d_state = A.shape[-1]
+    x, z = xz.chunk(2, dim=1)
+    dim = x.shape[1]
+    if ctx.checkpoint_lvl == 1:
+        conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
+        delta = (delta_proj_weight @ x_dbl[:, :r].t()).view(dim, batch, L).permute(1, 0, 2)
+    dxz = torch.empty_like(xz)
+    dx, dz = dxz.chunk(2, dim=1)
+    if ctx.with_out_proj:
+        # dout: (B, L, E) -> (E, B*L); dy = W_out^T dout as (B, D, L) laid out [D][B][L]   (:387-388)
+        dout_m = dout.reshape(batch * L, -1).t()
+        dout_y = (out_proj_weight.t() @ dout_m).view(dim, batch, L).permute(1, 0, 2)
+    else:
+        dout_m = None
+        dout_y = _unit_l(dout)
+    dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = selective_scan_hip.bwd(
+        conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz, ctx.delta_softplus,
+        ctx.with_out_proj)[:9] if ctx.with_out_proj else (
+        *selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz,
+                                ctx.delta_softplus, False), None)
+    dout_proj_weight = dout_proj_bias = None
+    if ctx.with_out_proj:
+        dout_proj_weight = dout_m @ _dbl_view(out_z).t()  # (E, D)            (:394)
+        dout_proj_bias = dout.sum(dim=(0, 1)) if not ctx.out_proj_bias_is_None else None
+    dx_dbl = torch.empty_like(x_dbl)
+    dB_proj_bias = dC_proj_bias = None
+    if ctx.is_variable_B:
+        dBm = dB.squeeze(1).permute(0, 2, 1).reshape(batch * L, d_state)
+        dB_proj_bias = dBm.sum(0) if not ctx.B_proj_bias_is_None else None
+        dx_dbl[:, r:r + d_state] = dBm
+        dB = None
+    if ctx.is_variable_C:
+        dCm = dC.squeeze(1).permute(0, 2, 1).reshape(batch * L, d_state)
+        dC_proj_bias = dCm.sum(0) if not ctx.C_proj_bias_is_None else None
+        dx_dbl[:, -d_state:] = dCm
+        dC = None
+    ddelta_m = _dbl_view(ddelta)                                   # (D, B*L)
+    ddelta_proj_weight = ddelta_m @ x_dbl[:, :r]                    # (D, r)           (:273)
+    dx_dbl[:, :r] = ddelta_m.t() @ delta_proj_weight                # (B*L, r)         (:274)
+    dconv_m = _dbl_view(dconv1d_out)                                # (D, B*L)
+    dx_proj_weight = dx_dbl.t() @ _dbl_view(conv1d_out).t()         # (r+2N, D)        (:276)
+    if dconv_m.data_ptr() == dconv1d_out.data_ptr():
+        dconv_m.addmm_(x_proj_weight.t(), dx_dbl.t())               # in place         (:277)
+    else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
+        dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dbl.t())
+    dconv1d_out = dconv_m.view(dim, batch, L).permute(1, 0, 2)
+    dx, dconv1d_weight, dconv1d_bias = causal_conv1d_hip.causal_conv1d_bwd(x, conv1d_weight, conv1d_bias,
+                                                                           dconv1d_out, dx, True)
+    dconv1d_bias = dconv1d_bias if conv1d_bias is not None else None
+    dconv1d_weight = dconv1d_weight.unsqueeze(1)  # "d w -> d 1 w"
+    return dict(dxz=dxz, dconv1d_weight=dconv1d_weight, dconv1d_bias=dconv1d_bias, dx_proj_weight=dx_proj_weight,
+                ddelta_proj_weight=ddelta_proj_weight, dout_proj_weight=dout_proj_weight,
+                dout_proj_bias=dout_proj_bias, dA=dA, dB=dB, dC=dC, dD=dD if D is not None else None,
+                ddelta_bias=ddelta_bias if delta_bias is not None else None, dB_proj_bias=dB_proj_bias,
+                dC_proj_bias=dC_proj_bias)
+
+
+class MambaInnerFnNoOutProj(torch.autograd.Function):
+    """selective_scan_interface.py:155-289 -- returns out_z (batch, dim, L)."""
+
+    @staticmethod
+    @custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None, D=None,
+                delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1):
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A,
+                              B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, checkpoint_lvl, False)
+
+    @staticmethod
+    @custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv1d_weight"], g["dconv1d_bias"], g["dx_proj_weight"], g["ddelta_proj_weight"],
+                g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"], None,
+                None)
+
+
+class MambaInnerFn(torch.autograd.Function):
+    """selective_scan_interface.py:292-434 -- returns out_proj(out_z) (batch, L, d_model)."""
+
+    @staticmethod
+    @custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                out_proj_bias, A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                delta_softplus=True, checkpoint_lvl=1):
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                              out_proj_weight, out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
+                              delta_softplus, checkpoint_lvl, True)
+
+    @staticmethod
+    @custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv1d_weight"], g["dconv1d_bias"], g["dx_proj_weight"], g["ddelta_proj_weight"],
+                g["dout_proj_weight"], g["dout_proj_bias"], g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"],
+                g["dB_proj_bias"], g["dC_proj_bias"], None, None)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                   out_proj_bias, A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                   delta_softplus=True):
+    return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
+                               D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C,
+                                       D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                     out_proj_bias, A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                     C_proj_bias=None, delta_softplus=True):
+    """Shared-projection bidirectional variant (selective_scan_interface.py:437-603; exported by the
+    reference, not called by MM-UNet).  Built from the differentiable primitives following
+    bimamba_inner_ref (:673-709): one conv + projection, a forward scan with A and a scan over the
+    flipped sequence with A_b, summed, then out_proj."""
+    from .causal_conv1d_interface import causal_conv1d_fn
+    ac = _autocast_dtype()
+    if ac is not None:
+        x_proj_weight, delta_proj_weight = x_proj_weight.to(ac), delta_proj_weight.to(ac)
+        out_proj_weight = out_proj_weight.to(ac)
+        out_proj_bias = out_proj_bias.to(ac) if out_proj_bias is not None else None
+    d_state = A.shape[-1]
+    x, z = _unit_l(xz).chunk(2, dim=1)
+    x = causal_conv1d_fn(x, conv1d_weight.view(conv1d_weight.shape[0], -1), conv1d_bias, "silu")
+    _, delta, B, C = _project(x, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias)
+    y = selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
+    y_b = selective_scan_fn(x.flip([-1]), delta.flip([-1]), A_b, B.flip([-1]), C.flip([-1]), D, z.flip([-1]),
+                            delta_bias, delta_softplus=delta_softplus)
+    y = y + y_b.flip([-1])
+    return F.linear(y.permute(0, 2, 1), out_proj_weight, out_proj_bias)
+
+
+class BiMambaInnerFn:
+    """Name kept for API parity (selective_scan_interface.py:437); ``apply`` forwards to
+    :func:`bimamba_inner_fn` (autograd comes from the primitives it is built of)."""
+
+    @staticmethod
+    def apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A,
+              A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+              delta_softplus=True, checkpoint_lvl=1):
+        return bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                                out_proj_bias, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
+                                delta_softplus)

@@ -1,0 +1,8 @@
+"""Import alias: the package lives in ``mm-unet_amd/`` (not a valid Python identifier)."""
+import os as _os
+
+_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mm-unet_amd")
+__path__ = [_real]
+with open(_os.path.join(_real, "__init__.py")) as _f:
+    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+del _f

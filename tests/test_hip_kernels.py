@@ -1,0 +1,348 @@
+"""GPU parity tests for the hand-written kernels, called through the extension-shaped host
+modules (which call the C-ABI): HIP result vs (a) the committed golden vectors produced by the
+reference's own *_ref functions, (b) the CPU oracle on seeded inputs, (c) size-independent
+properties at BASELINE.json's full sizes.
+
+Tolerances are the reference's fp32 ones (tests/ops/test_selective_scan.py:45-51,137-149;
+tests/test_causal_conv1d.py:31-34); forward outputs are additionally held to the north-star
+bound of 1e-3 absolute.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+
+SCAN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "scan_*.npz")))
+CONV = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "conv1d_*.npz")))
+RTOL, ATOL = 6e-4, 2e-3
+RTOLW, ATOLW = 1e-3, 2e-3
+DEV = "cuda:0"
+
+
+def _g(g, k):
+    return torch.from_numpy(g[k]).to(DEV) if k in g else None
+
+
+def close(a, b, rtol, atol, what):
+    a = torch.as_tensor(a).detach().float().cpu()
+    b = torch.as_tensor(b).detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{what}: max abs err {err:.3e}"
+    return err
+
+
+def _bc4(t):
+    return t if t.dim() == 4 else t.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------- wave primitives
+@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wave_affine_scan(reverse, variant):
+    import ctypes
+    from mm_unet_amd import _lib
+    nw = 7
+    gen = torch.Generator().manual_seed(3)
+    P = (0.5 + 0.5 * torch.rand(nw * 64, generator=gen)).to(DEV)
+    S = torch.randn(nw * 64, generator=gen).to(DEV)
+    oP, oS = torch.empty_like(P), torch.empty_like(S)
+    _lib.check(_lib.lib().mmu_debug_wave_scan(P.data_ptr(), S.data_ptr(), oP.data_ptr(), oS.data_ptr(), nw,
+                                              reverse, variant, _lib.stream_of(P)))
+    torch.cuda.synchronize()
+    p, s = P.cpu().double().view(nw, 64), S.cpu().double().view(nw, 64)
+    if reverse:
+        p, s = p.flip(1), s.flip(1)
+    ep, es = torch.empty_like(p), torch.empty_like(s)
+    cp, cs = torch.ones(nw, dtype=torch.double), torch.zeros(nw, dtype=torch.double)
+    for i in range(64):
+        cs = p[:, i] * cs + s[:, i]
+        cp = cp * p[:, i]
+        ep[:, i], es[:, i] = cp, cs
+    if reverse:
+        ep, es = ep.flip(1), es.flip(1)
+    close(oP.view(nw, 64), ep.float(), 1e-5, 1e-6, "P")
+    close(oS.view(nw, 64), es.float(), 1e-5, 1e-5, "S")
+
+
+# --------------------------------------------------------------------------- selective scan
+def _run_fwd(g):
+    from mm_unet_amd import selective_scan_hip as ss
+    u, delta, A, B, C = (_g(g, k) for k in ("u", "delta", "A", "B", "C"))
+    res = ss.fwd(u, delta, A, _bc4(B), _bc4(C), _g(g, "D"), _g(g, "z"), _g(g, "delta_bias"), bool(g["softplus"]))
+    torch.cuda.synchronize()
+    return res
+
+
+@pytest.mark.parametrize("name", SCAN)
+def test_scan_fwd_golden(name):
+    g = golden(name)
+    res = _run_fwd(g)
+    out = res[2] if "z" in g else res[0]
+    err = close(out, g["out"], RTOL, ATOL, "out")
+    assert err <= 1e-3 * max(1.0, float(np.abs(g["out"]).max())), f"north-star 1e-3 bound exceeded: {err}"
+    x = res[1]
+    close(x[:, :, -1, 1::2], g["last_state"], RTOL, ATOL, "last_state")
+
+
+@pytest.mark.parametrize("name", SCAN)
+@pytest.mark.parametrize("pass_x", [True, False])
+def test_scan_bwd_golden(name, pass_x):
+    from mm_unet_amd import selective_scan_hip as ss
+    g = golden(name)
+    u, delta, A, B, C = (_g(g, k) for k in ("u", "delta", "A", "B", "C"))
+    D, z, bias, dout = (_g(g, k) for k in ("D", "z", "delta_bias", "dout"))
+    sp = bool(g["softplus"])
+    res = ss.fwd(u, delta, A, _bc4(B), _bc4(C), D, z, bias, sp)
+    r = ss.bwd(u, delta, A, _bc4(B), _bc4(C), D, z, bias, dout, res[1] if pass_x else None, res[0], None, sp,
+               z is not None)
+    torch.cuda.synchronize()
+    du, ddelta, dA, dB, dC, dD, dbias = r[:7]
+    close(du, g["du"], RTOL * 2, ATOL * 2, "du")
+    close(ddelta, g["ddelta"], RTOL * 5, ATOL * 10, "ddelta")
+    close(dA, g["dA"], RTOLW, ATOLW * 5, "dA")
+    close(dB.reshape(g["dB"].shape), g["dB"], RTOL, ATOL, "dB")
+    close(dC.reshape(g["dC"].shape), g["dC"], RTOL, ATOL, "dC")
+    if "dD" in g:
+        close(dD, g["dD"], RTOLW, ATOLW, "dD")
+    if "ddelta_bias" in g:
+        close(dbias, g["ddelta_bias"], RTOLW, ATOLW, "ddelta_bias")
+    if "dz" in g:
+        close(r[7], g["dz"], RTOLW, ATOLW, "dz")
+        close(r[8], g["out"], RTOL, ATOL, "recomputed out_z")
+
+
+def _rand_case(b, d, l, n, seed, device=DEV):
+    gen = torch.Generator().manual_seed(seed)
+    A = -0.5 * torch.rand(d, n, generator=gen)
+    B = torch.randn(b, 1, n, l, generator=gen)
+    C = torch.randn(b, 1, n, l, generator=gen)
+    D = torch.randn(d, generator=gen)
+    z = torch.randn(b, d, l, generator=gen)
+    bias = 0.5 * torch.rand(d, generator=gen)
+    u = torch.randn(b, d, l, generator=gen)
+    delta = 0.5 * torch.rand(b, d, l, generator=gen)
+    dout = torch.randn(b, d, l, generator=gen)
+    return dict(u=u, delta=delta, A=A, B=B, C=C, D=D, z=z, delta_bias=bias, dout=dout)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 1024, 16), (2, 6, 4099, 16), (1, 128, 2048, 16), (2, 2, 256, 16),
+                                   (1, 8, 777, 64), (1, 4, 300, 128), (3, 5, 130, 8)])
+def test_scan_fwd_bwd_vs_oracle_mamba_layout(shape):
+    """Seeded inputs in the layout mamba_inner hands over: u, delta, z are physically [D][B][L]
+    (strides (L, B*L, 1)), SURVEY.md section 8a-5."""
+    import oracle
+    from mm_unet_amd import selective_scan_hip as ss
+    b, d, l, n = shape
+    c = _rand_case(b, d, l, n, seed=11)
+
+    def dbl(t):  # [D][B][L] physical, viewed as (B, D, L)
+        return t.permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)
+
+    u, delta, z, dout = dbl(c["u"]), dbl(c["delta"]), dbl(c["z"]), dbl(c["dout"])
+    assert b == 1 or u.stride() == (l, b * l, 1)
+    A, B, C, D, bias = (c[k].to(DEV) for k in ("A", "B", "C", "D", "delta_bias"))
+    res = ss.fwd(u, delta, A, B, C, D, z, bias, True)
+    assert b == 1 or (res[0].stride() == delta.stride() and res[2].stride() == z.stride())
+    o_out, o_outz, o_last = oracle.selective_scan_fwd(c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"],
+                                                      c["delta_bias"], True)
+    close(res[0], o_out, RTOL, ATOL, "out")
+    close(res[2], o_outz, RTOL, ATOL, "out_z")
+    close(res[1][:, :, -1, 1::2], o_last, RTOL, ATOL, "last_state")
+    # dz given as a pre-allocated strided view (selective_scan_interface.py:244-251)
+    dxz = torch.empty(2 * d, b, l, device=DEV).permute(1, 0, 2)
+    dz_view = dxz[:, d:, :]
+    r = ss.bwd(u, delta, A, B, C, D, z, bias, dout, res[1], res[0], dz_view, True, True)
+    og = oracle.selective_scan_bwd(c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"],
+                                   c["dout"], True)
+    assert r[7].data_ptr() == dz_view.data_ptr()
+    close(r[0], og["du"], RTOL * 2, ATOL * 2, "du")
+    close(r[1], og["ddelta"], RTOL * 5, ATOL * 10, "ddelta")
+    close(r[2], og["dA"], RTOLW, ATOLW * 5 * max(1, l // 1024), "dA")
+    close(r[3], og["dB"], RTOL, ATOL, "dB")
+    close(r[4], og["dC"], RTOL, ATOL, "dC")
+    close(r[5], og["dD"], RTOLW, ATOLW * max(1, l // 1024), "dD")
+    close(r[6], og["ddelta_bias"], RTOLW, ATOLW * max(1, l // 1024), "ddelta_bias")
+    close(r[7], og["dz"], RTOLW, ATOLW, "dz")
+    close(r[8], o_outz, RTOL, ATOL, "out_z (recomputed)")
+
+
+def test_scan_bwd_reproducibility():
+    """du, ddelta, dz, dA, dD, ddelta_bias are bit-identical run to run (no global atomics anywhere);
+    dB/dC are summed over channels with LDS float atomics whose order across waves is not fixed,
+    so they are only required to agree to fp32 rounding (the reference uses global atomics for all
+    of dA/dB/dC/dD/dbias, selective_scan_bwd_kernel.cuh:312-313,469-487)."""
+    from mm_unet_amd import selective_scan_hip as ss
+    c = {k: v.to(DEV) for k, v in _rand_case(2, 6, 2048, 16, seed=5).items()}
+    res = ss.fwd(c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"], True)
+    outs = []
+    for _ in range(3):
+        r = ss.bwd(c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"], c["dout"], res[1],
+                   res[0], None, True, False)
+        outs.append([t.clone() for t in r[:8]])
+    names = ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz"]
+    for other in outs[1:]:
+        for nm, a, b_ in zip(names, outs[0], other):
+            if nm in ("dB", "dC"):
+                close(a, b_, 1e-5, 1e-5, nm)
+            else:
+                assert torch.equal(a, b_), f"{nm} is not run-to-run bit-identical"
+
+
+def test_scan_full_size_properties():
+    """BASELINE headline shape (B=8, D=128, L=65536, N=16): causality (a prefix of the output
+    depends only on the prefix of the input), linearity in u, and a 3-channel spot check
+    against the oracle."""
+    import oracle
+    from mm_unet_amd import selective_scan_hip as ss
+    b, d, l, n = 8, 128, 65536, 16
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    A = -0.5 * torch.rand(d, n, device=DEV, generator=gen)
+    B = torch.randn(b, 1, n, l, device=DEV, generator=gen)
+    C = torch.randn(b, 1, n, l, device=DEV, generator=gen)
+    D = torch.randn(d, device=DEV, generator=gen)
+    z = torch.randn(b, d, l, device=DEV, generator=gen)
+    bias = 0.5 * torch.rand(d, device=DEV, generator=gen)
+    u = torch.randn(b, d, l, device=DEV, generator=gen)
+    delta = 0.5 * torch.rand(b, d, l, device=DEV, generator=gen)
+    out, x, out_z = ss.fwd(u, delta, A, B, C, D, z, bias, True)
+    # causality
+    lp = 4096 + 256
+    out_p, _, out_z_p = ss.fwd(u[..., :lp].contiguous(), delta[..., :lp].contiguous(), A,
+                               B[..., :lp].contiguous(), C[..., :lp].contiguous(), D, z[..., :lp].contiguous(), bias,
+                               True)
+    close(out[..., :lp], out_p, 1e-5, 1e-5, "causality(out)")
+    close(out_z[..., :lp], out_z_p, 1e-5, 1e-5, "causality(out_z)")
+    # linearity in u (delta fixed): out(2u) == 2 out(u)
+    out2, _, _ = ss.fwd(2 * u, delta, A, B, C, D, z, bias, True)
+    close(out2, 2 * out, 1e-4, 1e-4, "linearity")
+    # oracle spot check on batch 3, channels 0, 77, 127
+    sel = [0, 77, 127]
+    o_out, o_outz, o_last = oracle.selective_scan_fwd(u[3:4, sel].cpu(), delta[3:4, sel].cpu(), A[sel].cpu(),
+                                                      B[3:4].cpu(), C[3:4].cpu(), D[sel].cpu(), z[3:4, sel].cpu(),
+                                                      bias[sel].cpu(), True)
+    close(out_z[3:4, sel], o_outz, RTOL, ATOL, "out_z vs oracle")
+    close(x[3:4, sel, -1, 1::2], o_last, RTOL, ATOL, "last_state vs oracle")
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 1024, 16), (1, 128, 1024, 16)])
+def test_scan_bf16_io(shape):
+    """bf16 I/O contract: u, delta, z, B, C, out in bf16; A, D, bias, states fp32."""
+    import oracle
+    from mm_unet_amd import selective_scan_hip as ss
+    b, d, l, n = shape
+    c = _rand_case(b, d, l, n, seed=2)
+    q = {k: (v.bfloat16() if k in ("u", "delta", "z", "B", "C", "dout") else v) for k, v in c.items()}
+    g = {k: v.to(DEV) for k, v in q.items()}
+    res = ss.fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["z"], g["delta_bias"], True)
+    assert res[2].dtype == torch.bfloat16 and res[1].dtype == torch.float32
+    f = {k: v.float() for k, v in q.items()}
+    _, o_outz, _ = oracle.selective_scan_fwd(f["u"], f["delta"], f["A"], f["B"], f["C"], f["D"], f["z"],
+                                             f["delta_bias"], True)
+    close(res[2], o_outz, 3e-2, 5e-2, "out_z (bf16)")
+    r = ss.bwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["z"], g["delta_bias"], g["dout"], res[1],
+               res[0], None, True, False)
+    og = oracle.selective_scan_bwd(f["u"], f["delta"], f["A"], f["B"], f["C"], f["D"], f["z"], f["delta_bias"],
+                                   f["dout"], True)
+    close(r[0], og["du"], 6e-2, 1e-1, "du (bf16)")
+    close(r[2], og["dA"], 3e-2, 5e-1, "dA (bf16)")
+    assert r[3].dtype == torch.bfloat16
+
+
+def test_scan_rejects_bad_arguments():
+    from mm_unet_amd import selective_scan_hip as ss
+    c = {k: v.to(DEV) for k, v in _rand_case(1, 4, 64, 16, seed=1).items()}
+    with pytest.raises(RuntimeError):
+        ss.fwd(c["u"].cpu(), c["delta"], c["A"], c["B"], c["C"], None, None, None, False)
+    with pytest.raises(RuntimeError):
+        ss.fwd(c["u"], c["delta"][..., :32], c["A"], c["B"], c["C"], None, None, None, False)
+    with pytest.raises(RuntimeError):
+        ss.fwd(c["u"].transpose(1, 2).contiguous().transpose(1, 2), c["delta"], c["A"], c["B"], c["C"], None, None,
+               None, False)
+    with pytest.raises(RuntimeError):  # dstate > 128
+        ss.fwd(c["u"], c["delta"], torch.zeros(4, 200, device=DEV), torch.zeros(1, 1, 200, 64, device=DEV),
+               torch.zeros(1, 1, 200, 64, device=DEV), None, None, None, False)
+
+
+# --------------------------------------------------------------------------- causal conv1d
+@pytest.mark.parametrize("name", CONV)
+def test_conv1d_golden(name):
+    from mm_unet_amd import causal_conv1d_hip as cc
+    g = golden(name)
+    silu = bool(g["silu"])
+    x, w, b, dout = _g(g, "x"), _g(g, "weight"), _g(g, "bias"), _g(g, "dout")
+    out = cc.causal_conv1d_fwd(x, w, b, silu)
+    close(out, g["out"], 3e-4, 1e-3, "out")
+    dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, None, silu)
+    close(dx, g["dx"], 3e-4, 1e-3, "dx")
+    close(dw, g["dweight"], 1e-3, 1e-3, "dweight")
+    if "dbias" in g:
+        close(db, g["dbias"], 1e-3, 1e-3, "dbias")
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 4099), (2, 12, 1024), (1, 256, 2048), (3, 4, 3)])
+def test_conv1d_vs_oracle_strided(shape):
+    """x is the first half of an xz tensor laid out [2D][B][L] (selective_scan_interface.py:175);
+    dx is written into a view of dxz (:244-245,281-283)."""
+    import oracle
+    from mm_unet_amd import causal_conv1d_hip as cc
+    b, d, l = shape
+    gen = torch.Generator().manual_seed(7)
+    xz = torch.randn(2 * d, b, l, generator=gen)
+    w = torch.randn(d, 4, generator=gen)
+    bias = torch.randn(d, generator=gen)
+    dout = torch.randn(b, d, l, generator=gen)
+    xz_g = xz.to(DEV).permute(1, 0, 2)
+    x_g = xz_g[:, :d]
+    out = cc.causal_conv1d_fwd(x_g, w.to(DEV), bias.to(DEV), True)
+    x_c = xz.permute(1, 0, 2)[:, :d].contiguous()
+    close(out, oracle.causal_conv1d_fwd(x_c, w, bias, True), 3e-4, 1e-3, "out")
+    dxz = torch.zeros(2 * d, b, l, device=DEV).permute(1, 0, 2)
+    dx_view = dxz[:, :d]
+    dx, dw, db = cc.causal_conv1d_bwd(x_g, w.to(DEV), bias.to(DEV), dout.to(DEV), dx_view, True)
+    odx, odw, odb = oracle.causal_conv1d_bwd(x_c, w, bias, dout, True)
+    assert dx.data_ptr() == dx_view.data_ptr()
+    close(dx, odx, 3e-4, 1e-3, "dx")
+    close(dw, odw, 1e-3, 1e-3 * max(1, l // 512), "dweight")
+    close(db, odb, 1e-3, 1e-3 * max(1, l // 512), "dbias")
+    assert float(dxz[:, d:].abs().max()) == 0.0, "conv1d bwd wrote outside its dx view"
+
+
+def test_conv1d_update_matches_reference_semantics():
+    """causal_conv1d_update_ref (causal_conv1d_interface.py:83-104): roll, append, dot, silu."""
+    from mm_unet_amd import causal_conv1d_hip as cc
+    gen = torch.Generator().manual_seed(9)
+    b, d, w = 3, 70, 4
+    x = torch.randn(b, d, generator=gen)
+    state = torch.randn(b, d, w, generator=gen)
+    weight = torch.randn(d, w, generator=gen)
+    bias = torch.randn(d, generator=gen)
+    st = state.clone()
+    st = torch.roll(st, shifts=-1, dims=-1)
+    st[:, :, -1] = x
+    ref = torch.nn.functional.silu((st * weight).sum(-1) + bias)
+    sg = state.to(DEV)
+    out = cc.causal_conv1d_update(x.to(DEV), sg, weight.to(DEV), bias.to(DEV), True)
+    close(out, ref, 1e-4, 1e-4, "out")
+    assert torch.equal(sg.cpu(), st), "conv_state not rolled exactly"
+
+
+def test_conv1d_full_size_shift_property():
+    """(B=8, D=128, L=65536): causal conv of a sequence delayed by 4 tokens equals the delayed
+    output (time invariance), and bias-free/no-activation conv is linear."""
+    from mm_unet_amd import causal_conv1d_hip as cc
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(8, 128, 65536, device=DEV, generator=gen)
+    w = torch.randn(128, 4, device=DEV, generator=gen)
+    out = cc.causal_conv1d_fwd(x, w, None, False)
+    xs = torch.zeros_like(x)
+    xs[..., 4:] = x[..., :-4]
+    outs = cc.causal_conv1d_fwd(xs, w, None, False)
+    close(outs[..., 4:], out[..., :-4], 1e-6, 1e-6, "shift invariance")
+    close(cc.causal_conv1d_fwd(3 * x, w, None, False), 3 * out, 1e-5, 1e-5, "linearity")
