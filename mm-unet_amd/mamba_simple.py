@@ -1,0 +1,157 @@
+"""``Mamba`` block with the reference's patched interface (requirements/mamba_simple.py:34-362):
+uni- ("none"/"v1"), bi- ("v2") and tri-directional ("v3") selective scan, 4-tuple return.
+
+Parameter names, shapes, creation order (hence RNG draw order under ``torch.manual_seed``) and
+initialisers are those of the reference, so reference state_dicts load and identical seeds give
+identical weights (mamba_simple.py:69-183):
+
+    in_proj, conv1d, x_proj, dt_proj (special dt init :89-108), A_log, D,
+    A_b_log, conv1d_b, x_proj_b, dt_proj_b, D_b, A_s_log, conv1d_s, x_proj_s, dt_proj_s, D_s, out_proj
+
+The shipped reference is inconsistent about ``bimamba_type`` (``assert == "v3"`` at :125 while
+MMConv passes "v1", MMUNet.py:32, and the tuple return at :362 only binds o_1..o_3 in the v3
+branch).  Resolution: every type constructs; "none"/"v1" run the
+uni-directional branch (:303-318) and return ``(out, None, None, None)``; "v2" runs forward +
+reversed (:272-302) and returns ``(out, None, None, None)``; "v3" returns
+``(out, o_1, o_2, o_3)`` exactly as :267-270 (o_2 stays in reversed token order).
+
+Not provided (never reached from MM-UNet): ``step`` / inference cache, the ``Block`` wrapper.
+The compute goes through the HIP kernels only (no CPU path).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .causal_conv1d_interface import causal_conv1d_fn
+from .selective_scan_interface import mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn
+
+
+class Mamba(nn.Module):
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False, use_fast_path=True,
+                 layer_idx=None, device=None, dtype=None, bimamba_type="none", nslices=5):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        if bimamba_type not in ("none", "v1", "v2", "v3"):
+            raise ValueError(f"unknown bimamba_type {bimamba_type!r}")
+        self.d_model = d_model
+        self.d_state = d_state
+        self.d_conv = d_conv
+        self.expand = expand
+        self.d_inner = int(self.expand * self.d_model)
+        self.dt_rank = math.ceil(self.d_model / 16) if dt_rank == "auto" else dt_rank
+        self.use_fast_path = use_fast_path
+        self.layer_idx = layer_idx
+        self.bimamba_type = bimamba_type
+        self.nslices = nslices
+        self.activation = "silu"
+
+        def conv():
+            return nn.Conv1d(self.d_inner, self.d_inner, kernel_size=d_conv, groups=self.d_inner,
+                             padding=d_conv - 1, bias=conv_bias, **factory_kwargs)
+
+        def a_log():
+            a = torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device)
+            p = nn.Parameter(torch.log(a.repeat(self.d_inner, 1).contiguous()))  # S4D-real, fp32
+            p._no_weight_decay = True
+            return p
+
+        def skip():
+            p = nn.Parameter(torch.ones(self.d_inner, device=device))  # fp32
+            p._no_weight_decay = True
+            return p
+
+        self.in_proj = nn.Linear(self.d_model, self.d_inner * 2, bias=bias, **factory_kwargs)
+        self.conv1d = conv()
+        self.act = nn.SiLU()
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+        # dt projection init: weight ~ U(+-dt_rank^-0.5 * scale); bias = softplus^-1(dt), dt log-uniform
+        dt_init_std = self.dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(self.dt_proj.weight, dt_init_std)
+        elif dt_init == "random":
+            nn.init.uniform_(self.dt_proj.weight, -dt_init_std, dt_init_std)
+        else:
+            raise NotImplementedError
+        dt = torch.exp(torch.rand(self.d_inner, **factory_kwargs) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        inv_dt = dt + torch.log(-torch.expm1(-dt))
+        with torch.no_grad():
+            self.dt_proj.bias.copy_(inv_dt)
+        self.dt_proj.bias._no_reinit = True
+        self.A_log = a_log()
+        self.D = skip()
+        # reversed-direction branch (default nn.Linear init for dt_proj_b, mamba_simple.py:149)
+        self.A_b_log = a_log()
+        self.conv1d_b = conv()
+        self.x_proj_b = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj_b = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+        self.D_b = skip()
+        # slice-interleaved ("spatial") branch
+        self.A_s_log = a_log()
+        self.conv1d_s = conv()
+        self.x_proj_s = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj_s = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+        self.D_s = skip()
+        self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
+
+    def _branch(self, xz, suffix):
+        g = lambda n: getattr(self, n + suffix)  # noqa: E731
+        A = -torch.exp(getattr(self, {"": "A_log", "_b": "A_b_log", "_s": "A_s_log"}[suffix]).float())
+        return mamba_inner_fn_no_out_proj(xz, g("conv1d").weight, g("conv1d").bias, g("x_proj").weight,
+                                          g("dt_proj").weight, A, None, None, g("D").float(),
+                                          delta_bias=g("dt_proj").bias.float(), delta_softplus=True)
+
+    def forward(self, hidden_states, inference_params=None):
+        """hidden_states: (B, L, D) -> (out (B, L, D), o_1, o_2, o_3)."""
+        if inference_params is not None:
+            raise NotImplementedError("incremental decoding (inference_params/step) is outside the MM-UNet path")
+        batch, seqlen, dim = hidden_states.shape
+        # in_proj fused with the BLD -> [2*d_inner][B][L] transpose (mamba_simple.py:201-205)
+        xz = (self.in_proj.weight @ hidden_states.reshape(batch * seqlen, dim).t()) \
+            .view(2 * self.d_inner, batch, seqlen).permute(1, 0, 2)
+        if self.in_proj.bias is not None:
+            xz = xz + self.in_proj.bias.to(dtype=xz.dtype).view(1, -1, 1)
+        o_1 = o_2 = o_3 = None
+        if self.use_fast_path:
+            if self.bimamba_type == "v3":
+                if seqlen % self.nslices != 0:
+                    raise RuntimeError(f"Mamba v3: seqlen {seqlen} must be divisible by nslices {self.nslices}")
+                out = self._branch(xz, "")
+                out_b = self._branch(xz.flip([-1]), "_b")
+                # token i of slice s -> position i*nslices + s   (mamba_simple.py:245-247)
+                ns = self.nslices
+                xz_s = xz.reshape(batch, 2 * self.d_inner, ns, seqlen // ns).transpose(-1, -2) \
+                    .reshape(batch, 2 * self.d_inner, seqlen)
+                out_s = self._branch(xz_s, "_s")
+                out_s = out_s.reshape(batch, self.d_inner, seqlen // ns, ns).permute(0, 1, 3, 2).flatten(-2)
+                o_1, o_2, o_3 = out, out_b, out_s
+                out = F.linear((out + out_b.flip([-1]) + out_s).permute(0, 2, 1), self.out_proj.weight,
+                               self.out_proj.bias)
+            elif self.bimamba_type == "v2":
+                out = self._branch(xz, "")
+                out_b = self._branch(xz.flip([-1]), "_b")
+                out = F.linear((out + out_b.flip([-1])).permute(0, 2, 1), self.out_proj.weight, self.out_proj.bias)
+            else:
+                A = -torch.exp(self.A_log.float())
+                out = mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                     self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, None, None,
+                                     self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+        else:
+            # un-fused path (mamba_simple.py:319-361), uni-directional
+            A = -torch.exp(self.A_log.float())
+            x, z = xz.chunk(2, dim=1)
+            x = causal_conv1d_fn(x, self.conv1d.weight.view(self.d_inner, self.d_conv), self.conv1d.bias,
+                                 self.activation)
+            x_dbl = self.x_proj(x.permute(0, 2, 1).reshape(batch * seqlen, self.d_inner))
+            dt, B, C = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+            dt = (self.dt_proj.weight @ dt.t()).view(self.d_inner, batch, seqlen).permute(1, 0, 2)
+            B = B.reshape(batch, seqlen, self.d_state).permute(0, 2, 1).contiguous()
+            C = C.reshape(batch, seqlen, self.d_state).permute(0, 2, 1).contiguous()
+            y = selective_scan_fn(x, dt, A, B, C, self.D.float(), z=z, delta_bias=self.dt_proj.bias.float(),
+                                  delta_softplus=True)
+            out = self.out_proj(y.permute(0, 2, 1))
+        return out, o_1, o_2, o_3

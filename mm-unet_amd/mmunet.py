@@ -1,0 +1,313 @@
+"""MM-UNet (``MM_Net``) and its blocks with the reference's module surface
+(src/UM_Net/MMUNet.py): ``MMConv`` (MorphMamba conv, :10-274), ``CBAM`` (:313-338),
+``SideoutBlock`` (:341-352), ``RCG`` (:354-418), ``DecoderBlock`` (:420-431),
+``ResidualBlock`` (:433-467), ``MM_Net`` (:474-585), ``HPPF`` (:278-310, defined but unused there).
+
+Sub-module names, creation order (RNG draw order) and parameter shapes are the reference's, so
+``state_dict`` keys match and equal seeds give equal weights -- including the parameters the
+reference creates but never uses (``MMConv.dsc_conv_y``, the ``_b``/``_s`` Mamba branches of "v1"
+blocks).  All Mamba compute goes through the HIP kernels; the remaining layers are ATen-ROCm ops.
+
+Differences from the reference, all deliberate:
+  * ``MMConv(device=...)`` defaults to ``None`` (build where you are, move with ``.to()``) instead of
+    the hard-coded ``"cuda"`` (:19,41-42); coordinate grids are created on the input's device.
+  * ``d_state`` is exposed on ``MMConv`` / ``RCG`` / ``MM_Net`` (reference hard-codes 16, :29,355) for
+    BASELINE config 5 (d_state=64).
+  * the constructor does not print.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .mamba_simple import Mamba
+
+
+class MMConv(nn.Module):
+    def __init__(self, in_channels: int = 1, out_channels: int = 1, kernel_size: int = 9, extend_scope: float = 1.0,
+                 morph: int = 0, if_offset: bool = True, device=None, num_slices=4, d_state=16):
+        super().__init__()
+        if morph not in (0, 1):
+            raise ValueError("morph should be 0 or 1.")
+        self.mamba = Mamba(d_model=kernel_size, d_state=d_state, d_conv=4, expand=2, bimamba_type="v1",
+                           nslices=num_slices)
+        self.kernel_size = kernel_size
+        self.extend_scope = extend_scope
+        self.morph = morph
+        self.if_offset = if_offset
+        if device is not None:
+            self.to(device)
+        self.gn_offset = nn.GroupNorm(kernel_size, 2 * kernel_size)
+        self.gn = nn.GroupNorm(out_channels // 4, out_channels)
+        self.relu = nn.ReLU(inplace=False)
+        self.tanh = nn.Tanh()
+        self.offset_conv = nn.Conv2d(in_channels, 2 * kernel_size, 3, padding=1)
+        self.dsc_conv_x = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1),
+                                    stride=(kernel_size, 1), padding=0)
+        self.dsc_conv_y = nn.Conv2d(in_channels, out_channels, kernel_size=(1, kernel_size),
+                                    stride=(1, kernel_size), padding=0)
+        self.altho = nn.Parameter(torch.log(torch.exp(torch.tensor(1.0)) - 1.0))
+
+    # -- token order of the scan: rows are paired, a pair is walked column by column
+    #    (2p,w),(2p+1,w),(2p,w+1)...; an odd last row is appended row-major (MMUNet.py:68-121)
+    @staticmethod
+    def two_row_columnwise_flatten_grad_safe(x):
+        B, C, H, W = x.shape
+        He = H // 2 * 2
+        flat = x[:, :, :He].reshape(B, C, He // 2, 2, W).permute(0, 1, 2, 4, 3).reshape(B, C, He * W)
+        if H % 2 == 1:
+            flat = torch.cat([flat, x[:, :, He:].reshape(B, C, -1)], dim=2)
+        return flat
+
+    @staticmethod
+    def inverse_two_row_columnwise_flatten(x_flat, H, W):
+        B, C, _ = x_flat.shape
+        He = H // 2 * 2
+        out = x_flat[:, :, :He * W].reshape(B, C, He // 2, W, 2).permute(0, 1, 2, 4, 3).reshape(B, C, He, W)
+        if H % 2 == 1:
+            out = torch.cat([out, x_flat[:, :, He * W:].reshape(B, C, 1, W)], dim=2)
+        return out
+
+    def get_coordinate_map_2D(self, offset, morph, extend_scope=1.0, device=None):
+        """Returns (y_map, x_map), each (B, H*K, W): sampling rows / columns of the K taps
+        (MMUNet.py:122-193).  Only the row (y) coordinate is learned."""
+        if morph not in (0, 1):
+            raise ValueError("morph should be 0 or 1.")
+        B, _, H, W = offset.shape
+        K = offset.shape[1] // 2
+        center = K // 2
+        dev = offset.device
+        y_off = offset[:, :K]  # x_offset (second half) is unused by the reference as well (:136)
+        rows = torch.arange(0, H, dtype=torch.float32, device=dev).view(1, 1, H, 1)
+        cols = torch.arange(0, W, dtype=torch.float32, device=dev).view(1, 1, 1, W)
+        x_spread = torch.linspace(-center, center, K, device=dev).view(1, K, 1, 1)
+        x_new = (cols + x_spread).expand(B, K, H, W)
+        # iterative offset: centre tap stays, taps further out accumulate (:162-170).  The reference
+        # writes these sums (built from the NON-detached offsets) into a detached clone, so gradient
+        # does flow through every non-centre tap; only the clone's initial values are cut off.
+        acc = [None] * K
+        acc[center] = torch.zeros_like(y_off[:, center])
+        for i in range(1, center + 1):
+            acc[center + i] = acc[center + i - 1] + y_off[:, center + i]
+            acc[center - i] = acc[center - i + 1] + y_off[:, center - i]
+        y_new = rows + torch.stack(acc, dim=1) * extend_scope
+        # Mamba over the offsets, tokens in two-row zig-zag order (:176-183)
+        seq = self.two_row_columnwise_flatten_grad_safe(y_off).transpose(-1, -2)
+        seq, _, _, _ = self.mamba(seq)
+        y_keep = self.inverse_two_row_columnwise_flatten(seq.transpose(-1, -2), H, W)
+        weight = torch.clamp(F.softplus(self.altho), min=0.01)
+        y = weight * y_keep + y_new
+        # "b k h w -> b (h k) w"
+        y_map = y.permute(0, 2, 1, 3).reshape(B, H * K, W)
+        x_map = x_new.permute(0, 2, 1, 3).reshape(B, H * K, W)
+        return y_map, x_map
+
+    @staticmethod
+    def _coordinate_map_scaling(coordinate_map, origin, target=(-1, 1)):
+        lo, hi = origin
+        a, b = target
+        return a + (b - a) / (hi - lo) * (torch.clamp(coordinate_map, lo, hi) - lo)
+
+    def get_interpolated_feature(self, input_feature, y_coordinate_map, x_coordinate_map, interpolate_mode="bilinear"):
+        if interpolate_mode not in ("bilinear", "bicubic"):
+            raise ValueError("interpolate_mode should be 'bilinear' or 'bicubic'.")
+        y_max = input_feature.shape[-2] - 1
+        x_max = input_feature.shape[-1] - 1
+        ys = self._coordinate_map_scaling(y_coordinate_map, origin=[0, y_max])
+        xs = self._coordinate_map_scaling(x_coordinate_map, origin=[0, x_max])
+        grid = torch.stack([xs, ys], dim=-1)  # (B, H*K, W, 2), last dim = (x, y)
+        return F.grid_sample(input_feature, grid, mode=interpolate_mode, padding_mode="zeros", align_corners=True)
+
+    def forward(self, input):
+        offset = self.tanh(self.gn_offset(self.offset_conv(input)))
+        y_map, x_map = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope)
+        deformed = self.get_interpolated_feature(input, y_map, x_map)
+        output = self.dsc_conv_x(deformed) if self.morph == 0 else self.dsc_conv_y(deformed)
+        return self.gn(output)
+
+
+class HPPF(nn.Module):
+    """MMUNet.py:278-310 (defined by the reference, not used by MM_Net)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.conv2 = nn.Sequential(nn.Conv2d(in_channels, in_channels // 64, 1, 1), nn.ReLU(inplace=True))
+        self.conv1 = nn.Sequential(MMConv(in_channels, in_channels // 16, num_slices=64, kernel_size=1),
+                                   nn.ReLU(inplace=True))
+        self.avg = nn.AdaptiveAvgPool2d(1)
+        self.max1 = nn.AdaptiveMaxPool2d(4)
+        self.max2 = nn.AdaptiveMaxPool2d(8)
+        self.mlp = nn.Sequential(nn.Conv2d(in_channels, in_channels // 8, kernel_size=1), nn.ReLU(inplace=True),
+                                 nn.Conv2d(in_channels // 8, in_channels, kernel_size=1), nn.Sigmoid())
+        self.feat_conv = nn.Sequential(nn.Conv2d(in_channels, in_channels // 3, 3, 1, 1),
+                                       nn.BatchNorm2d(in_channels // 3), nn.ReLU(inplace=True))
+
+    def forward(self, x1, x2, x3):
+        x2 = F.interpolate(x2, size=x1.size()[2:], mode="bilinear", align_corners=True)
+        x3 = F.interpolate(x3, size=x1.size()[2:], mode="bilinear", align_corners=True)
+        feat = torch.cat((x1, x2, x3), 1)
+        b, c, h, w = feat.size()
+        y1 = self.avg(feat)
+        y2 = self.conv1(self.max1(feat)).reshape(b, c, 1, 1)
+        y3 = self.conv2(self.max2(feat)).reshape(b, c, 1, 1)
+        attention = self.mlp((y1 + y2 + y3) / 3)
+        return self.feat_conv(attention * feat)
+
+
+class CBAM(nn.Module):
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.max_pool = nn.AdaptiveMaxPool2d(1)
+        self.mlp = nn.Sequential(nn.Conv2d(channel, channel // reduction, kernel_size=1, bias=False),
+                                 nn.ReLU(inplace=True),
+                                 nn.Conv2d(channel // reduction, channel, kernel_size=1, bias=False))
+        self.conv = nn.Conv2d(2, 1, kernel_size=7, stride=1, padding=3, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        c_out = self.sigmoid(self.mlp(self.avg_pool(x)) + self.mlp(self.max_pool(x)))
+        y1 = c_out * x
+        s_avg = torch.mean(y1, dim=1, keepdim=True)
+        s_max, _ = torch.max(y1, dim=1, keepdim=True)
+        s_out = self.sigmoid(self.conv(torch.cat((s_max, s_avg), 1)))
+        return s_out * y1
+
+
+class SideoutBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, num_slices=4, d_state=16):
+        super().__init__()
+        self.conv1 = nn.Sequential(MMConv(in_channels, in_channels // 4, num_slices=num_slices, kernel_size=3,
+                                          d_state=d_state),
+                                   nn.BatchNorm2d(in_channels // 4), nn.ReLU(inplace=True))
+        self.dropout = nn.Dropout2d(0.1)
+        self.conv2 = nn.Conv2d(in_channels // 4, out_channels, kernel_size=1)
+
+    def forward(self, x):
+        return self.conv2(self.dropout(self.conv1(x)))
+
+
+class RCG(nn.Module):
+    def __init__(self, d_state=16, d_conv=4, expand=2, head=4, num_slices=4, step=1):
+        super().__init__()
+        self.conv1 = nn.Sequential(MMConv(128, 64, num_slices=num_slices, kernel_size=3, d_state=d_state),
+                                   nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.upsample = nn.ConvTranspose2d(64, 64, kernel_size=4, stride=2, padding=1, output_padding=0)
+        self.downsample = nn.Conv2d(64, 64, kernel_size=4, stride=2, padding=1)
+        self.mamba = Mamba(d_model=64, d_state=d_state, d_conv=d_conv, expand=expand, bimamba_type="v3",
+                           nslices=num_slices)
+        self.mlp = nn.Sequential(nn.Conv2d(64, 1, kernel_size=1), nn.Sigmoid())
+
+    def forward(self, pre, edge, f):
+        r = (1 - torch.sigmoid(pre)) * f
+        edge1 = F.interpolate(edge, size=f.size()[2:], mode="bilinear", align_corners=True)
+        x2 = self.conv1(torch.cat((edge1, r), 1))
+        # tri-directional Mamba at 2x resolution (MMUNet.py:398-412)
+        x0 = self.upsample(x2)
+        B, C, H, W = x0.shape
+        out, _, _, _ = self.mamba(x0.reshape(B, C, H * W).transpose(-1, -2))
+        x0 = self.downsample(out.transpose(-1, -2).reshape(B, C, H, W))
+        return x0 * self.mlp(x2) * x2 + f
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, num_slices=4, d_state=16):
+        super().__init__()
+        self.conv1 = nn.Sequential(MMConv(in_channels, in_channels // 4, kernel_size=3, num_slices=num_slices,
+                                          d_state=d_state),
+                                   nn.BatchNorm2d(in_channels // 4), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(MMConv(in_channels // 4, out_channels, kernel_size=3, num_slices=num_slices,
+                                          d_state=d_state),
+                                   nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return F.interpolate(self.conv2(self.conv1(x)), scale_factor=2, mode="bilinear", align_corners=True)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, num_slices, downsample=False, d_state=16):
+        super().__init__()
+        self.downsample = downsample
+        if downsample:
+            self.block1 = nn.Sequential(
+                nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=False),
+                nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True),
+                MMConv(out_channels, out_channels, num_slices=num_slices, kernel_size=3, d_state=d_state),
+                nn.BatchNorm2d(out_channels))
+            self.block2 = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=2, bias=False),
+                                        nn.BatchNorm2d(out_channels))
+        else:
+            self.block1 = nn.Sequential(
+                MMConv(in_channels, out_channels, num_slices=num_slices, kernel_size=3, d_state=d_state),
+                nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True),
+                MMConv(out_channels, out_channels, num_slices=num_slices, kernel_size=3, d_state=d_state),
+                nn.BatchNorm2d(out_channels))
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        x1 = self.block1(x)
+        if self.downsample:
+            return self.relu(self.block2(x) + x1)
+        return self.relu(x1 + x)
+
+
+class MM_Net(nn.Module):
+    def __init__(self, num_classes, num_slices_list=[64, 32, 16, 8], out_indices=[0, 1, 2, 3], heads=[1, 2, 4, 4],
+                 d_state=16):
+        super().__init__()
+        s = num_slices_list
+        rb = lambda i, o, n, **kw: ResidualBlock(i, o, num_slices=n, d_state=d_state, **kw)  # noqa: E731
+        self.encoder1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False),
+                                      nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1, dilation=1, ceil_mode=False)
+        self.encoder2 = nn.Sequential(rb(64, 64, s[0]), rb(64, 64, s[0]), rb(64, 64, s[0]))
+        self.encoder3 = nn.Sequential(rb(64, 128, s[1], downsample=True), rb(128, 128, s[1]), rb(128, 128, s[1]),
+                                      rb(128, 128, s[1]))
+        self.encoder4 = nn.Sequential(rb(128, 256, s[2], downsample=True), rb(256, 256, s[2]), rb(256, 256, s[2]),
+                                      rb(256, 256, s[2]), rb(256, 256, s[2]), rb(256, 256, s[2]))
+        self.encoder5 = nn.Sequential(rb(256, 512, s[3], downsample=True), rb(512, 512, s[3]), rb(512, 512, s[3]))
+
+        def down(c):
+            return nn.Sequential(MMConv(c, 64, num_slices=s[-1], kernel_size=1, d_state=d_state),
+                                 nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+
+        self.down3 = down(128)
+        self.down4 = down(256)
+        self.down5 = down(512)
+        self.cbam = nn.Sequential(nn.Conv2d(64, 64, 3, 1, 1), nn.BatchNorm2d(64), nn.ReLU(inplace=True), CBAM(64),
+                                  nn.Conv2d(64, 64, 3, 1, 1), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.line_predict = nn.Conv2d(64, 1, 3, 1, 1)
+        self.side2 = SideoutBlock(64, 1, num_slices=s[0], d_state=d_state)
+        self.side3 = SideoutBlock(64, 1, num_slices=s[1], d_state=d_state)
+        self.side4 = SideoutBlock(64, 1, num_slices=s[2], d_state=d_state)
+        self.side5 = SideoutBlock(64, 1, num_slices=s[3], d_state=d_state)
+        self.rcg2 = RCG(d_state=d_state, num_slices=s[0], head=heads[0])
+        self.rcg3 = RCG(d_state=d_state, num_slices=s[1], head=heads[1])
+        self.rcg4 = RCG(d_state=d_state, num_slices=s[2], head=heads[2])
+        self.decoder5 = DecoderBlock(in_channels=64, out_channels=64, num_slices=s[3], d_state=d_state)
+        self.decoder4 = DecoderBlock(in_channels=128, out_channels=64, num_slices=s[2], d_state=d_state)
+        self.decoder3 = DecoderBlock(in_channels=128, out_channels=64, num_slices=s[1], d_state=d_state)
+        self.decoder2 = DecoderBlock(in_channels=128, out_channels=64, num_slices=s[0], d_state=d_state)
+
+    def forward(self, x):
+        size = x.size()[2:]
+        up = lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=True)  # noqa: E731
+        e1 = self.encoder1(x)
+        e2 = self.encoder2(self.maxpool(e1))
+        e3 = self.encoder3(e2)
+        e4 = self.encoder4(e3)
+        e5 = self.encoder5(e4)
+        e3, e4, e5 = self.down3(e3), self.down4(e4), self.down5(e5)
+        d5 = self.decoder5(e5)
+        out5 = self.side5(d5)
+        c1 = self.cbam(e1)          # contour branch on the stride-2 stem features
+        p_c = self.line_predict(c1)
+        r4 = self.rcg4(out5, c1, e4)
+        d4 = self.decoder4(torch.cat((d5, r4), dim=1))
+        out4 = self.side4(d4)
+        r3 = self.rcg3(out4, c1, e3)
+        d3 = self.decoder3(torch.cat((d4, r3), dim=1))
+        out3 = self.side3(d3)
+        r2 = self.rcg2(out3, c1, e2)
+        d2 = self.decoder2(torch.cat((d3, r2), dim=1))
+        out2 = self.side2(d2)
+        return up(out2) + up(out3) + up(out4) + up(out5) + up(p_c)

@@ -1,0 +1,181 @@
+"""Module-level golden fixtures from the REFERENCE modules on CPU (build container only; see
+tools/ref_import.py for how the reference is imported).  Called by tools/make_golden.py.
+
+Small modules: the reference state_dict is stored next to inputs/outputs/grads.
+Large modules (MM_Net 65 MB, Unet 124 MB): weights are reproduced by RNG draw order --
+``torch.manual_seed(seed)`` followed by construction -- and proven identical by per-tensor
+checksums stored in the fixture (SURVEY.md section 8c "Weights").
+"""
+import os
+
+import numpy as np
+import torch
+
+import ref_import
+from make_golden import _np, save
+
+
+def _sd(m, prefix="sd."):
+    return {prefix + k: _np(v) for k, v in m.state_dict().items()}
+
+
+def _checksums(m):
+    names, sums, abss = [], [], []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        v = v.double()
+        sums.append(float(v.sum()))
+        abss.append(float(v.abs().sum()))
+    return dict(ck_names=np.array(names), ck_sum=np.array(sums), ck_abs=np.array(abss))
+
+
+def make_mamba(R):
+    for name, d_model, btype, ns, b, l in (("v1_d3", 3, "v1", 4, 2, 300), ("v3_d64", 64, "v3", 16, 2, 256),
+                                           ("v2_d8", 8, "v2", 4, 1, 128), ("none_d16", 16, "none", 4, 1, 64)):
+        torch.manual_seed(7)
+        m = R.Mamba(d_model=d_model, d_state=16, d_conv=4, expand=2, bimamba_type=btype, nslices=ns)
+        x = torch.randn(b, l, d_model, requires_grad=True)
+        out, o1, o2, o3 = m(x)
+        g = torch.randn_like(out)
+        out.backward(g)
+        grads = {"grad." + k: _np(p.grad) for k, p in m.named_parameters() if p.grad is not None}
+        extra = {}
+        if btype == "v3":
+            extra = dict(o_1=_np(o1), o_2=_np(o2), o_3=_np(o3))
+        save("mamba_" + name, x=_np(x), out=_np(out), dout=_np(g), dx=_np(x.grad), d_model=np.array(d_model),
+             nslices=np.array(ns), btype=np.array(btype), **_sd(m), **grads, **extra)
+
+
+def make_mmconv(R):
+    for name, cin, cout, k, h, w in (("c16_k3_16x16", 16, 16, 3, 16, 16), ("c16_k3_15x16", 16, 16, 3, 15, 16),
+                                     ("c32to8_k1_8x8", 32, 8, 1, 8, 8)):
+        torch.manual_seed(3)
+        m = R.MMConv(cin, cout, kernel_size=k, num_slices=4)
+        m.train()
+        x = torch.randn(2, cin, h, w, requires_grad=True)
+        out = m(x)
+        g = torch.randn_like(out)
+        out.backward(g)
+        grads = {"grad." + kk: _np(p.grad) for kk, p in m.named_parameters() if p.grad is not None}
+        save("mmconv_" + name, x=_np(x), out=_np(out), dout=_np(g), dx=_np(x.grad),
+             cfg=np.array([cin, cout, k]), **_sd(m), **grads)
+
+
+GRAD_KEYS = ["encoder1.0.weight", "line_predict.weight", "rcg4.mamba.x_proj_s.weight", "rcg4.mamba.A_b_log",
+             "rcg2.mamba.conv1d.weight", "rcg2.mamba.dt_proj.bias", "encoder2.0.block1.0.mamba.in_proj.weight",
+             "encoder2.0.block1.0.offset_conv.weight", "encoder2.0.block1.0.altho",
+             "encoder3.1.block1.0.dsc_conv_x.weight", "decoder2.conv2.0.mamba.A_log", "side5.conv2.weight",
+             "rcg3.upsample.weight", "down5.0.mamba.D"]
+
+
+def make_mmnet(R):
+    """MM_Net at 64x64, weights = seed 50 + construction order.
+
+    Stored: (a) eval-mode forward logits (the north-star forward-parity case); (b) fwd+bwd with Dice+BCE
+    in eval mode (BatchNorm running stats) and in train mode (batch stats; Dropout2d p forced to 0 so no
+    RNG is involved): logits, loss, gradients of GRAD_KEYS, |grad| sums of every live parameter.
+    Because bilinear sampling at learned coordinates is only piecewise smooth (and train-mode BN sees
+    8 samples per channel at the deepest stage), deep-layer gradients respond by several percent to a
+    1e-6 input perturbation.  The REFERENCE'S OWN response to such a perturbation is recorded per key
+    (``*sens.*``); parity tests may not ask for better agreement than the reference has with itself."""
+    import io
+    import contextlib
+    torch.manual_seed(50)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = R.MM_Net(num_classes=1)
+    ck = _checksums(m)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m.eval()
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        logits = m(x)
+    torch.manual_seed(1)
+    xb = torch.randn(2, 3, 64, 64)
+    tb = (torch.rand(2, 1, 64, 64) > 0.88).float()
+    torch.manual_seed(2)
+    noise = torch.randn_like(xb)
+
+    def step(train, eps):
+        m.load_state_dict(state0)  # reset BatchNorm running stats
+        m.train(train)
+        m.zero_grad(set_to_none=True)
+        lt = m(xb + eps * noise)
+        loss = R.DICE_BCE_Loss()(lt, tb)
+        loss.backward()
+        params = dict(m.named_parameters())
+        return lt.detach(), float(loss), {k: p.grad.clone() for k, p in params.items() if p.grad is not None}
+
+    out = {}
+    for tag, train in (("train", True), ("eval", False)):
+        lt, loss, g0 = step(train, 0.0)
+        lt1, _, g1 = step(train, 1e-6)
+        out[f"{tag}_logits"] = _np(lt)
+        out[f"{tag}_loss"] = np.array(loss)
+        out[f"{tag}_logits_sens"] = np.array(float((lt - lt1).abs().max()))
+        for k in GRAD_KEYS:
+            out[f"{tag}_grad.{k}"] = _np(g0[k])
+            out[f"{tag}_sens.{k}"] = np.array(float((g0[k] - g1[k]).abs().max() / g0[k].abs().max()))
+        out[f"{tag}_gabs"] = np.array([float(v.double().abs().sum()) for v in g0.values()])
+        out[f"{tag}_gabs_sens"] = np.array([abs(float(a.double().abs().sum()) - float(b.double().abs().sum()))
+                                            / max(float(a.double().abs().sum()), 1e-30)
+                                            for a, b in zip(g0.values(), g1.values())])
+        live_names = list(g0.keys())
+        print(f"  MM_Net {tag}: loss {loss:.6f}  logits response to 1e-6 noise {float((lt - lt1).abs().max()):.2e}  "
+              f"grad response encoder1 {float(out[tag + '_sens.encoder1.0.weight']):.2e}")
+    params = dict(m.named_parameters())
+    no_grad = np.array([k for k in params if k not in live_names])
+    n_live = sum(params[k].numel() for k in live_names)
+    save("mmnet_64", x=_np(x), logits=_np(logits), xb=_np(xb), tb=_np(tb), no_grad_names=no_grad,
+         n_live=np.array(n_live), gabs_names=np.array(live_names), **ck, **out)
+    print(f"  MM_Net: live grads {n_live}, never-used params {len(no_grad)}")
+
+
+def make_unet(R):
+    torch.manual_seed(50)
+    m = R.Unet(3, 1)
+    ck = _checksums(m)
+    m.eval()
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        out = m(x)
+    m.train()
+    torch.manual_seed(1)
+    xb = torch.randn(2, 3, 64, 64)
+    tb = (torch.rand(2, 1, 64, 64) > 0.88).float()
+    lt = m(xb)
+    loss = R.DICE_BCE_Loss()(lt, tb)
+    loss.backward()
+    p = dict(m.named_parameters())
+    save("unet_64", x=_np(x), out=_np(out), xb=_np(xb), tb=_np(tb), train_logits=_np(lt),
+         loss=np.array(float(loss)), **ck,
+         **{"grad.inc.conv.0.weight": _np(p["inc.conv.0.weight"].grad),
+            "grad.outc.conv.weight": _np(p["outc.conv.weight"].grad),
+            "grad.up1.up.weight_abs": np.array(float(p["up1.up.weight"].grad.double().abs().sum()))})
+
+
+def make_loss(R):
+    torch.manual_seed(2)
+    logits = torch.randn(2, 1, 32, 32, requires_grad=True)
+    t = (torch.rand(2, 1, 32, 32) > 0.8).float()
+    loss = R.DICE_BCE_Loss()(logits, t)
+    loss.backward()
+    save("loss_dice_bce", logits=_np(logits), targets=_np(t), loss=np.array(float(loss)), dlogits=_np(logits.grad))
+
+
+def main():
+    R = ref_import.load_reference_model()
+    print("Mamba fixtures (reference mamba_simple.Mamba on CPU)")
+    make_mamba(R)
+    print("MMConv fixtures")
+    make_mmconv(R)
+    print("loss fixture")
+    make_loss(R)
+    print("Unet fixture")
+    make_unet(R)
+    print("MM_Net fixture")
+    make_mmnet(R)
