@@ -1,0 +1,179 @@
+"""GPU parity of the nn.Module surface (HIP kernels underneath) against fixtures produced by the
+REFERENCE's own modules: Mamba (uni/bi/tri-directional), MMConv, MM_Net (eval logits <= 1e-3 = the
+north-star forward bound; Dice+BCE fwd+bwd in eval and train mode), Unet."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, rtol, atol, what):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{what}: max abs err {err:.3e} (ref max {b.abs().max():.3e})"
+    return err
+
+
+def _load(m, g):
+    sd = {k[3:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["mamba_v1_d3", "mamba_v3_d64", "mamba_v2_d8", "mamba_none_d16"])
+def test_mamba_vs_reference(name):
+    from mm_unet_amd.mamba_simple import Mamba
+    g = golden(name)
+    m = _load(Mamba(int(g["d_model"]), d_state=16, d_conv=4, expand=2, bimamba_type=str(g["btype"]),
+                    nslices=int(g["nslices"])), g)
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_()
+    out, o1, o2, o3 = m(x)
+    close(out, g["out"], 1e-4, 1e-4, "out")
+    if "o_1" in g:
+        close(o1, g["o_1"], 1e-4, 1e-4, "o_1")
+        close(o2, g["o_2"], 1e-4, 1e-4, "o_2")
+        close(o3, g["o_3"], 1e-4, 1e-4, "o_3")
+    else:
+        assert o1 is None and o2 is None and o3 is None
+    out.backward(torch.from_numpy(g["dout"]).to(DEV))
+    close(x.grad, g["dx"], 1e-3, 1e-4, "dx")
+    params = dict(m.named_parameters())
+    for k in g:
+        if k.startswith("grad."):
+            close(params[k[5:]].grad, g[k], 2e-3, 2e-3, k)
+    live = {k[5:] for k in g if k.startswith("grad.")}
+    assert {k for k, p in params.items() if p.grad is not None} == live
+
+
+def test_mamba_unfused_path_matches_fused():
+    from mm_unet_amd.mamba_simple import Mamba
+    g = golden("mamba_none_d16")
+    m = _load(Mamba(16, bimamba_type="none", nslices=4), g)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    m.use_fast_path = False
+    out, _, _, _ = m(x)
+    close(out, g["out"], 1e-4, 1e-4, "un-fused out")
+
+
+@pytest.mark.parametrize("name", ["mmconv_c16_k3_16x16", "mmconv_c16_k3_15x16", "mmconv_c32to8_k1_8x8"])
+def test_mmconv_vs_reference(name):
+    from mm_unet_amd.mmunet import MMConv
+    g = golden(name)
+    cin, cout, k = (int(v) for v in g["cfg"])
+    m = _load(MMConv(cin, cout, kernel_size=k, num_slices=4), g).train()
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_()
+    out = m(x)
+    close(out, g["out"], 1e-4, 1e-4, "out")
+    out.backward(torch.from_numpy(g["dout"]).to(DEV))
+    close(x.grad, g["dx"], 1e-3, 2e-4, "dx")
+    params = dict(m.named_parameters())
+    for kk in g:
+        if kk.startswith("grad."):
+            close(params[kk[5:]].grad, g[kk], 2e-3, 2e-3, kk)
+
+
+def _mmnet():
+    import mm_unet_amd.mmunet as pm
+    torch.manual_seed(50)
+    m = pm.MM_Net(num_classes=1)  # on CPU: identical RNG draws as the reference (test_host_logic.py)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    return m.to(DEV)
+
+
+def test_mmnet_forward_parity_1e3():
+    """North-star forward bound: |logits - reference CPU logits| <= 1e-3, fp32, identical inputs/weights."""
+    g = golden("mmnet_64")
+    m = _mmnet().eval()
+    with torch.no_grad():
+        logits = m(torch.from_numpy(g["x"]).to(DEV))
+    err = close(logits, g["logits"], 0.0, 1e-3, "logits")
+    print(f"MM_Net eval logits max abs err vs reference: {err:.3e}")
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_mmnet_fwd_bwd_vs_reference(mode):
+    """Dice+BCE training-step parity; tolerances tied to the reference's own response to a 1e-6 input
+    perturbation (see tests/test_oracle_model.py and tools/make_golden_modules.py)."""
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    g = golden("mmnet_64")
+    m = _mmnet().train(mode == "train")
+    lt = m(torch.from_numpy(g["xb"]).to(DEV))
+    lsens = float(g[f"{mode}_logits_sens"])
+    close(lt, g[f"{mode}_logits"], 1e-3, max(1e-3, 4 * lsens), f"{mode} logits")
+    loss = DICE_BCE_Loss()(lt, torch.from_numpy(g["tb"]).to(DEV))
+    assert abs(float(loss) - float(g[f"{mode}_loss"])) < max(1e-4, lsens)
+    loss.backward()
+    params = dict(m.named_parameters())
+    never = set(str(s) for s in g["no_grad_names"])
+    assert {k for k, p in params.items() if p.grad is None} == never
+    pre = f"{mode}_grad."
+    for k in g:
+        if k.startswith(pre):
+            name = k[len(pre):]
+            ref = torch.from_numpy(g[k])
+            tol = max(2e-3, 4 * float(g[f"{mode}_sens.{name}"]))
+            close(params[name].grad, ref, tol, tol * float(ref.abs().max()), k)
+    # every live parameter: |grad| sum within the self-consistency band.  The per-parameter response
+    # stored in the fixture is a single sample, so a floor is added: 0.5 % in eval mode; 25 % in train
+    # mode, where the reference's own encoder gradients move by 16 % under 1e-6 input noise.
+    names = [str(s) for s in g["gabs_names"]]
+    floor = 5e-3 if mode == "eval" else 0.25
+    bad = []
+    for nme, a, s in zip(names, g[f"{mode}_gabs"], g[f"{mode}_gabs_sens"]):
+        mine = float(params[nme].grad.double().abs().sum())
+        if abs(mine - a) > max(floor, 6 * s) * max(a, 1e-12) + 1e-10:
+            bad.append((nme, a, mine))
+    assert len(bad) <= len(names) // 50, f"{len(bad)} of {len(names)} gradient checksums off: {bad[:5]}"
+
+
+def test_unet_gpu_vs_reference():
+    import mm_unet_amd.unet as pu
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    g = golden("unet_64")
+    torch.manual_seed(50)
+    m = pu.Unet(3, 1).to(DEV).eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["x"]).to(DEV))
+    close(out, g["out"], 1e-3, 1e-3, "unet eval")
+    m.train()
+    lt = m(torch.from_numpy(g["xb"]).to(DEV))
+    loss = DICE_BCE_Loss()(lt, torch.from_numpy(g["tb"]).to(DEV))
+    assert abs(float(loss) - float(g["loss"])) < 2e-3
+    loss.backward()
+    p = dict(m.named_parameters())
+    ref = torch.from_numpy(g["grad.outc.conv.weight"])
+    close(p["outc.conv.weight"].grad, ref, 2e-2, 2e-2 * float(ref.abs().max()), "outc grad")
+
+
+def test_mmnet_bf16_autocast_smoke():
+    """bf16 contract: runs under autocast, finite, and close to the fp32 logits."""
+    g = golden("mmnet_64")
+    m = _mmnet().eval()
+    x = torch.from_numpy(g["x"]).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        lb = m(x)
+    assert torch.isfinite(lb).all()
+    ref = torch.from_numpy(g["logits"])
+    assert float((lb.float().cpu() - ref).abs().max()) < 0.15 * max(1.0, float(ref.abs().max()))
+
+
+def test_dropin_module_names():
+    import sys
+    import mm_unet_amd.dropin as dropin
+    dropin.install()
+    import selective_scan_cuda, causal_conv1d_cuda  # noqa: E401
+    from mamba_ssm import Mamba
+    from mamba_ssm.ops.selective_scan_interface import mamba_inner_fn_no_out_proj, selective_scan_fn  # noqa: F401
+    from causal_conv1d import causal_conv1d_fn  # noqa: F401
+    assert callable(selective_scan_cuda.fwd) and callable(selective_scan_cuda.bwd)
+    assert callable(causal_conv1d_cuda.causal_conv1d_fwd) and callable(causal_conv1d_cuda.causal_conv1d_update)
+    m = Mamba(8, bimamba_type="v3", nslices=4).to(DEV)
+    out, o1, o2, o3 = m(torch.randn(2, 64, 8, device=DEV))
+    assert out.shape == (2, 64, 8) and o1.shape == (2, 16, 64)
