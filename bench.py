@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json: images/sec of one MM-UNet training step
+(forward + Dice+BCE loss + backward + DP gradient all-reduce + AdamW) on synthetic 3x512x512 batches,
+bs=8 per GPU, data-parallel over N GPUs of one node (one process per GPU, RCCL over xGMI).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  "roofline":     the dominant hand-written kernel (selective-scan forward at the headline shape
+                  B=8, D=128, L=65536, N=16) timed live with HIP events on the stream it
+                  is launched on; achieved = algorithmic bytes s*B*L*(4D+2N) / mean duration of one
+                  mmu_selective_scan_fwd call; peak = 8 TB/s HBM3E; traffic from profiles/ if measured;
+  "cpu_baseline": the CPU oracle (oracle/model_ref.py + C scan, kind "port") running the same training
+                  step (fwd + loss + bwd) on one 3x512x512 image on this host's cores (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE: 8)")
+    ap.add_argument("--size", type=int, default=512, help="image side (BASELINE: 512)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="compute dtype; f32 = what the reference's train.py runs (no autocast)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=512, help="image side of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def scan_roofline(dev, iters=20):
+    """Live measurement of the selective-scan forward at the headline shape."""
+    from mm_unet_amd import selective_scan_hip as ss
+    b, d, l, n = 8, 128, 65536, 16
+    gen = torch.Generator(device=dev).manual_seed(0)
+    A = -0.5 * torch.rand(d, n, device=dev, generator=gen)
+    B = torch.randn(b, 1, n, l, device=dev, generator=gen)
+    C = torch.randn(b, 1, n, l, device=dev, generator=gen)
+    D = torch.randn(d, device=dev, generator=gen)
+    z = torch.randn(b, d, l, device=dev, generator=gen)
+    bias = 0.5 * torch.rand(d, device=dev, generator=gen)
+    u = torch.randn(b, d, l, device=dev, generator=gen)
+    delta = 0.5 * torch.rand(b, d, l, device=dev, generator=gen)
+    for _ in range(3):
+        ss.fwd(u, delta, A, B, C, D, z, bias, True)
+    st = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        ss.fwd(u, delta, A, B, C, D, z, bias, True)
+    e1.record(st)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    alg_bytes = 4 * b * l * (4 * d + 2 * n)  # fp32: u, delta, z read + out_z written + B, C read once
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "scan_fwd_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+            "kernel": "mmu_selective_scan_fwd (chunk_reduce + chunk_carry + chunk_apply_fwd)",
+            "shape": {"batch": b, "dim": d, "seqlen": l, "dstate": n, "dtype": "f32"},
+            "algorithmic_bytes": alg_bytes, "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(size):
+    """The oracle's training step (fwd + Dice+BCE + bwd) on ONE image, timed on this host's cores."""
+    import oracle
+    from oracle import model_ref
+    from mm_unet_amd.mmunet import MM_Net
+    oracle.build()
+    torch.manual_seed(50)
+    sd = {k: v.detach().clone() for k, v in MM_Net(num_classes=1).state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_()
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 3, size, size, generator=gen)
+    t = (torch.rand(1, 1, size, size, generator=gen) > 0.88).float()
+    t0 = time.time()
+    logits = model_ref.mm_net(sd, x, training=True)
+    model_ref.dice_bce_loss(logits, t).backward()
+    dt = time.time() - t0
+    cores = max(torch.get_num_threads(), oracle.num_threads())
+    return {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/model_ref.py MM_Net fwd + Dice+BCE + bwd on 1 image 3x{size}x{size} fp32 "
+                      f"({dt:.1f} s, torch CPU ops + C scan/conv1d oracle, {cores} threads)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from mm_unet_amd.dp import broadcast_module_state
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    from mm_unet_amd.mmunet import MM_Net
+    from mm_unet_amd.train_step import TrainStep, make_optimizer
+
+    torch.manual_seed(50)  # reference: same_seeds(50), train.py:160
+    model = MM_Net(num_classes=1).to(dev).train()
+    if world > 1:
+        broadcast_module_state(model)
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+    step = TrainStep(model, DICE_BCE_Loss(), make_optimizer(model), amp_dtype=amp)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # rank r owns samples [8r, 8r+8)
+    images = torch.randn(args.batch, 3, args.size, args.size, device=dev, generator=gen)
+    targets = (torch.rand(args.batch, 1, args.size, args.size, device=dev, generator=gen) > 0.88).float()
+
+    for _ in range(args.warmup):
+        step(images, targets)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(images, targets)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    assert torch.isfinite(loss), "training diverged in the benchmark"
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        line = {
+            "metric": "images/sec fwd+bwd, MM-UNet 3x512x512 bs=8 per GPU",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"MM_Net train step (fwd + Dice+BCE + bwd + grad all-reduce + AdamW), "
+                                   f"3x{args.size}x{args.size}, bs={args.batch}/GPU, random-init seed 50",
+                       "global_batch": args.batch * world, "image": [3, args.size, args.size],
+                       "parallelism": f"dp{world}", "grad_allreduce_bytes": step.reducer.payload_bytes(),
+                       "final_loss": round(float(loss), 5)},
+        }
+        if not args.no_roofline:
+            line["roofline"] = scan_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_size)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
