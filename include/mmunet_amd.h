@@ -163,7 +163,9 @@ int mmu_causal_conv1d_update(const mmu_conv1d_update_params *p, void *stream);
 
 /* ---- test hooks (exercise the wave-level primitives on the GPU) -------- */
 /* Runs the in-wave affine-pair scan on n_waves*64 (P,S) pairs, one wave per 64.
- * reverse=0: forward inclusive; reverse=1: reverse inclusive.  variant 0 = DPP, 1 = shuffle. */
+ * reverse=0: forward inclusive; reverse=1: reverse inclusive.  variant 0 = DPP intrinsics,
+ * 1 = shuffle, 2 = hand-written fused DPP, 3/4 = second/first of two interleaved fused scans
+ * (the first one runs on (0.5*P, -S)). */
 int mmu_debug_wave_scan(const float *P, const float *S, float *outP, float *outS, int n_waves,
                         int reverse, int variant, void *stream);
 

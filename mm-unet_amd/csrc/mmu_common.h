@@ -56,9 +56,10 @@ struct alignas(sizeof(T) * K) Pack {
 
 // Loads K consecutive items at p (items beyond nvalid read as 0).  `vec` = the
 // host verified that every such K-group is naturally aligned.
-template <typename T, int K>
+// FULL = compile-time promise that every K-group is in range and aligned (no tail, no branches).
+template <typename T, int K, bool FULL = false>
 __device__ __forceinline__ void load_k(const T *__restrict__ p, int nvalid, bool vec, float (&o)[K]) {
-    if (vec && nvalid >= K) {
+    if (FULL || (vec && nvalid >= K)) {
         Pack<T, K> v = *reinterpret_cast<const Pack<T, K> *>(p);
 #pragma unroll
         for (int i = 0; i < K; ++i) o[i] = to_f32(v.e[i]);
@@ -68,9 +69,9 @@ __device__ __forceinline__ void load_k(const T *__restrict__ p, int nvalid, bool
     }
 }
 
-template <typename T, int K>
+template <typename T, int K, bool FULL = false>
 __device__ __forceinline__ void store_k(T *__restrict__ p, int nvalid, bool vec, const float (&v)[K]) {
-    if (vec && nvalid >= K) {
+    if (FULL || (vec && nvalid >= K)) {
         Pack<T, K> o;
 #pragma unroll
         for (int i = 0; i < K; ++i) o.e[i] = from_f32<T>(v[i]);
@@ -86,9 +87,18 @@ __device__ __forceinline__ void store_k(T *__restrict__ p, int nvalid, bool vec,
 // math
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
-// softplus with the reference kernel's threshold (selective_scan_fwd_kernel.cuh:153-156)
-__device__ __forceinline__ float softplus_thr(float x) { return x <= 20.f ? log1pf(expf(x)) : x; }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * MMU_LOG2E); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * MMU_LN2; }  // v_log_f32
+// softplus with the reference kernel's threshold (selective_scan_fwd_kernel.cuh:153-156), on the
+// hardware exp2/log2 units: libm expf/log1pf cost ~60 instructions each, which per token was as
+// much work as the 16-state recurrence itself.  log1p(e) for tiny e via its series (1 + e would
+// round to 1).
+__device__ __forceinline__ float softplus_thr(float x) {
+    const float e = fast_exp(fminf(x, 20.f));
+    const float sp = e < 1e-4f ? e * (1.f - 0.5f * e) : fast_log(1.f + e);
+    return x <= 20.f ? sp : x;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + fast_exp(-x)); }
 
 // ---------------------------------------------------------------------------
 // wave64 cross-lane primitives (DPP: row_shr 1/2/4/8, row_bcast15, row_bcast31)
@@ -142,11 +152,54 @@ __device__ __forceinline__ void wave_scan_affine_shfl(float &P, float &S) {
 #define MMU_SCAN_USE_SHFL 0
 #endif
 
+// Hand-scheduled form of wave_scan_affine_dpp: each scan step is ONE v_fmac_f32_dpp
+// (S += dpp(S) * P) and ONE v_mul_f32_dpp (P *= dpp(P)); lanes whose DPP source does not exist
+// are not written (bound_ctrl off), rows masked out by row_mask are not written -- which is
+// exactly the identity behaviour the scan needs, so no `old` registers and no selects.
+// hipcc lowers the intrinsic form to v_mov_b32_dpp + s_nop + separate fmac/mul (7 instructions
+// per step).  Two independent scans are interleaved so that every DPP read is >= 2 VALU
+// instructions after the write of the register it reads (the VALU->DPP hazard), no s_nop needed
+// inside.  Requires EXEC = all 64 lanes.
+#define MMU_SCAN2_STEP(ctrl, mask)                                                         \
+    "v_fmac_f32_dpp %1, %1, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"               \
+    "v_fmac_f32_dpp %3, %3, %2 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"               \
+    "v_mul_f32_dpp %0, %0, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                \
+    "v_mul_f32_dpp %2, %2, %2 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"
+
+__device__ __forceinline__ void wave_scan_affine_x2(float &P0, float &S0, float &P1, float &S1) {
+#if MMU_SCAN_USE_SHFL
+    wave_scan_affine_shfl(P0, S0);
+    wave_scan_affine_shfl(P1, S1);
+#else
+    asm volatile("s_nop 1\n\t"
+                 MMU_SCAN2_STEP("row_shr:1", "0xf")
+                 MMU_SCAN2_STEP("row_shr:2", "0xf")
+                 MMU_SCAN2_STEP("row_shr:4", "0xf")
+                 MMU_SCAN2_STEP("row_shr:8", "0xf")
+                 MMU_SCAN2_STEP("row_bcast:15", "0xa")
+                 MMU_SCAN2_STEP("row_bcast:31", "0xc")
+                 "s_nop 1"
+                 : "+v"(P0), "+v"(S0), "+v"(P1), "+v"(S1));
+#endif
+}
+
+#define MMU_SCAN1_STEP(ctrl, mask)                                                         \
+    "v_fmac_f32_dpp %1, %1, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"               \
+    "v_mul_f32_dpp %0, %0, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                \
+    "s_nop 1\n\t"
+
 __device__ __forceinline__ void wave_scan_affine(float &P, float &S) {
 #if MMU_SCAN_USE_SHFL
     wave_scan_affine_shfl(P, S);
 #else
-    wave_scan_affine_dpp(P, S);
+    asm volatile("s_nop 1\n\t"
+                 MMU_SCAN1_STEP("row_shr:1", "0xf")
+                 MMU_SCAN1_STEP("row_shr:2", "0xf")
+                 MMU_SCAN1_STEP("row_shr:4", "0xf")
+                 MMU_SCAN1_STEP("row_shr:8", "0xf")
+                 MMU_SCAN1_STEP("row_bcast:15", "0xa")
+                 MMU_SCAN1_STEP("row_bcast:31", "0xc")
+                 : "+v"(P), "+v"(S));
 #endif
 }
 
@@ -185,6 +238,23 @@ __device__ __forceinline__ float wave_scan_add(float v) {
     v += dpp_mov<MMU_DPP_ROW_BCAST31, 0xc>(0.f, v);
     return v;
 #endif
+}
+
+// inclusive prefix / suffix sums within each 16-lane DPP row (4 steps, no cross-row traffic)
+__device__ __forceinline__ float row_scan_add_up(float v) {  // lane l gets sum over lanes <= l of its row
+    v += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, v);
+    return v;
+}
+#define MMU_DPP_ROW_SHL(n) (0x100 + (n))
+__device__ __forceinline__ float row_scan_add_down(float v) {  // lane l gets sum over lanes >= l of its row
+    v += dpp_mov<MMU_DPP_ROW_SHL(1), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHL(2), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHL(4), 0xf>(0.f, v);
+    v += dpp_mov<MMU_DPP_ROW_SHL(8), 0xf>(0.f, v);
+    return v;
 }
 
 __device__ __forceinline__ float wave_bcast_last(float v) {

@@ -53,7 +53,7 @@ struct ScanArgs {
 };
 
 // Stage one [N][T] tile of B or C (tokens [t0, t0+T) of batch b, group g) into LDS as fp32.
-template <typename io_t, int K>
+template <typename io_t, int K, bool FULL>
 __device__ __forceinline__ void stage_tile(float *__restrict__ s, const io_t *__restrict__ g, long row_stride,
                                            int N, int t0, int L, bool vec) {
     constexpr int T = 64 * K;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ s, const io_t *__
         const int n = idx >> 6, j = idx & 63;
         const int t = t0 + j * K;
         float v[K];
-        load_k<io_t, K>(g + (long)n * row_stride + t, L - t, vec, v);
+        load_k<io_t, K, FULL>(g + (long)n * row_stride + t, L - t, vec, v);
         float *dst = s + n * T + j * K;
 #pragma unroll
         for (int i = 0; i < K; ++i) dst[i] = v[i];
@@ -73,7 +73,7 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ s, const io_t *__
 //                            BWD=true : (Q, R) of the adjoint recurrence.
 // grid (n_chunks, batch, ngroups), block W*64.  LDS: tile[N][T] | A2[W][N] | res[W][2N]
 // ---------------------------------------------------------------------------
-template <typename io_t, int K, bool BWD>
+template <typename io_t, int K, bool BWD, bool FULL>
 __global__ __launch_bounds__(1024) void chunk_reduce_kernel(ScanArgs p) {
     constexpr int T = 64 * K;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -86,9 +86,9 @@ __global__ __launch_bounds__(1024) void chunk_reduce_kernel(ScanArgs p) {
     float *sR = smem + N * T + W * N + w * 2 * N;
 
     if (!BWD)
-        stage_tile<io_t, K>(sT, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
+        stage_tile<io_t, K, FULL>(sT, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
     else
-        stage_tile<io_t, K>(sT, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
+        stage_tile<io_t, K, FULL>(sT, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
     __syncthreads();
 
     const int dpg = p.dim / p.ngroups;
@@ -100,24 +100,24 @@ __global__ __launch_bounds__(1024) void chunk_reduce_kernel(ScanArgs p) {
         for (int n = lane; n < N; n += 64) sA[n] = p.A[(long)d * p.A_ds + (long)n * p.A_ns] * MMU_LOG2E;
         const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
         float dl[K], wv[K];  // wv: fwd = dl*u ; bwd = dout*silu(z)
-        load_k<io_t, K>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
+        load_k<io_t, K, FULL>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
                         p.vec_io, dl);
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             float v = dl[i] + bias;
             if (p.softplus) v = softplus_thr(v);
-            dl[i] = (i < nvalid) ? v : 0.f;  // identity element beyond L: a = 1, b = 0
+            dl[i] = (FULL || i < nvalid) ? v : 0.f;  // identity element beyond L: a = 1, b = 0
         }
         if (!BWD) {
-            load_k<io_t, K>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io, wv);
+            load_k<io_t, K, FULL>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io, wv);
 #pragma unroll
             for (int i = 0; i < K; ++i) wv[i] *= dl[i];
         } else {
-            load_k<io_t, K>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid,
+            load_k<io_t, K, FULL>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid,
                             p.vec_io, wv);
             if (p.z) {
                 float zv[K];
-                load_k<io_t, K>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io,
+                load_k<io_t, K, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io,
                                 zv);
 #pragma unroll
                 for (int i = 0; i < K; ++i) wv[i] *= zv[i] * sigmoidf_(zv[i]);
@@ -162,6 +162,133 @@ __global__ __launch_bounds__(1024) void chunk_reduce_kernel(ScanArgs p) {
     }
 }
 
+// ---- 8-tokens-per-lane tiles -------------------------------------------------------------------
+// A [N][512]-token tile whose consumer lane l owns tokens 8l..8l+7.  Stored as [n][2][64][4]:
+// the lane's two 16-B halves sit 1 KiB apart, so each ds_read_b128 of a wave is 1 KiB contiguous
+// (conflict-free); the natural [n][512] order would put lanes 32 B apart = 2-way conflicts
+// (measured: 42 % of the LDS cycles of the first version of chunk_apply_fwd).
+template <typename io_t, bool FULL>
+__device__ __forceinline__ void stage_tile8(float *__restrict__ s, const io_t *__restrict__ g, long row_stride,
+                                            int N, int t0, int L, bool vec) {
+    for (int idx = threadIdx.x; idx < N * 64; idx += blockDim.x) {
+        const int n = idx >> 6, j = idx & 63;
+        const int t = t0 + j * 8;
+        float v[8];
+        load_k<io_t, 8, FULL>(g + (long)n * row_stride + t, L - t, vec, v);
+        float4 *dst = reinterpret_cast<float4 *>(s + n * 512) + j;
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[64] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+__device__ __forceinline__ void tile8_read(const float *row, int lane, float (&v)[8]) {
+    const float4 lo = reinterpret_cast<const float4 *>(row)[lane];
+    const float4 hi = reinterpret_cast<const float4 *>(row)[64 + lane];
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
+
+// ---------------------------------------------------------------------------
+// K1 (fast form, 128-token chunks): per-chunk aggregates with 8 tokens per lane, so one wave covers
+// FOUR chunks (one per 16-lane DPP row) and every cross-lane step is a 4-step row operation.
+// grid (ceil(n_chunks / 4), batch, ngroups), block W*64.  LDS: tile[N][512] | A2[W][N] | res[W][4][2N]
+// ---------------------------------------------------------------------------
+template <typename io_t, bool BWD, bool FULL>
+__global__ __launch_bounds__(1024) void chunk_reduce8_kernel(ScanArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = p.dstate, L = p.seqlen;
+    const int b = blockIdx.y, g = blockIdx.z;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
+    const int t0 = blockIdx.x * 512;
+    const int c0 = blockIdx.x * 4;
+    float *sT = smem;
+    float *sA = sT + N * 512 + w * N;
+    float *sR = smem + N * 512 + W * N + w * 8 * N;
+
+    if (!BWD)
+        stage_tile8<io_t, FULL>(sT, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
+    else
+        stage_tile8<io_t, FULL>(sT, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
+    __syncthreads();
+
+    const int dpg = p.dim / p.ngroups;
+    const int tl = lane * 8;
+    const int nvalid = L - (t0 + tl);
+    const int q = lane >> 4;  // which of the wave's 4 chunks
+    float *dst_base = BWD ? p.gx : p.x;
+    const int nq = p.n_chunks - c0 < 4 ? p.n_chunks - c0 : 4;
+
+    for (int d = g * dpg + w; d < (g + 1) * dpg; d += W) {
+        for (int n = lane; n < N; n += 64) sA[n] = p.A[(long)d * p.A_ds + (long)n * p.A_ns] * MMU_LOG2E;
+        const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+        float dl[8], wv[8];
+        load_k<io_t, 8, FULL>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
+                              p.vec_io, dl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = dl[i] + bias;
+            if (p.softplus) v = softplus_thr(v);
+            dl[i] = (FULL || i < nvalid) ? v : 0.f;
+        }
+        if (!BWD) {
+            load_k<io_t, 8, FULL>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io,
+                                  wv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] *= dl[i];
+        } else {
+            load_k<io_t, 8, FULL>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid,
+                                  p.vec_io, wv);
+            if (p.z) {
+                float zv[8];
+                load_k<io_t, 8, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid,
+                                      p.vec_io, zv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wv[i] *= zv[i] * sigmoidf_(zv[i]);
+            }
+        }
+        float lane_tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lane_tot += dl[i];
+        float cum[8], tot;
+        if (!BWD) {  // exclusive suffix sums inside the chunk; chunk total lands on the row's lane 0
+            const float incl = row_scan_add_down(lane_tot);
+            tot = incl;
+            float run = incl - lane_tot;
+#pragma unroll
+            for (int i = 7; i >= 0; --i) {
+                cum[i] = run;
+                run += dl[i];
+            }
+        } else {     // inclusive prefix sums; chunk total lands on the row's lane 15
+            const float incl = row_scan_add_up(lane_tot);
+            tot = incl;
+            float run = incl - lane_tot;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                run += dl[i];
+                cum[i] = run;
+            }
+        }
+        const bool writer = (lane & 15) == (BWD ? 15 : 0);
+        for (int n = 0; n < N; ++n) {
+            const float a2 = sA[n];
+            float row[8];
+            tile8_read(sT + n * 512, lane, row);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fmaf(fast_exp2(a2 * cum[i]) * wv[i], row[i], s);
+            s = BWD ? row_scan_add_up(s) : row_scan_add_down(s);
+            if (writer) {
+                sR[q * 2 * N + 2 * n] = fast_exp2(a2 * tot);
+                sR[q * 2 * N + 2 * n + 1] = s;
+            }
+        }
+        // the 4 chunks' (P, S) records are contiguous in memory
+        float *dst = dst_base + (((long)b * p.dim + d) * p.n_chunks + c0) * 2 * N;
+        for (int j = lane; j < nq * 2 * N; j += 64) dst[j] = sR[j];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K2: carry over chunks, in place on buf[bd][c][n] = (P, S) -> (P, H).
 // reverse=0: H_c = P_c H_{c-1} + S_c ; reverse=1: H_c = P_c H_{c+1} + S_c.
@@ -174,7 +301,7 @@ __global__ __launch_bounds__(256) void chunk_carry_kernel(float *__restrict__ bu
     const int n = (int)(idx % N);
     float2 *p = reinterpret_cast<float2 *>(buf) + bd * n_chunks * N + n;
     float h = 0.f;
-    constexpr int U = 8;
+    constexpr int U = 32;  // latency-bound: 32 independent 8-B loads in flight per thread
     for (int c0 = 0; c0 < n_chunks; c0 += U) {
         float2 v[U];
 #pragma unroll
@@ -198,88 +325,227 @@ __global__ __launch_bounds__(256) void chunk_carry_kernel(float *__restrict__ bu
 }
 
 // ---------------------------------------------------------------------------
-// K3: forward apply.  grid (n_chunks, batch, ngroups), block W*64.
-// LDS: B[N][T] | C[N][T] | A2[W][N] | H0[W][N]
+// K3: forward apply.  grid (ceil(L / (64*KX)), batch, ngroups), block W*64.
+// KX tokens per lane (tile of 64*KX tokens); chunk carries live at 64*KC-token granularity
+// (KX is a multiple of KC, so a tile always starts on a chunk boundary).
+// LDS: B[N][TT] | C[N][TT] | A2[W][N] | H0[W][N]
 // ---------------------------------------------------------------------------
-template <typename io_t, int K>
+// One or two states at a time: K-token serial recurrence in registers, lanes joined by the DPP
+// affine scan.  The chunk carry h0 is folded into lane 0's element before the scan, so the
+// inclusive scan directly yields the state at the end of every lane.
+template <int KX, int NS>
+__device__ __forceinline__ void fwd_states(const float (&dl)[KX], const float (&du)[KX], float (&y)[KX],
+                                           const float *rowB, const float *rowC, int TT, const float *a2,
+                                           const float *h0, int lane) {
+    // rowB / rowC: start of state n's row in the B / C tile
+    float a[NS][KX], bb[NS][KX], P[NS], S[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float Bv[KX];
+        if constexpr (KX == 8) {
+            tile8_read(rowB + s * TT, lane, Bv);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KX; ++i) Bv[i] = rowB[s * TT + lane * KX + i];
+        }
+#pragma unroll
+        for (int i = 0; i < KX; ++i) {
+            a[s][i] = fast_exp2(dl[i] * a2[s]);
+            bb[s][i] = du[i] * Bv[i];
+        }
+        P[s] = a[s][0];
+        S[s] = bb[s][0];
+#pragma unroll
+        for (int i = 1; i < KX; ++i) {
+            S[s] = fmaf(a[s][i], S[s], bb[s][i]);
+            P[s] *= a[s][i];
+        }
+        S[s] = lane == 0 ? fmaf(P[s], h0[s], S[s]) : S[s];
+    }
+    if constexpr (NS == 2)
+        wave_scan_affine_x2(P[0], S[0], P[1], S[1]);
+    else
+        wave_scan_affine(P[0], S[0]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float Cv[KX];
+        if constexpr (KX == 8) {
+            tile8_read(rowC + s * TT, lane, Cv);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KX; ++i) Cv[i] = rowC[s * TT + lane * KX + i];
+        }
+        float h = wave_shift_up1(S[s], h0[s]);  // state entering this lane's tokens
+#pragma unroll
+        for (int i = 0; i < KX; ++i) {
+            h = fmaf(a[s][i], h, bb[s][i]);
+            y[i] = fmaf(Cv[i], h, y[i]);
+        }
+    }
+}
+
+template <typename io_t, int KX, int KC, bool FULL>
 __global__ __launch_bounds__(1024) void chunk_apply_fwd_kernel(ScanArgs p) {
-    constexpr int T = 64 * K;
+    constexpr int TT = 64 * KX;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N = p.dstate, L = p.seqlen;
-    const int c = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
+    const int b = blockIdx.y, g = blockIdx.z;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
-    const int t0 = c * T;
+    const int t0 = blockIdx.x * TT;
+    const int cprev = t0 / (64 * KC) - 1;  // chunk whose end state enters this tile
     float *sB = smem;
-    float *sC = sB + N * T;
-    float *sA = sC + N * T + w * N;
-    float *sH = smem + 2 * N * T + W * N + w * N;
+    float *sC = sB + N * TT;
+    float *sA = sC + N * TT + w * N;
+    float *sH = smem + 2 * N * TT + W * N + w * N;
 
-    stage_tile<io_t, K>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
-    stage_tile<io_t, K>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
+    if constexpr (KX == 8) {
+        stage_tile8<io_t, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
+        stage_tile8<io_t, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
+    } else {
+        stage_tile<io_t, KX, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L,
+                                   p.vec_bc);
+        stage_tile<io_t, KX, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L,
+                                   p.vec_bc);
+    }
     __syncthreads();
 
     const int dpg = p.dim / p.ngroups;
-    const int tl = lane * K;
+    const int tl = lane * KX;
     const int nvalid = L - (t0 + tl);
+    const int dend = (g + 1) * dpg;
+    const io_t *pdelta = (const io_t *)p.delta + (long)b * p.delta_bs + t0 + tl;
+    const io_t *pu = (const io_t *)p.u + (long)b * p.u_bs + t0 + tl;
 
-    for (int d = g * dpg + w; d < (g + 1) * dpg; d += W) {
-        const float *xprev = p.x + (((long)b * p.dim + d) * p.n_chunks + (c - 1)) * 2 * N;
+    // software pipeline over channels: the next channel's u / delta are in flight during this one's scan
+    float dl_n[KX], du_n[KX];
+    int d = g * dpg + w;
+    if (d < dend) {
+        load_k<io_t, KX, FULL>(pdelta + (long)d * p.delta_ds, nvalid, p.vec_io, dl_n);
+        load_k<io_t, KX, FULL>(pu + (long)d * p.u_ds, nvalid, p.vec_io, du_n);
+    }
+    for (; d < dend; d += W) {
+        const float *xprev = p.x + (((long)b * p.dim + d) * p.n_chunks + cprev) * 2 * N;
         for (int n = lane; n < N; n += 64) {
             sA[n] = p.A[(long)d * p.A_ds + (long)n * p.A_ns] * MMU_LOG2E;
-            sH[n] = (c > 0) ? xprev[2 * n + 1] : 0.f;
+            sH[n] = (cprev >= 0) ? xprev[2 * n + 1] : 0.f;
         }
         const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
         const float Dv = p.D ? p.D[d] : 0.f;
-        float dl[K], du[K], y[K];
-        load_k<io_t, K>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
-                        p.vec_io, dl);
-        load_k<io_t, K>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io, du);
+        float dl[KX], du[KX], y[KX], zv[KX];
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
+        for (int i = 0; i < KX; ++i) {
+            dl[i] = dl_n[i];
+            du[i] = du_n[i];
+        }
+        if (d + W < dend) {
+            load_k<io_t, KX, FULL>(pdelta + (long)(d + W) * p.delta_ds, nvalid, p.vec_io, dl_n);
+            load_k<io_t, KX, FULL>(pu + (long)(d + W) * p.u_ds, nvalid, p.vec_io, du_n);
+        }
+        if (p.z)  // consumed after the state loop
+            load_k<io_t, KX, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io,
+                                   zv);
+#pragma unroll
+        for (int i = 0; i < KX; ++i) {
             float v = dl[i] + bias;
             if (p.softplus) v = softplus_thr(v);
-            dl[i] = (i < nvalid) ? v : 0.f;
+            dl[i] = (FULL || i < nvalid) ? v : 0.f;
             y[i] = Dv * du[i];
             du[i] *= dl[i];
         }
-
-        for (int n = 0; n < N; ++n) {
-            const float a2 = sA[n];
-            const float h0 = sH[n];
-            const float *rb = sB + n * T + tl;
-            const float *rc = sC + n * T + tl;
-            float a[K], bb[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                a[i] = fast_exp2(dl[i] * a2);
-                bb[i] = du[i] * rb[i];
-            }
-            float P = a[0], S = bb[0];
-#pragma unroll
-            for (int i = 1; i < K; ++i) {
-                S = fmaf(a[i], S, bb[i]);
-                P *= a[i];
-            }
-            wave_scan_affine(P, S);
-            const float Pe = wave_shift_up1(P, 1.f);
-            const float Se = wave_shift_up1(S, 0.f);
-            float h = fmaf(Pe, h0, Se);  // state entering this lane's tokens
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                h = fmaf(a[i], h, bb[i]);
-                y[i] = fmaf(rc[i], h, y[i]);
-            }
-        }
+        int n = 0;
+        for (; n + 1 < N; n += 2)
+            fwd_states<KX, 2>(dl, du, y, sB + n * TT, sC + n * TT, TT, sA + n, sH + n, lane);
+        if (n < N) fwd_states<KX, 1>(dl, du, y, sB + n * TT, sC + n * TT, TT, sA + n, sH + n, lane);
         if (p.out)
-            store_k<io_t, K>((io_t *)p.out + (long)b * p.out_bs + (long)d * p.out_ds + t0 + tl, nvalid, p.vec_io, y);
+            store_k<io_t, KX, FULL>((io_t *)p.out + (long)b * p.out_bs + (long)d * p.out_ds + t0 + tl, nvalid,
+                                    p.vec_io, y);
         if (p.z) {
-            float zv[K];
-            load_k<io_t, K>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io, zv);
 #pragma unroll
-            for (int i = 0; i < K; ++i) y[i] *= zv[i] * sigmoidf_(zv[i]);
-            store_k<io_t, K>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
-                             p.vec_io, y);
+            for (int i = 0; i < KX; ++i) y[i] *= zv[i] * sigmoidf_(zv[i]);
+            store_k<io_t, KX, FULL>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
+                                    p.vec_io, y);
         }
+    }
+}
+
+// Backward work of one or two states for this lane's K tokens (see the math block at the top).
+// dB/dC contributions of this channel go to accB/accC: REG=true -> the caller's register
+// accumulators [NS][K] (summed over the wave's channel loop, flushed once per chunk);
+// REG=false -> LDS float atomics into tiles laid out [n][i][lane] (generic-dstate fallback: the
+// LDS atomic unit retires only ~1 lane per 3.5 cycles per CU, measured, so this path is slow).
+template <int K, int NS, bool REG>
+__device__ __forceinline__ void bwd_states(const float (&dl)[K], const float (&uv)[K], const float (&dy)[K],
+                                           float (&y)[K], float (&duv)[K], float (&ddl)[K], const float *rb,
+                                           const float *rc, float *accB, float *accC, int T, const float *a2,
+                                           const float *h0, const float *g0, float *dA_out, int lane) {
+    float a[NS][K], bb[NS][K], hh[NS][K], cc[NS][K], P[NS], S[NS], Q[NS], R[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            a[s][i] = fast_exp2(dl[i] * a2[s]);
+            bb[s][i] = dl[i] * uv[i] * rb[s * T + i];
+            cc[s][i] = rc[s * T + i] * dy[i];
+        }
+        P[s] = a[s][0];
+        S[s] = bb[s][0];
+#pragma unroll
+        for (int i = 1; i < K; ++i) {
+            S[s] = fmaf(a[s][i], S[s], bb[s][i]);
+            P[s] *= a[s][i];
+        }
+        // adjoint map of this lane, composed right-to-left: gamma_out = a_i (c_i + gamma_in)
+        Q[s] = P[s];
+        R[s] = 0.f;
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) R[s] = a[s][i] * (cc[s][i] + R[s]);
+        S[s] = lane == 0 ? fmaf(P[s], h0[s], S[s]) : S[s];
+        R[s] = lane == 63 ? fmaf(Q[s], g0[s], R[s]) : R[s];
+        Q[s] = wave_reverse(Q[s]);
+        R[s] = wave_reverse(R[s]);
+    }
+    if constexpr (NS == 2) {
+        wave_scan_affine_x2(P[0], S[0], P[1], S[1]);
+        wave_scan_affine_x2(Q[0], R[0], Q[1], R[1]);
+    } else {
+        wave_scan_affine(P[0], S[0]);
+        wave_scan_affine(Q[0], R[0]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float An = a2[s] * MMU_LN2;
+        float h = wave_shift_up1(S[s], h0[s]);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            h = fmaf(a[s][i], h, bb[s][i]);
+            hh[s][i] = h;
+        }
+        // gamma entering this lane from the right = reversed-order inclusive R of lane+1
+        float gam = __builtin_bit_cast(
+            float, __builtin_amdgcn_ds_bpermute((62 - lane) << 2, __builtin_bit_cast(int, R[s])));
+        gam = lane == 63 ? g0[s] : gam;
+        float dAp = 0.f;
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+            const float gt = cc[s][i] + gam;
+            gam = a[s][i] * gt;
+            const float ahp = hh[s][i] - bb[s][i];  // a_t * h_{t-1}
+            const float gdl = gt * dl[i];
+            const float Bv = rb[s * T + i];
+            duv[i] = fmaf(gdl, Bv, duv[i]);
+            ddl[i] += gt * fmaf(uv[i], Bv, An * ahp);
+            dAp = fmaf(gdl, ahp, dAp);
+            y[i] = fmaf(rc[s * T + i], hh[s][i], y[i]);
+            if constexpr (REG) {
+                accB[s * K + i] = fmaf(gdl, uv[i], accB[s * K + i]);
+                accC[s * K + i] = fmaf(dy[i], hh[s][i], accC[s * K + i]);
+            } else {
+                atomicAdd(accB + s * T + i * 64, gdl * uv[i]);
+                atomicAdd(accC + s * T + i * 64, dy[i] * hh[s][i]);
+            }
+        }
+        dAp = wave_scan_add(dAp);
+        if (lane == 63) dA_out[s] = dAp;
     }
 }
 
@@ -287,7 +553,7 @@ __global__ __launch_bounds__(1024) void chunk_apply_fwd_kernel(ScanArgs p) {
 // K4: backward apply.  grid (n_chunks, batch, ngroups), block W*64 (W <= 8).
 // LDS: B[N][T] | C[N][T] | dB[N][T] | dC[N][T] | A2[W][N] | H0[W][N] | G0[W][N] | dAp[W][N]
 // ---------------------------------------------------------------------------
-template <typename io_t, int K>
+template <typename io_t, int K, bool FULL>
 __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
     constexpr int T = 64 * K;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -305,8 +571,8 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
     float *sG = scr + 2 * W * N + w * N;
     float *sdA = scr + 3 * W * N + w * N;
 
-    stage_tile<io_t, K>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
-    stage_tile<io_t, K>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
+    stage_tile<io_t, K, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
+    stage_tile<io_t, K, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
     for (int i = threadIdx.x; i < 2 * N * T; i += blockDim.x) sdB[i] = 0.f;  // sdB and sdC are adjacent
     __syncthreads();
 
@@ -324,14 +590,14 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
         const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
         const float Dv = p.D ? p.D[d] : 0.f;
         float dl[K], uv[K], dy[K], y[K], dsp[K], duv[K], ddl[K], go[K];
-        load_k<io_t, K>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
+        load_k<io_t, K, FULL>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
                         p.vec_io, dl);
-        load_k<io_t, K>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io, uv);
-        load_k<io_t, K>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid, p.vec_io,
+        load_k<io_t, K, FULL>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io, uv);
+        load_k<io_t, K, FULL>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid, p.vec_io,
                         go);
         float zv[K], zsig[K];
         if (p.z) {
-            load_k<io_t, K>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io, zv);
+            load_k<io_t, K, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io, zv);
 #pragma unroll
             for (int i = 0; i < K; ++i) zsig[i] = sigmoidf_(zv[i]);
         }
@@ -343,7 +609,7 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
                 sp = softplus_thr(v);
                 dspv = v <= 20.f ? sigmoidf_(v) : 1.f;  // d softplus / dx  (bwd_kernel.cuh:439-453)
             }
-            dl[i] = (i < nvalid) ? sp : 0.f;
+            dl[i] = (FULL || i < nvalid) ? sp : 0.f;
             dsp[i] = dspv;
             dy[i] = p.z ? go[i] * zv[i] * zsig[i] : go[i];
             y[i] = Dv * uv[i];
@@ -354,85 +620,32 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
 #pragma unroll
         for (int i = 0; i < K; ++i) dDp = fmaf(dy[i], uv[i], dDp);
 
-        for (int n = 0; n < N; ++n) {
-            const float a2 = sA[n];
-            const float An = a2 * MMU_LN2;
-            const float h0 = sH[n], g0 = sG[n];
-            const float *rb = sB + n * T + tl;
-            const float *rc = sC + n * T + tl;
-            float a[K], bb[K], hh[K], cc[K], Bv[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                Bv[i] = rb[i];
-                a[i] = fast_exp2(dl[i] * a2);
-                bb[i] = dl[i] * uv[i] * Bv[i];
-                cc[i] = rc[i] * dy[i];
-            }
-            // forward state recompute
-            float P = a[0], S = bb[0];
-#pragma unroll
-            for (int i = 1; i < K; ++i) {
-                S = fmaf(a[i], S, bb[i]);
-                P *= a[i];
-            }
-            const float Plane = P;
-            wave_scan_affine(P, S);
-            const float Pe = wave_shift_up1(P, 1.f);
-            const float Se = wave_shift_up1(S, 0.f);
-            float h = fmaf(Pe, h0, Se);
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                h = fmaf(a[i], h, bb[i]);
-                hh[i] = h;
-            }
-            // adjoint: gamma_out = a_i (c_i + gamma_in), composed right-to-left
-            float Q = Plane, R = 0.f;
-#pragma unroll
-            for (int i = K - 1; i >= 0; --i) R = a[i] * (cc[i] + R);
-            Q = wave_reverse(Q);
-            R = wave_reverse(R);
-            wave_scan_affine(Q, R);
-            float Qe = wave_shift_up1(Q, 1.f);
-            float Re = wave_shift_up1(R, 0.f);
-            Qe = wave_reverse(Qe);
-            Re = wave_reverse(Re);
-            float gam = fmaf(Qe, g0, Re);  // gamma entering this lane from the right
-            float dAp = 0.f;
-#pragma unroll
-            for (int i = K - 1; i >= 0; --i) {
-                const float gt = cc[i] + gam;
-                gam = a[i] * gt;
-                const float ahp = hh[i] - bb[i];  // a_t * h_{t-1}
-                const float gdl = gt * dl[i];
-                duv[i] = fmaf(gdl, Bv[i], duv[i]);
-                ddl[i] += gt * fmaf(uv[i], Bv[i], An * ahp);
-                dAp = fmaf(gdl, ahp, dAp);
-                y[i] = fmaf(rc[i], hh[i], y[i]);
-                atomicAdd(&sdB[n * T + tl + i], gdl * uv[i]);
-                atomicAdd(&sdC[n * T + tl + i], dy[i] * hh[i]);
-            }
-            dAp = wave_scan_add(dAp);
-            if (lane == 63) sdA[n] = dAp;
-        }
+        int n = 0;
+        for (; n + 1 < N; n += 2)
+            bwd_states<K, 2, false>(dl, uv, dy, y, duv, ddl, sB + n * T + tl, sC + n * T + tl, sdB + n * T + lane,
+                             sdC + n * T + lane, T, sA + n, sH + n, sG + n, sdA + n, lane);
+        if (n < N)
+            bwd_states<K, 1, false>(dl, uv, dy, y, duv, ddl, sB + n * T + tl, sC + n * T + tl, sdB + n * T + lane,
+                             sdC + n * T + lane, T, sA + n, sH + n, sG + n, sdA + n, lane);
         // per-channel outputs
         float dbp = 0.f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             ddl[i] *= dsp[i];
-            if (i < nvalid) dbp += ddl[i];
+            if (FULL || i < nvalid) dbp += ddl[i];
         }
-        store_k<io_t, K>((io_t *)p.du + (long)b * p.du_bs + (long)d * p.du_ds + t0 + tl, nvalid, p.vec_io, duv);
-        store_k<io_t, K>((io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)d * p.ddelta_ds + t0 + tl, nvalid, p.vec_io,
+        store_k<io_t, K, FULL>((io_t *)p.du + (long)b * p.du_bs + (long)d * p.du_ds + t0 + tl, nvalid, p.vec_io, duv);
+        store_k<io_t, K, FULL>((io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)d * p.ddelta_ds + t0 + tl, nvalid, p.vec_io,
                          ddl);
         if (p.z) {
             float dzv[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) dzv[i] = go[i] * y[i] * zsig[i] * (1.f + zv[i] * (1.f - zsig[i]));
-            store_k<io_t, K>((io_t *)p.dz + (long)b * p.dz_bs + (long)d * p.dz_ds + t0 + tl, nvalid, p.vec_io, dzv);
+            store_k<io_t, K, FULL>((io_t *)p.dz + (long)b * p.dz_bs + (long)d * p.dz_ds + t0 + tl, nvalid, p.vec_io, dzv);
             if (p.out_z) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) dzv[i] = y[i] * zv[i] * zsig[i];
-                store_k<io_t, K>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
+                store_k<io_t, K, FULL>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
                                  p.vec_io, dzv);
             }
         }
@@ -450,46 +663,226 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
     float *dBg = p.dB + ((long)b * p.ngroups + g) * N * L;
     float *dCg = p.dC + ((long)b * p.ngroups + g) * N * L;
     for (int idx = threadIdx.x; idx < N * T; idx += blockDim.x) {
-        const int n = idx / T, j = idx % T;
+        const int n = idx / T, j = idx % T;  // j = local token; accumulators are stored [n][j % K][j / K]
         const int t = t0 + j;
         if (t < L) {
-            dBg[(long)n * L + t] = sdB[idx];
-            dCg[(long)n * L + t] = sdC[idx];
+            const int src = n * T + (j % K) * 64 + j / K;
+            dBg[(long)n * L + t] = sdB[src];
+            dCg[(long)n * L + t] = sdC[src];
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// K5: dA[d][n], dD[d], dbias[d] = sum over (b, chunk) of part[b][c][d][N+2]
-// grid (dim), block 256
+// K4r: backward apply, register-accumulating form for dstate == NST (16 on the MM-UNet path).
+// grid (n_chunks, batch, ngroups), block W*64 with W in {1, 2, 4}: each wave walks dpg / W
+// channels and keeps its dB/dC sums for all NST states x K tokens in registers (the state loop
+// is fully unrolled so the accumulators have static indices).  They leave the wave once per
+// chunk: plain 16-B stores when W == 1, otherwise LDS atomics + one cooperative store.
+// LDS: B[N][T] | C[N][T] | (W > 1: dB[N][T] | dC[N][T]) | A2[W][N] | H0[W][N] | G0[W][N] | dAp[W][N]
+// ---------------------------------------------------------------------------
+template <typename io_t, int K, int NST, bool FULL>
+__global__ __launch_bounds__(256, 2) void chunk_apply_bwd_reg_kernel(ScanArgs p) {
+    constexpr int T = 64 * K;
+    constexpr int N = NST;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = p.seqlen;
+    const int c = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
+    const int t0 = c * T;
+    float *sB = smem;
+    float *sC = sB + N * T;
+    float *sdB = sC + N * T;                       // only present when W > 1
+    float *scr = sC + N * T + (W > 1 ? 2 * N * T : 0);
+    float *sA = scr + w * N;
+    float *sH = scr + W * N + w * N;
+    float *sG = scr + 2 * W * N + w * N;
+    float *sdA = scr + 3 * W * N + w * N;
+
+    stage_tile<io_t, K, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
+    stage_tile<io_t, K, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
+    if (W > 1)
+        for (int i = threadIdx.x; i < 2 * N * T; i += blockDim.x) sdB[i] = 0.f;
+    __syncthreads();
+
+    const int dpg = p.dim / p.ngroups;
+    const int tl = lane * K;
+    const int nvalid = L - (t0 + tl);
+    float accB[N * K], accC[N * K];
+#pragma unroll
+    for (int i = 0; i < N * K; ++i) accB[i] = accC[i] = 0.f;
+
+    for (int d = g * dpg + w; d < (g + 1) * dpg; d += W) {
+        // The B/C tile is invariant in this loop, so LICM would cache all 4*N*K/... of its values in
+        // registers on top of the 2*N*K accumulators (~350 VGPRs -> scratch spills).  Re-reading them
+        // from LDS every iteration is cheap; make the compiler do that.
+        asm volatile("" ::: "memory");
+        const long bdc = ((long)b * p.dim + d) * p.n_chunks;
+        if (lane < N) {
+            sA[lane] = p.A[(long)d * p.A_ds + (long)lane * p.A_ns] * MMU_LOG2E;
+            sH[lane] = (c > 0) ? p.x[(bdc + c - 1) * 2 * N + 2 * lane + 1] : 0.f;
+            sG[lane] = (c + 1 < p.n_chunks) ? p.gx[(bdc + c + 1) * 2 * N + 2 * lane + 1] : 0.f;
+        }
+        const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+        const float Dv = p.D ? p.D[d] : 0.f;
+        float dl[K], uv[K], dy[K], y[K], dsp[K], duv[K], ddl[K], go[K];
+        load_k<io_t, K, FULL>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
+                        p.vec_io, dl);
+        load_k<io_t, K, FULL>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io, uv);
+        load_k<io_t, K, FULL>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid, p.vec_io,
+                        go);
+        float zv[K], zsig[K];
+        if (p.z) {
+            load_k<io_t, K, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io, zv);
+#pragma unroll
+            for (int i = 0; i < K; ++i) zsig[i] = sigmoidf_(zv[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const float v = dl[i] + bias;
+            float sp = v, dspv = 1.f;
+            if (p.softplus) {
+                sp = softplus_thr(v);
+                dspv = v <= 20.f ? sigmoidf_(v) : 1.f;
+            }
+            dl[i] = (FULL || i < nvalid) ? sp : 0.f;
+            dsp[i] = dspv;
+            dy[i] = p.z ? go[i] * zv[i] * zsig[i] : go[i];
+            y[i] = Dv * uv[i];
+            duv[i] = Dv * dy[i];
+            ddl[i] = 0.f;
+        }
+        float dDp = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) dDp = fmaf(dy[i], uv[i], dDp);
+#pragma unroll
+        for (int n = 0; n < N; n += 2) {
+            bwd_states<K, 2, true>(dl, uv, dy, y, duv, ddl, sB + n * T + tl, sC + n * T + tl, accB + n * K,
+                                   accC + n * K, T, sA + n, sH + n, sG + n, sdA + n, lane);
+            // keep the unrolled state pairs in program order: letting the scheduler hoist the next
+            // pairs' LDS reads across this point costs more registers than the file has
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float dbp = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            ddl[i] *= dsp[i];
+            if (FULL || i < nvalid) dbp += ddl[i];
+        }
+        store_k<io_t, K, FULL>((io_t *)p.du + (long)b * p.du_bs + (long)d * p.du_ds + t0 + tl, nvalid, p.vec_io, duv);
+        store_k<io_t, K, FULL>((io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)d * p.ddelta_ds + t0 + tl, nvalid, p.vec_io,
+                         ddl);
+        if (p.z) {
+            float dzv[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) dzv[i] = go[i] * y[i] * zsig[i] * (1.f + zv[i] * (1.f - zsig[i]));
+            store_k<io_t, K, FULL>((io_t *)p.dz + (long)b * p.dz_bs + (long)d * p.dz_ds + t0 + tl, nvalid, p.vec_io, dzv);
+            if (p.out_z) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) dzv[i] = y[i] * zv[i] * zsig[i];
+                store_k<io_t, K, FULL>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
+                                 p.vec_io, dzv);
+            }
+        }
+        dDp = wave_sum(dDp);
+        dbp = wave_sum(dbp);
+        float *part = p.part + (((long)b * p.n_chunks + c) * p.dim + d) * (N + 2);
+        if (lane < N) part[lane] = sdA[lane];
+        if (lane == 0) {
+            part[N] = dDp;
+            part[N + 1] = dbp;
+        }
+    }
+    float *dBg = p.dB + ((long)b * p.ngroups + g) * N * L;
+    float *dCg = p.dC + ((long)b * p.ngroups + g) * N * L;
+    if (W == 1) {
+        const bool vecf = (L % K) == 0;  // dB/dC rows are contiguous fp32 allocations of ours
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            float vb[K], vc[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                vb[i] = accB[n * K + i];
+                vc[i] = accC[n * K + i];
+            }
+            store_k<float, K, FULL>(dBg + (long)n * L + t0 + tl, nvalid, vecf, vb);
+            store_k<float, K, FULL>(dCg + (long)n * L + t0 + tl, nvalid, vecf, vc);
+        }
+        return;
+    }
+    float *sdC = sdB + N * T;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            atomicAdd(sdB + n * T + i * 64 + lane, accB[n * K + i]);
+            atomicAdd(sdC + n * T + i * 64 + lane, accC[n * K + i]);
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < N * T; idx += blockDim.x) {
+        const int n = idx / T, j = idx % T;
+        const int t = t0 + j;
+        if (t < L) {
+            const int src = n * T + (j % K) * 64 + j / K;
+            dBg[(long)n * L + t] = sdB[src];
+            dCg[(long)n * L + t] = sdC[src];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5: dA[d][n], dD[d], dbias[d] += sum over a slice of (b, chunk) of part[b][c][d][N+2].
+// grid (dim, n_slices = ceil(BC / 512)), block 256.  One slice: results go straight to dA/dD/dbias.
+// Several slices: slice sums go to part2[slice][d][N+2] and reduce_slices_kernel adds them in fixed
+// order -- no float atomics, so dA/dD/dbias stay bit-reproducible.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int BC, int dim, int N,
-                                                              float *dA, float *dD, float *dbias) {
+                                                              float *dA, float *dD, float *dbias,
+                                                              float *__restrict__ part2) {
     __shared__ float red[256];
     const int d = blockIdx.x;
+    const int bc0 = blockIdx.y * 512;
+    const int bc1 = bc0 + 512 < BC ? bc0 + 512 : BC;
     const int M = N + 2;
     for (int j0 = 0; j0 < M; j0 += 32) {
-        // 8 rows of (b,c) x 32 slots per pass
         const int j = j0 + (threadIdx.x & 31);
         const int r = threadIdx.x >> 5;
         float s = 0.f;
         if (j < M)
-            for (int bc = r; bc < BC; bc += 8) s += part[((long)bc * dim + d) * M + j];
+            for (int bc = bc0 + r; bc < bc1; bc += 8) s += part[((long)bc * dim + d) * M + j];
         red[threadIdx.x] = s;
         __syncthreads();
         if (threadIdx.x < 32) {
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) t += red[k * 32 + threadIdx.x];
-            if (j < N)
+            if (part2) {
+                if (j < M) part2[((long)blockIdx.y * dim + d) * M + j] = t;
+            } else if (j < N) {
                 dA[(long)d * N + j] = t;
-            else if (j == N) {
+            } else if (j == N) {
                 if (dD) dD[d] = t;
             } else if (j == N + 1) {
                 if (dbias) dbias[d] = t;
             }
         }
         __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void reduce_slices_kernel(const float *__restrict__ part2, int n_slices, int dim, int N,
+                                                           float *dA, float *dD, float *dbias) {
+    const int d = blockIdx.x, M = N + 2;
+    for (int j = threadIdx.x; j < M; j += 64) {
+        float t = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) t += part2[((long)sl * dim + d) * M + j];
+        if (j < N)
+            dA[(long)d * N + j] = t;
+        else if (j == N) {
+            if (dD) dD[d] = t;
+        } else if (dbias)
+            dbias[d] = t;
     }
 }
 
@@ -504,10 +897,20 @@ __global__ void debug_wave_scan_kernel(const float *P, const float *S, float *oP
         p = wave_reverse(p);
         s = wave_reverse(s);
     }
-    if (variant == 0)
-        wave_scan_affine_dpp(p, s);
-    else
-        wave_scan_affine_shfl(p, s);
+    if (variant == 0) {
+        wave_scan_affine_dpp(p, s);      // compiler-lowered DPP intrinsics
+    } else if (variant == 1) {
+        wave_scan_affine_shfl(p, s);     // shuffle reference
+    } else if (variant == 2) {
+        wave_scan_affine(p, s);          // hand-written fused DPP, one scan
+    } else {
+        float p2 = p * 0.5f, s2 = -s;    // hand-written fused DPP, two interleaved scans
+        wave_scan_affine_x2(p2, s2, p, s);
+        if (variant == 4) {              // return the first of the pair instead
+            p = p2;
+            s = s2;
+        }
+    }
     if (reverse) {
         p = wave_reverse(p);
         s = wave_reverse(s);
@@ -519,7 +922,9 @@ __global__ void debug_wave_scan_kernel(const float *P, const float *S, float *oP
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-inline int items_per_lane(int dstate) { return dstate <= 32 ? 4 : (dstate <= 64 ? 2 : 1); }
+// tokens per lane of the chunk kernels (chunk = 64 * this).  dstate <= 16 uses 2 so that the backward's
+// per-lane dB/dC register accumulators (2 * dstate * K) fit next to its working set at 2+ waves/SIMD.
+inline int items_per_lane(int dstate) { return dstate <= 16 ? 2 : (dstate <= 32 ? 4 : (dstate <= 64 ? 2 : 1)); }
 
 inline bool aligned_to(const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; }
 inline bool mult(long v, int k) { return (v % k) == 0; }
@@ -534,27 +939,76 @@ int set_lds(F kernel, size_t bytes) {
     return 0;
 }
 
+// runtime bool -> template bool
+#define MMU_BOOL(cond, NAME, ...)        \
+    do {                                 \
+        if (cond) {                      \
+            constexpr bool NAME = true;  \
+            __VA_ARGS__                  \
+        } else {                         \
+            constexpr bool NAME = false; \
+            __VA_ARGS__                  \
+        }                                \
+    } while (0)
+
+// K1 in its fast (8 tokens / lane, 4 chunks per wave) or generic form
+template <typename io_t, int K, bool BWD>
+int launch_reduce(const ScanArgs &a, int W, hipStream_t st) {
+    const int N = a.dstate, T = 64 * K;
+    if (K == 2 && N <= 16) {
+        const bool full = a.vec_io && a.vec_bc && a.seqlen % 512 == 0;
+        size_t lds = sizeof(float) * ((size_t)N * 512 + (size_t)W * N * 9);
+        dim3 grid((a.n_chunks + 3) / 4, a.batch, a.ngroups);
+        MMU_BOOL(full, FULL, {
+            if (int r = set_lds(chunk_reduce8_kernel<io_t, BWD, FULL>, lds)) return r;
+            chunk_reduce8_kernel<io_t, BWD, FULL><<<grid, W * 64, lds, st>>>(a);
+        });
+    } else {
+        const bool full = a.vec_io && a.vec_bc && a.seqlen % T == 0;
+        size_t lds = sizeof(float) * ((size_t)N * T + (size_t)W * N * 3);
+        dim3 grid(a.n_chunks, a.batch, a.ngroups);
+        MMU_BOOL(full, FULL, {
+            if (int r = set_lds(chunk_reduce_kernel<io_t, K, BWD, FULL>, lds)) return r;
+            chunk_reduce_kernel<io_t, K, BWD, FULL><<<grid, W * 64, lds, st>>>(a);
+        });
+    }
+    MMU_HIP_LAUNCH_CHECK(BWD ? "chunk_reduce<bwd>" : "chunk_reduce<fwd>");
+    return 0;
+}
+
 template <typename io_t, int K>
 int launch_fwd(const ScanArgs &a, hipStream_t st) {
     const int N = a.dstate, T = 64 * K;
     const int dpg = a.dim / a.ngroups;
     const int W = dpg < 16 ? dpg : 16;
     dim3 grid(a.n_chunks, a.batch, a.ngroups);
-    {
-        size_t lds = sizeof(float) * ((size_t)N * T + (size_t)W * N * 3);
-        if (int r = set_lds(chunk_reduce_kernel<io_t, K, false>, lds)) return r;
-        chunk_reduce_kernel<io_t, K, false><<<grid, W * 64, lds, st>>>(a);
-        MMU_HIP_LAUNCH_CHECK("chunk_reduce<fwd>");
-    }
+    const bool full = a.vec_io && a.vec_bc && a.seqlen % T == 0;  // no ragged tail, everything aligned
+    if (int r = launch_reduce<io_t, K, false>(a, W, st)) return r;
     {
         const long total = (long)a.batch * a.dim * N;
         chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.x, total, a.n_chunks, N, 0);
         MMU_HIP_LAUNCH_CHECK("chunk_carry");
     }
     {
-        size_t lds = sizeof(float) * ((size_t)2 * N * T + (size_t)W * N * 2);
-        if (int r = set_lds(chunk_apply_fwd_kernel<io_t, K>, lds)) return r;
-        chunk_apply_fwd_kernel<io_t, K><<<grid, W * 64, lds, st>>>(a);
+        // wider tiles (8 tokens per lane) when the B/C tile still fits twice per CU
+        constexpr int KX = K == 2 ? 8 : K;
+        const bool wide = KX != K && N <= 16;
+        if (wide) {
+            size_t lds = sizeof(float) * ((size_t)2 * N * 64 * KX + (size_t)W * N * 2);
+            dim3 gridw((a.seqlen + 64 * KX - 1) / (64 * KX), a.batch, a.ngroups);
+            const int Ww = W > 8 ? 8 : W;  // two 8-wave workgroups per CU: one loads its tile while the other scans
+            lds = sizeof(float) * ((size_t)2 * N * 64 * KX + (size_t)Ww * N * 2);
+            MMU_BOOL(full && a.seqlen % (64 * KX) == 0, FULL, {
+                if (int r = set_lds(chunk_apply_fwd_kernel<io_t, KX, K, FULL>, lds)) return r;
+                chunk_apply_fwd_kernel<io_t, KX, K, FULL><<<gridw, Ww * 64, lds, st>>>(a);
+            });
+        } else {
+            size_t lds = sizeof(float) * ((size_t)2 * N * T + (size_t)W * N * 2);
+            MMU_BOOL(full, FULL, {
+                if (int r = set_lds(chunk_apply_fwd_kernel<io_t, K, K, FULL>, lds)) return r;
+                chunk_apply_fwd_kernel<io_t, K, K, FULL><<<grid, W * 64, lds, st>>>(a);
+            });
+        }
         MMU_HIP_LAUNCH_CHECK("chunk_apply_fwd");
     }
     return 0;
@@ -565,36 +1019,39 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st) {
     const int N = a.dstate, T = 64 * K;
     const int dpg = a.dim / a.ngroups;
     dim3 grid(a.n_chunks, a.batch, a.ngroups);
+    const bool full = a.vec_io && a.vec_bc && a.seqlen % T == 0;
     const size_t xs = (size_t)a.batch * a.dim * a.n_chunks * 2 * N;
     a.gx = ws;
     a.part = ws + xs;
     const int W16 = dpg < 16 ? dpg : 16;
     if (!have_x) {
         a.x = ws + xs + (size_t)a.batch * a.n_chunks * a.dim * (N + 2);
-        size_t lds = sizeof(float) * ((size_t)N * T + (size_t)W16 * N * 3);
-        if (int r = set_lds(chunk_reduce_kernel<io_t, K, false>, lds)) return r;
-        chunk_reduce_kernel<io_t, K, false><<<grid, W16 * 64, lds, st>>>(a);
-        MMU_HIP_LAUNCH_CHECK("chunk_reduce<fwd> (bwd recompute)");
+        if (int r = launch_reduce<io_t, K, false>(a, W16, st)) return r;
         const long total = (long)a.batch * a.dim * N;
         chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.x, total, a.n_chunks, N, 0);
         MMU_HIP_LAUNCH_CHECK("chunk_carry (bwd recompute)");
     }
-    {
-        size_t lds = sizeof(float) * ((size_t)N * T + (size_t)W16 * N * 3);
-        if (int r = set_lds(chunk_reduce_kernel<io_t, K, true>, lds)) return r;
-        chunk_reduce_kernel<io_t, K, true><<<grid, W16 * 64, lds, st>>>(a);
-        MMU_HIP_LAUNCH_CHECK("chunk_reduce<bwd>");
-    }
+    if (int r = launch_reduce<io_t, K, true>(a, W16, st)) return r;
     {
         const long total = (long)a.batch * a.dim * N;
         chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.gx, total, a.n_chunks, N, 1);
         MMU_HIP_LAUNCH_CHECK("chunk_carry(reverse)");
     }
-    {
+    if (K == 2 && N == 16) {
+        const int W = dpg >= 16 ? 4 : (dpg >= 8 ? 2 : 1);
+        size_t lds = sizeof(float) * ((size_t)(W > 1 ? 4 : 2) * N * T + (size_t)W * N * 4);
+        MMU_BOOL(full, FULL, {
+            if (int r = set_lds(chunk_apply_bwd_reg_kernel<io_t, 2, 16, FULL>, lds)) return r;
+            chunk_apply_bwd_reg_kernel<io_t, 2, 16, FULL><<<grid, W * 64, lds, st>>>(a);
+        });
+        MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd_reg");
+    } else {
         const int W = dpg < 8 ? dpg : 8;
         size_t lds = sizeof(float) * ((size_t)4 * N * T + (size_t)W * N * 4);
-        if (int r = set_lds(chunk_apply_bwd_kernel<io_t, K>, lds)) return r;
-        chunk_apply_bwd_kernel<io_t, K><<<grid, W * 64, lds, st>>>(a);
+        MMU_BOOL(full, FULL, {
+            if (int r = set_lds(chunk_apply_bwd_kernel<io_t, K, FULL>, lds)) return r;
+            chunk_apply_bwd_kernel<io_t, K, FULL><<<grid, W * 64, lds, st>>>(a);
+        });
         MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd");
     }
     return 0;  // K5 (reduce_partials) is launched by the extern "C" wrapper, which owns dA/dD/dbias
@@ -614,7 +1071,8 @@ extern "C" size_t mmu_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, i
     const size_t nc = ((size_t)seqlen + T - 1) / T;
     const size_t xs = (size_t)batch * dim * nc * 2 * dstate;
     const size_t parts = (size_t)batch * nc * dim * (dstate + 2);
-    return sizeof(float) * (xs + parts + (have_x ? 0 : xs));
+    const size_t slices = ((size_t)batch * nc + 511) / 512 * dim * (dstate + 2);
+    return sizeof(float) * (xs + parts + (have_x ? 0 : xs) + slices);
 }
 
 #define SCAN_COMMON_CHECKS(p)                                                                                       \
@@ -714,8 +1172,18 @@ extern "C" int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream
     }
     if (r) return r;
     const size_t xs = (size_t)p->batch * p->dim * p->n_chunks * 2 * p->dstate;
-    reduce_partials_kernel<<<p->dim, 256, 0, st>>>(p->workspace + xs, p->batch * p->n_chunks, p->dim, p->dstate,
-                                                   p->dA, p->dD, p->ddelta_bias);
+    {
+        const int BC = p->batch * p->n_chunks;
+        const int n_slices = (BC + 511) / 512;
+        const size_t parts = (size_t)BC * p->dim * (p->dstate + 2);
+        float *part2 = n_slices > 1 ? p->workspace + xs + parts + (have_x ? 0 : xs) : nullptr;
+        dim3 g5(p->dim, n_slices);
+        reduce_partials_kernel<<<g5, 256, 0, st>>>(p->workspace + xs, BC, p->dim, p->dstate, p->dA, p->dD,
+                                                   p->ddelta_bias, part2);
+        if (part2)
+            reduce_slices_kernel<<<p->dim, 64, 0, st>>>(part2, n_slices, p->dim, p->dstate, p->dA, p->dD,
+                                                        p->ddelta_bias);
+    }
     MMU_HIP_LAUNCH_CHECK("reduce_partials");
     return 0;
 }

@@ -9,7 +9,7 @@ pointers only.
 
 Differences a caller can observe:
   * the chunk-state tensor ``x`` is ``(batch, dim, n_chunks, 2*dstate)`` with
-    ``n_chunks = ceil(seqlen / chunk_len(dstate))`` (chunk_len 256 for dstate<=32) instead of
+    ``n_chunks = ceil(seqlen / chunk_len(dstate))`` (chunk_len 128 for dstate<=16) instead of
     the reference's fixed 2048; ``x[:, :, -1, 1::2]`` is still the last state
     (selective_scan_interface.py:40);
   * real ``A`` and input-dependent (``dim() >= 3``) ``B``/``C`` only -- the only variant
@@ -61,12 +61,18 @@ def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     return batch, dim, seqlen, dstate, g
 
 
-def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
-    """selective_scan_cuda.fwd: returns ``[out, x]`` or ``[out, x, out_z]`` (selective_scan.cpp:226-336)."""
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
+    """selective_scan_cuda.fwd: returns ``[out, x]`` or ``[out, x, out_z]`` (selective_scan.cpp:226-336).
+
+    ``want_out=False`` (extension over the reference signature, only valid with ``z_``): do not
+    materialise the un-gated ``out``; the list then holds ``None`` in its place.  The fused
+    ``mamba_inner`` path uses it -- its backward recomputes y, so writing ``out`` would be a wasted
+    [batch, dim, L] store per call."""
     batch, dim, seqlen, dstate, g = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     T = chunk_len(dstate, u.dtype)
     n_chunks = (seqlen + T - 1) // T
-    out = torch.empty_like(delta)
+    _check(want_out or z_ is not None, "selective_scan_fwd: want_out=False needs z")
+    out = torch.empty_like(delta) if want_out else None
     out_z = torch.empty_like(z_) if z_ is not None else None
     x = torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device, dtype=torch.float32)
     p = _lib.ScanFwdParams()
@@ -76,10 +82,11 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     p.n_chunks = n_chunks
     p.u, p.delta, p.A, p.B, p.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
     p.D, p.z, p.delta_bias = _lib.ptr(D_), _lib.ptr(z_), _lib.ptr(delta_bias_)
-    p.out, p.out_z, p.x = out.data_ptr(), _lib.ptr(out_z), x.data_ptr()
+    p.out, p.out_z, p.x = _lib.ptr(out), _lib.ptr(out_z), x.data_ptr()
     p.u_bs, p.u_ds = u.stride(0), u.stride(1)
     p.delta_bs, p.delta_ds = delta.stride(0), delta.stride(1)
-    p.out_bs, p.out_ds = out.stride(0), out.stride(1)
+    if out is not None:
+        p.out_bs, p.out_ds = out.stride(0), out.stride(1)
     if z_ is not None:
         p.z_bs, p.z_ds = z_.stride(0), z_.stride(1)
         p.out_z_bs, p.out_z_ds = out_z.stride(0), out_z.stride(1)

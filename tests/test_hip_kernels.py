@@ -44,7 +44,7 @@ def _bc4(t):
 
 # --------------------------------------------------------------------------- wave primitives
 @pytest.mark.parametrize("reverse", [0, 1])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_wave_affine_scan(reverse, variant):
     import ctypes
     from mm_unet_amd import _lib
@@ -57,6 +57,8 @@ def test_wave_affine_scan(reverse, variant):
                                               reverse, variant, _lib.stream_of(P)))
     torch.cuda.synchronize()
     p, s = P.cpu().double().view(nw, 64), S.cpu().double().view(nw, 64)
+    if variant == 4:  # first scan of the interleaved pair runs on (0.5*P, -S)
+        p, s = 0.5 * p, -s
     if reverse:
         p, s = p.flip(1), s.flip(1)
     ep, es = torch.empty_like(p), torch.empty_like(s)

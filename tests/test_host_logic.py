@@ -22,7 +22,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"libmmunet_hip.so does not export {name}"
     lib = _lib.lib()
     assert lib.mmu_abi_version() == 1
-    assert lib.mmu_scan_chunk_len(16, 0) == 256 and lib.mmu_scan_chunk_len(64, 0) == 128
+    assert lib.mmu_scan_chunk_len(16, 0) == 128 and lib.mmu_scan_chunk_len(32, 0) == 256
+    assert lib.mmu_scan_chunk_len(64, 0) == 128
     assert lib.mmu_scan_chunk_len(300, 0) == 0
 
 
