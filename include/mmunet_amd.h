@@ -161,6 +161,27 @@ typedef struct {
 
 int mmu_causal_conv1d_update(const mmu_conv1d_update_params *p, void *stream);
 
+/* ---- MorphMamba deformable sampling -------- */
+/* Replaces, inside MMConv.forward, _coordinate_map_scaling (x and y) + the [B, H*K, W, 2] grid +
+ * F.grid_sample(bilinear, zeros, align_corners=True) and their autograd
+ * (src/UM_Net/MMUNet.py:196-242,259-263).  The column of tap k at pixel (h, w) is the integer
+ * w + k - K/2, only the row coordinate y is learned, so the gather is a 2-tap vertical lerp.
+ * All tensors contiguous float32.
+ *   fwd: out[b,c,h*K+k,w] from input[b,c,:,:] and y[b,k,h,w] (pixels, unclamped)
+ *   bwd: dinput (zeroed inside, accumulated with float atomics) and dy (clamp mask applied) */
+typedef struct {
+    int32_t batch, channels, height, width, taps;
+    const float *input;  /* [batch, channels, height, width] */
+    const float *y;      /* [batch, taps, height, width] */
+    float *out;          /* fwd: [batch, channels, height*taps, width] */
+    const float *dout;   /* bwd: same shape as out */
+    float *dinput;       /* bwd: [batch, channels, height, width] */
+    float *dy;           /* bwd: [batch, taps, height, width] */
+} mmu_morph_params;
+
+int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
+int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
+
 /* ---- test hooks (exercise the wave-level primitives on the GPU) -------- */
 /* Runs the in-wave affine-pair scan on n_waves*64 (P,S) pairs, one wave per 64.
  * reverse=0: forward inclusive; reverse=1: reverse inclusive.  variant 0 = DPP intrinsics,

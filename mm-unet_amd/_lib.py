@@ -62,11 +62,16 @@ class Conv1dUpdateParams(ctypes.Structure):
     )
 
 
+class MorphParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "channels", "height", "width", "taps")]
+                + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")])
+
+
 # every symbol include/mmunet_amd.h declares (tests check that the library exports all of them)
 EXPORTS = (
     "mmu_abi_version", "mmu_last_error", "mmu_scan_chunk_len", "mmu_scan_bwd_workspace_bytes",
     "mmu_selective_scan_fwd", "mmu_selective_scan_bwd", "mmu_causal_conv1d_fwd", "mmu_causal_conv1d_bwd",
-    "mmu_causal_conv1d_update", "mmu_debug_wave_scan",
+    "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_debug_wave_scan",
 )
 
 _lib = None
@@ -93,7 +98,8 @@ def lib():
     L.mmu_scan_bwd_workspace_bytes.argtypes = [ctypes.c_int] * 6
     for name, st in (("mmu_selective_scan_fwd", ScanFwdParams), ("mmu_selective_scan_bwd", ScanBwdParams),
                      ("mmu_causal_conv1d_fwd", Conv1dFwdParams), ("mmu_causal_conv1d_bwd", Conv1dBwdParams),
-                     ("mmu_causal_conv1d_update", Conv1dUpdateParams)):
+                     ("mmu_causal_conv1d_update", Conv1dUpdateParams),
+                     ("mmu_morph_sample_fwd", MorphParams), ("mmu_morph_sample_bwd", MorphParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba
+from .morph_sample import morph_sample
 
 
 class MMConv(nn.Module):
@@ -67,7 +68,7 @@ class MMConv(nn.Module):
             out = torch.cat([out, x_flat[:, :, He * W:].reshape(B, C, 1, W)], dim=2)
         return out
 
-    def get_coordinate_map_2D(self, offset, morph, extend_scope=1.0, device=None):
+    def get_coordinate_map_2D(self, offset, morph, extend_scope=1.0, device=None, rows_only=False):
         """Returns (y_map, x_map), each (B, H*K, W): sampling rows / columns of the K taps
         (MMUNet.py:122-193).  Only the row (y) coordinate is learned."""
         if morph not in (0, 1):
@@ -96,6 +97,8 @@ class MMConv(nn.Module):
         y_keep = self.inverse_two_row_columnwise_flatten(seq.transpose(-1, -2), H, W)
         weight = torch.clamp(F.softplus(self.altho), min=0.01)
         y = weight * y_keep + y_new
+        if rows_only:
+            return y  # (B, K, H, W): all the fused sampler needs
         # "b k h w -> b (h k) w"
         y_map = y.permute(0, 2, 1, 3).reshape(B, H * K, W)
         x_map = x_new.permute(0, 2, 1, 3).reshape(B, H * K, W)
@@ -119,8 +122,11 @@ class MMConv(nn.Module):
 
     def forward(self, input):
         offset = self.tanh(self.gn_offset(self.offset_conv(input)))
-        y_map, x_map = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope)
-        deformed = self.get_interpolated_feature(input, y_map, x_map)
+        # Fused HIP sampler (morph_sample): the tap columns are the integers w + k - K//2, so only the
+        # row coordinates are passed on.  get_interpolated_feature (grid_sample) stays as the
+        # reference-shaped method and is what the fused op is tested against.
+        y_rows = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope, rows_only=True)
+        deformed = morph_sample(input, y_rows)
         output = self.dsc_conv_x(deformed) if self.morph == 0 else self.dsc_conv_y(deformed)
         return self.gn(output)
 
@@ -165,7 +171,11 @@ class CBAM(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
-        c_out = self.sigmoid(self.mlp(self.avg_pool(x)) + self.mlp(self.max_pool(x)))
+        # global max as a flat reduction: ATen's adaptive_max_pool2d kernel takes 6 ms on the
+        # [8, 64, 256, 256] stem map (one thread per output element); same value, and like the pooling
+        # op the gradient goes to one arg-max element.
+        x_max = x.flatten(2).max(dim=2)[0].unsqueeze(-1).unsqueeze(-1)
+        c_out = self.sigmoid(self.mlp(self.avg_pool(x)) + self.mlp(x_max))
         y1 = c_out * x
         s_avg = torch.mean(y1, dim=1, keepdim=True)
         s_max, _ = torch.max(y1, dim=1, keepdim=True)

@@ -1,0 +1,62 @@
+"""``morph_sample`` -- MMConv's deformable sampling as one HIP op (fwd + bwd).
+
+Stands where MMConv.get_interpolated_feature stands in the reference (src/UM_Net/MMUNet.py:196-242):
+coordinate clamp + scaling to [-1, 1] + grid construction + ``F.grid_sample(bilinear, zeros,
+align_corners=True)``.  In MMConv the sampling column of tap k at pixel (h, w) is the integer
+``w + k - K//2`` (MMUNet.py:141-151) and only the row coordinate is learned, so the op takes the row
+coordinate map alone:
+
+    out[b, c, h*K + k, w] = lerp(input[b, c, floor(yc), col], input[b, c, floor(yc)+1, col], frac(yc))
+    yc = clamp(y[b, k, h, w], 0, H-1),  col = clamp(w + k - K//2, 0, W-1)
+
+Gradients: d input (float atomics, like ATen's grid_sampler backward) and d y (zero where y was
+clamped, like torch.clamp).  float32 only -- ``F.grid_sample`` is on autocast's fp32 list, so the
+reference computes this step in fp32 under autocast as well.
+"""
+import torch
+
+from . import _lib
+
+
+class MorphSampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, y):
+        _lib.require_gpu(input, y)
+        if input.dim() != 4 or y.dim() != 4 or y.shape[0] != input.shape[0] or y.shape[2:] != input.shape[2:]:
+            raise RuntimeError("morph_sample: input must be (B, C, H, W) and y (B, K, H, W)")
+        if y.shape[1] % 2 != 1:
+            raise RuntimeError("morph_sample: the number of taps K must be odd")
+        x = input.float().contiguous()
+        yy = y.float().contiguous()
+        B, C, H, W = x.shape
+        K = yy.shape[1]
+        out = torch.empty((B, C, H * K, W), device=x.device, dtype=torch.float32)
+        p = _lib.MorphParams()
+        p.batch, p.channels, p.height, p.width, p.taps = B, C, H, W, K
+        p.input, p.y, p.out = x.data_ptr(), yy.data_ptr(), out.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_morph_sample_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, yy)
+        ctx.in_dtype, ctx.y_dtype = input.dtype, y.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, yy = ctx.saved_tensors
+        B, C, H, W = x.shape
+        K = yy.shape[1]
+        g = dout.float().contiguous()
+        dinput = torch.empty_like(x)
+        dy = torch.empty_like(yy)
+        p = _lib.MorphParams()
+        p.batch, p.channels, p.height, p.width, p.taps = B, C, H, W, K
+        p.input, p.y, p.dout = x.data_ptr(), yy.data_ptr(), g.data_ptr()
+        p.dinput, p.dy = dinput.data_ptr(), dy.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_morph_sample_bwd(p, _lib.stream_of(x)))
+        return dinput.to(ctx.in_dtype), dy.to(ctx.y_dtype)
+
+
+def morph_sample(input, y):
+    """input (B, C, H, W), y (B, K, H, W) row coordinates in pixels -> (B, C, H*K, W)."""
+    return MorphSampleFn.apply(input, y)

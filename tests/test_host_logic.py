@@ -47,7 +47,8 @@ def test_param_structs_match_header_field_order():
     for struct, cls in (("mmu_scan_fwd_params", _lib.ScanFwdParams), ("mmu_scan_bwd_params", _lib.ScanBwdParams),
                         ("mmu_conv1d_fwd_params", _lib.Conv1dFwdParams),
                         ("mmu_conv1d_bwd_params", _lib.Conv1dBwdParams),
-                        ("mmu_conv1d_update_params", _lib.Conv1dUpdateParams)):
+                        ("mmu_conv1d_update_params", _lib.Conv1dUpdateParams),
+                        ("mmu_morph_params", _lib.MorphParams)):
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 
 

