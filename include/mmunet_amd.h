@@ -103,7 +103,7 @@ typedef struct {
     const float *x;          /* chunk states from the forward, or NULL (recomputed) */
     void *du, *ddelta;       /* [batch, dim, L], I/O dtype */
     float *dA;               /* [dim, dstate] contiguous, OVERWRITTEN (not accumulated) */
-    float *dB, *dC;          /* [batch, G, dstate, L] contiguous float32, overwritten */
+    float *dB, *dC;          /* [batch, G, dstate, L] float32, strides (dB_bs, dB_gs, dB_ns, 1) / dC_*, overwritten */
     float *dD;               /* [dim] or NULL */
     float *ddelta_bias;      /* [dim] or NULL */
     void *dz;                /* [batch, dim, L] (may be a strided view); required iff z */
@@ -113,6 +113,7 @@ typedef struct {
     int64_t du_bs, du_ds, ddelta_bs, ddelta_ds, dz_bs, dz_ds, out_z_bs, out_z_ds;
     int64_t A_ds, A_ns;
     int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns;
+    int64_t dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
 } mmu_scan_bwd_params;
 
 int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream);

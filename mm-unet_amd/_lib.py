@@ -34,7 +34,8 @@ class ScanBwdParams(ctypes.Structure):
                               "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z", "workspace")]
         + [(n, _i64) for n in ("u_bs", "u_ds", "delta_bs", "delta_ds", "z_bs", "z_ds", "dout_bs", "dout_ds",
                                "du_bs", "du_ds", "ddelta_bs", "ddelta_ds", "dz_bs", "dz_ds", "out_z_bs",
-                               "out_z_ds", "A_ds", "A_ns", "B_bs", "B_gs", "B_ns", "C_bs", "C_gs", "C_ns")]
+                               "out_z_ds", "A_ds", "A_ns", "B_bs", "B_gs", "B_ns", "C_bs", "C_gs", "C_ns",
+                               "dB_bs", "dB_gs", "dB_ns", "dC_bs", "dC_gs", "dC_ns")]
     )
 
 

@@ -40,6 +40,7 @@ struct ScanArgs {
     int batch, dim, seqlen, dstate, ngroups, n_chunks, softplus;
     int vec_io;   // u/delta/z/out/... K-groups naturally aligned
     int vec_bc;   // B/C rows K-aligned
+    int vec_dbc;  // dB/dC rows K-aligned
     const void *u, *delta, *z, *B, *C, *dout;
     const float *A, *D, *delta_bias;
     void *out, *out_z, *du, *ddelta, *dz;
@@ -50,6 +51,7 @@ struct ScanArgs {
     long u_bs, u_ds, delta_bs, delta_ds, z_bs, z_ds, out_bs, out_ds, out_z_bs, out_z_ds;
     long dout_bs, dout_ds, du_bs, du_ds, ddelta_bs, ddelta_ds, dz_bs, dz_ds;
     long A_ds, A_ns, B_bs, B_gs, B_ns, C_bs, C_gs, C_ns;
+    long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
 };
 
 // Stage one [N][T] tile of B or C (tokens [t0, t0+T) of batch b, group g) into LDS as fp32.
@@ -660,15 +662,15 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
     }
     __syncthreads();
     // dB / dC of this (b, g, chunk): every channel of the group has been added -> plain stores
-    float *dBg = p.dB + ((long)b * p.ngroups + g) * N * L;
-    float *dCg = p.dC + ((long)b * p.ngroups + g) * N * L;
+    float *dBg = p.dB + (long)b * p.dB_bs + (long)g * p.dB_gs;
+    float *dCg = p.dC + (long)b * p.dC_bs + (long)g * p.dC_gs;
     for (int idx = threadIdx.x; idx < N * T; idx += blockDim.x) {
         const int n = idx / T, j = idx % T;  // j = local token; accumulators are stored [n][j % K][j / K]
         const int t = t0 + j;
         if (t < L) {
             const int src = n * T + (j % K) * 64 + j / K;
-            dBg[(long)n * L + t] = sdB[src];
-            dCg[(long)n * L + t] = sdC[src];
+            dBg[(long)n * p.dB_ns + t] = sdB[src];
+            dCg[(long)n * p.dC_ns + t] = sdC[src];
         }
     }
 }
@@ -793,10 +795,10 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_reg_kernel(ScanArgs p)
             part[N + 1] = dbp;
         }
     }
-    float *dBg = p.dB + ((long)b * p.ngroups + g) * N * L;
-    float *dCg = p.dC + ((long)b * p.ngroups + g) * N * L;
+    float *dBg = p.dB + (long)b * p.dB_bs + (long)g * p.dB_gs;
+    float *dCg = p.dC + (long)b * p.dC_bs + (long)g * p.dC_gs;
     if (W == 1) {
-        const bool vecf = (L % K) == 0;  // dB/dC rows are contiguous fp32 allocations of ours
+        const bool vecf = p.vec_dbc;
 #pragma unroll
         for (int n = 0; n < N; ++n) {
             float vb[K], vc[K];
@@ -805,8 +807,8 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_reg_kernel(ScanArgs p)
                 vb[i] = accB[n * K + i];
                 vc[i] = accC[n * K + i];
             }
-            store_k<float, K, FULL>(dBg + (long)n * L + t0 + tl, nvalid, vecf, vb);
-            store_k<float, K, FULL>(dCg + (long)n * L + t0 + tl, nvalid, vecf, vc);
+            store_k<float, K, false>(dBg + (long)n * p.dB_ns + t0 + tl, nvalid, vecf, vb);
+            store_k<float, K, false>(dCg + (long)n * p.dC_ns + t0 + tl, nvalid, vecf, vc);
         }
         return;
     }
@@ -825,8 +827,8 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_reg_kernel(ScanArgs p)
         const int t = t0 + j;
         if (t < L) {
             const int src = n * T + (j % K) * 64 + j / K;
-            dBg[(long)n * L + t] = sdB[src];
-            dCg[(long)n * L + t] = sdC[src];
+            dBg[(long)n * p.dB_ns + t] = sdB[src];
+            dCg[(long)n * p.dC_ns + t] = sdC[src];
         }
     }
 }
@@ -1148,6 +1150,10 @@ extern "C" int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream
     a.dz_bs = p->dz_bs; a.dz_ds = p->dz_ds; a.out_z_bs = p->out_z_bs; a.out_z_ds = p->out_z_ds;
     a.A_ds = p->A_ds; a.A_ns = p->A_ns; a.B_bs = p->B_bs; a.B_gs = p->B_gs; a.B_ns = p->B_ns;
     a.C_bs = p->C_bs; a.C_gs = p->C_gs; a.C_ns = p->C_ns;
+    a.dB_bs = p->dB_bs; a.dB_gs = p->dB_gs; a.dB_ns = p->dB_ns;
+    a.dC_bs = p->dC_bs; a.dC_gs = p->dC_gs; a.dC_ns = p->dC_ns;
+    a.vec_dbc = aligned_to(p->dB, 4 * K) && aligned_to(p->dC, 4 * K) && mult(p->dB_bs, K) && mult(p->dB_gs, K) &&
+                mult(p->dB_ns, K) && mult(p->dC_bs, K) && mult(p->dC_gs, K) && mult(p->dC_ns, K);
     const size_t al = es * K;
     a.vec_io = aligned_to(p->u, al) && aligned_to(p->delta, al) && aligned_to(p->z, al) && aligned_to(p->dout, al) &&
                aligned_to(p->du, al) && aligned_to(p->ddelta, al) && aligned_to(p->dz, al) &&

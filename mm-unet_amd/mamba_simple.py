@@ -25,7 +25,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .causal_conv1d_interface import causal_conv1d_fn
-from .selective_scan_interface import mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn
+from .selective_scan_interface import _dbl_view, mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn
+from .tall_gemm import proj_tokens
 
 
 class Mamba(nn.Module):
@@ -105,13 +106,22 @@ class Mamba(nn.Module):
                                           g("dt_proj").weight, A, None, None, g("D").float(),
                                           delta_bias=g("dt_proj").bias.float(), delta_softplus=True)
 
+    def _out_proj(self, y):
+        """(B, d_inner, L) -> (B, L, d_model): out_proj applied tokens-last (mamba_simple.py:270)."""
+        batch, _, seqlen = y.shape
+        o = proj_tokens(self.out_proj.weight, _dbl_view(y))
+        if self.out_proj.bias is not None:
+            o = o + self.out_proj.bias.view(-1, 1)
+        return o.view(-1, batch, seqlen).permute(1, 2, 0)
+
     def forward(self, hidden_states, inference_params=None):
         """hidden_states: (B, L, D) -> (out (B, L, D), o_1, o_2, o_3)."""
         if inference_params is not None:
             raise NotImplementedError("incremental decoding (inference_params/step) is outside the MM-UNet path")
         batch, seqlen, dim = hidden_states.shape
         # in_proj fused with the BLD -> [2*d_inner][B][L] transpose (mamba_simple.py:201-205)
-        xz = (self.in_proj.weight @ hidden_states.reshape(batch * seqlen, dim).t()) \
+        # (proj_tokens = W @ X with a split-K weight gradient: the reduction runs over all B*L tokens)
+        xz = proj_tokens(self.in_proj.weight, hidden_states.reshape(batch * seqlen, dim).t()) \
             .view(2 * self.d_inner, batch, seqlen).permute(1, 0, 2)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(dtype=xz.dtype).view(1, -1, 1)
@@ -129,12 +139,11 @@ class Mamba(nn.Module):
                 out_s = self._branch(xz_s, "_s")
                 out_s = out_s.reshape(batch, self.d_inner, seqlen // ns, ns).permute(0, 1, 3, 2).flatten(-2)
                 o_1, o_2, o_3 = out, out_b, out_s
-                out = F.linear((out + out_b.flip([-1]) + out_s).permute(0, 2, 1), self.out_proj.weight,
-                               self.out_proj.bias)
+                out = self._out_proj(out + out_b.flip([-1]) + out_s)
             elif self.bimamba_type == "v2":
                 out = self._branch(xz, "")
                 out_b = self._branch(xz.flip([-1]), "_b")
-                out = F.linear((out + out_b.flip([-1])).permute(0, 2, 1), self.out_proj.weight, self.out_proj.bias)
+                out = self._out_proj(out + out_b.flip([-1]))
             else:
                 A = -torch.exp(self.A_log.float())
                 out = mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,

@@ -98,10 +98,14 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
     return [out, x, out_z] if z_ is not None else [out, x]
 
 
-def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z):
+def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
+        dB_out=None, dC_out=None):
     """selective_scan_cuda.bwd: returns ``[du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]``
     (selective_scan.cpp:338-492).  ``out_`` is accepted for signature parity and not read: y is
-    recomputed from the states the kernel rebuilds anyway."""
+    recomputed from the states the kernel rebuilds anyway.
+
+    ``dB_out`` / ``dC_out`` (extension): pre-allocated float32 (batch, groups, dstate, L) views with unit
+    L stride to receive dB / dC (e.g. rows of the projection-gradient matrix), saving a copy."""
     batch, dim, seqlen, dstate, g = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     _lib.require_gpu(dout, x_, dz_)
     _check(dout.dtype == u.dtype and tuple(dout.shape) == (batch, dim, seqlen) and dout.stride(-1) == 1,
@@ -126,8 +130,13 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
     dA = torch.empty((dim, dstate), device=u.device, dtype=torch.float32)
-    dB = torch.empty((batch, g, dstate, seqlen), device=u.device, dtype=torch.float32)
-    dC = torch.empty((batch, g, dstate, seqlen), device=u.device, dtype=torch.float32)
+    def _acc(t):
+        if t is None:
+            return torch.empty((batch, g, dstate, seqlen), device=u.device, dtype=torch.float32)
+        _check(t.dtype == torch.float32 and tuple(t.shape) == (batch, g, dstate, seqlen) and t.stride(-1) == 1,
+               "selective_scan_bwd: dB_out/dC_out must be float32 (batch, groups, dstate, L) with unit L stride")
+        return t
+    dB, dC = _acc(dB_out), _acc(dC_out)
     dD = torch.empty_like(D_) if D_ is not None else None
     ddelta_bias = torch.empty_like(delta_bias_) if delta_bias_ is not None else None
     L = _lib.lib()
@@ -157,9 +166,12 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     p.A_ds, p.A_ns = A.stride(0), A.stride(1)
     p.B_bs, p.B_gs, p.B_ns = B.stride(0), B.stride(1), B.stride(2)
     p.C_bs, p.C_gs, p.C_ns = C.stride(0), C.stride(1), C.stride(2)
+    p.dB_bs, p.dB_gs, p.dB_ns = dB.stride(0), dB.stride(1), dB.stride(2)
+    p.dC_bs, p.dC_gs, p.dC_ns = dC.stride(0), dC.stride(1), dC.stride(2)
     with torch.cuda.device(u.device):
         _lib.check(L.mmu_selective_scan_bwd(p, _lib.stream_of(u)))
-    result = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
+    result = [du, ddelta, dA, dB if dB.dtype == B.dtype else dB.to(B.dtype),
+              dC if dC.dtype == C.dtype else dC.to(C.dtype), dD, ddelta_bias]
     if has_z:
         result.append(dz)
     if recompute_out_z:

@@ -15,9 +15,9 @@ Public surface = that of the reference's ``mamba_ssm/ops/selective_scan_interfac
 What each fused function computes (forward, reference lines :159-224 / :296-365):
     x, z      = xz.chunk(2, dim=1)
     conv_out  = silu(causal_conv1d(x))                       -> HIP kernel
-    x_dbl     = conv_out^T @ x_proj_weight^T                 (B*L, r+2N)  GEMM (hipBLASLt via ATen)
-    delta     = delta_proj_weight @ x_dbl[:, :r]^T           (D, B*L) viewed (B, D, L)
-    B, C      = x_dbl slices -> (B, 1, N, L)
+    x_dblT    = x_proj_weight @ conv_out                     (r+2N, B*L)  tokens-last, = reference x_dbl^T
+    delta     = delta_proj_weight @ x_dblT[:r]               (D, B*L) viewed (B, D, L)
+    B, C      = row blocks of x_dblT viewed (B, 1, N, L)     (strided views, no transpose copies)
     out_z     = selective_scan(conv_out, delta, A, B, C, D, z, delta_bias, softplus)  -> HIP kernels
     [out      = out_z^T @ out_proj_weight^T + out_proj_bias]
 Backward recomputes conv_out and delta (the reference's checkpoint_lvl=1, :218-219,238-241) and
@@ -29,6 +29,7 @@ import torch
 import torch.nn.functional as F
 
 from . import causal_conv1d_hip, selective_scan_hip
+from .tall_gemm import nt_splitk
 
 try:  # torch >= 2.4
     from torch.amp import custom_bwd as _custom_bwd, custom_fwd as _custom_fwd
@@ -117,27 +118,34 @@ def _dbl_view(t):
     return t.permute(1, 0, 2).reshape(d, b * l)
 
 
+def _rows_as_bnl(rows, batch, L):
+    """(N, B*L) rows of a tokens-last matrix -> (B, 1, N, L) view (strides (L, *, B*L, 1)); the scan
+    kernels take B/C with any batch/state stride, so no transpose copy is needed."""
+    n = rows.shape[0]
+    return rows.view(n, batch, L).permute(1, 0, 2).unsqueeze(1)
+
+
 def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias):
-    """x_dbl, delta, B, C from the conv output (selective_scan_interface.py:181-210)."""
+    """delta, B, C from the conv output (selective_scan_interface.py:181-210), computed tokens-last:
+    x_dblT = W_x @ conv (r+2N, B*L) -- the transpose of the reference's x_dbl -- so that delta, B and C
+    are row blocks of it and nothing has to be transposed."""
     batch, dim, L = conv1d_out.shape
     r = delta_proj_weight.shape[1]
-    x_dbl = F.linear(_dbl_view(conv1d_out).t(), x_proj_weight)  # (B*L, r + 2N)
-    delta = (delta_proj_weight @ x_dbl[:, :r].t()).view(dim, batch, L).permute(1, 0, 2)
+    x_dblT = x_proj_weight @ _dbl_view(conv1d_out)                       # (r + 2N, B*L)
+    delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
     if B is None:
-        Bv = x_dbl[:, r:r + d_state]
+        B = _rows_as_bnl(x_dblT[r:r + d_state], batch, L)
         if B_proj_bias is not None:
-            Bv = Bv + B_proj_bias.to(dtype=Bv.dtype)
-        B = Bv.reshape(batch, L, d_state).permute(0, 2, 1).unsqueeze(1).contiguous()
+            B = B + B_proj_bias.to(dtype=B.dtype).view(1, 1, -1, 1)
     else:
         B = _unit_l(B)
     if C is None:
-        Cv = x_dbl[:, -d_state:]
+        C = _rows_as_bnl(x_dblT[r + d_state:], batch, L)
         if C_proj_bias is not None:
-            Cv = Cv + C_proj_bias.to(dtype=Cv.dtype)
-        C = Cv.reshape(batch, L, d_state).permute(0, 2, 1).unsqueeze(1).contiguous()
+            C = C + C_proj_bias.to(dtype=C.dtype).view(1, 1, -1, 1)
     else:
         C = _unit_l(C)
-    return x_dbl, delta, B, C
+    return x_dblT, delta, B, C
 
 
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
@@ -163,8 +171,8 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.is_variable_C = C is None
     ctx.B_proj_bias_is_None = B_proj_bias is None
     ctx.C_proj_bias_is_None = C_proj_bias is None
-    x_dbl, delta, B, C = _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias,
-                                  C_proj_bias)
+    x_dblT, delta, B, C = _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias,
+                                   C_proj_bias)
     if D is not None:
         D = D.contiguous()
     # the un-gated `out` is not kept: this backward recomputes y from the states it rebuilds
@@ -176,16 +184,23 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.out_proj_bias_is_None = out_proj_bias is None
     if checkpoint_lvl >= 1:  # recomputed in the backward pass
         conv1d_out, delta = None, None
-    ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight,
-                          out_proj_weight if with_out_proj else None, conv1d_out, delta, A, B, C, D, delta_bias,
+    # B and C are views of x_dblT when they are input-dependent: save the matrix, rebuild the views
+    ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dblT, x_proj_weight, delta_proj_weight,
+                          out_proj_weight if with_out_proj else None, conv1d_out, delta, A,
+                          None if ctx.is_variable_B else B, None if ctx.is_variable_C else C, D, delta_bias,
                           scan_intermediates)
     if not with_out_proj:
         return out_z
-    return F.linear(out_z.permute(0, 2, 1), out_proj_weight, out_proj_bias)  # (B, L, d_model)
+    # (B, L, E) = out_z^T W_out^T, computed tokens-last then viewed
+    y = out_proj_weight @ _dbl_view(out_z)                                # (E, B*L)
+    if out_proj_bias is not None:
+        y = y + out_proj_bias.view(-1, 1)
+    batch, _, L = out_z.shape
+    return y.view(-1, batch, L).permute(1, 2, 0)
 
 
 def _inner_backward(ctx, dout):
-    (xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv1d_out, delta,
+    (xz, conv1d_weight, conv1d_bias, x_dblT, x_proj_weight, delta_proj_weight, out_proj_weight, conv1d_out, delta,
      A, B, C, D, delta_bias, scan_intermediates) = ctx.saved_tensors
     batch, _, L = xz.shape
     r = delta_proj_weight.shape[1]
@@ -194,46 +209,54 @@ def _inner_backward(ctx, dout):
     dim = x.shape[1]
     if ctx.checkpoint_lvl == 1:
         conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
-        delta = (delta_proj_weight @ x_dbl[:, :r].t()).view(dim, batch, L).permute(1, 0, 2)
+        delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
+    if ctx.is_variable_B:
+        B = _rows_as_bnl(x_dblT[r:r + d_state], batch, L)
+    if ctx.is_variable_C:
+        C = _rows_as_bnl(x_dblT[r + d_state:], batch, L)
     dxz = torch.empty_like(xz)
     dx, dz = dxz.chunk(2, dim=1)
     if ctx.with_out_proj:
-        # dout: (B, L, E) -> (E, B*L); dy = W_out^T dout as (B, D, L) laid out [D][B][L]   (:387-388)
-        dout_m = dout.reshape(batch * L, -1).t()
+        # dout: (B, L, E) -> (E, B*L); dy = W_out^T dout laid out [D][B][L]   (:387-388)
+        dout_m = dout.permute(2, 0, 1).reshape(dout.shape[-1], batch * L)
         dout_y = (out_proj_weight.t() @ dout_m).view(dim, batch, L).permute(1, 0, 2)
     else:
         dout_m = None
         dout_y = _unit_l(dout)
-    dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = selective_scan_hip.bwd(
-        conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz, ctx.delta_softplus,
-        ctx.with_out_proj)[:9] if ctx.with_out_proj else (
-        *selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz,
-                                ctx.delta_softplus, False), None)
+    # projection-gradient matrix; fp32 dB/dC are written straight into its rows by the scan kernel
+    dx_dblT = torch.empty_like(x_dblT)
+    direct = dx_dblT.dtype == torch.float32
+    dB_out = _rows_as_bnl(dx_dblT[r:r + d_state], batch, L) if (ctx.is_variable_B and direct) else None
+    dC_out = _rows_as_bnl(dx_dblT[r + d_state:], batch, L) if (ctx.is_variable_C and direct) else None
+    res = selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz,
+                                 ctx.delta_softplus, ctx.with_out_proj, dB_out=dB_out, dC_out=dC_out)
+    dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz = res[:8]
     dout_proj_weight = dout_proj_bias = None
     if ctx.with_out_proj:
-        dout_proj_weight = dout_m @ _dbl_view(out_z).t()  # (E, D)            (:394)
+        out_z = res[8]
+        dout_proj_weight = nt_splitk(dout_m, _dbl_view(out_z)).to(out_proj_weight.dtype)  # (E, D)   (:394)
         dout_proj_bias = dout.sum(dim=(0, 1)) if not ctx.out_proj_bias_is_None else None
-    dx_dbl = torch.empty_like(x_dbl)
     dB_proj_bias = dC_proj_bias = None
     if ctx.is_variable_B:
-        dBm = dB.squeeze(1).permute(0, 2, 1).reshape(batch * L, d_state)
-        dB_proj_bias = dBm.sum(0) if not ctx.B_proj_bias_is_None else None
-        dx_dbl[:, r:r + d_state] = dBm
+        if dB_out is None:
+            _rows_as_bnl(dx_dblT[r:r + d_state], batch, L).copy_(dB)
+        dB_proj_bias = dx_dblT[r:r + d_state].sum(1) if not ctx.B_proj_bias_is_None else None
         dB = None
     if ctx.is_variable_C:
-        dCm = dC.squeeze(1).permute(0, 2, 1).reshape(batch * L, d_state)
-        dC_proj_bias = dCm.sum(0) if not ctx.C_proj_bias_is_None else None
-        dx_dbl[:, -d_state:] = dCm
+        if dC_out is None:
+            _rows_as_bnl(dx_dblT[r + d_state:], batch, L).copy_(dC)
+        dC_proj_bias = dx_dblT[r + d_state:].sum(1) if not ctx.C_proj_bias_is_None else None
         dC = None
-    ddelta_m = _dbl_view(ddelta)                                   # (D, B*L)
-    ddelta_proj_weight = ddelta_m @ x_dbl[:, :r]                    # (D, r)           (:273)
-    dx_dbl[:, :r] = ddelta_m.t() @ delta_proj_weight                # (B*L, r)         (:274)
-    dconv_m = _dbl_view(dconv1d_out)                                # (D, B*L)
-    dx_proj_weight = dx_dbl.t() @ _dbl_view(conv1d_out).t()         # (r+2N, D)        (:276)
+    ddelta_m = _dbl_view(ddelta)                                            # (D, B*L)
+    ddelta_proj_weight = nt_splitk(ddelta_m, x_dblT[:r]).to(delta_proj_weight.dtype)  # (D, r)      (:273)
+    torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])         # (r, B*L)              (:274)
+    conv_m = _dbl_view(conv1d_out)
+    dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
+    dconv_m = _dbl_view(dconv1d_out)                                        # (D, B*L)
     if dconv_m.data_ptr() == dconv1d_out.data_ptr():
-        dconv_m.addmm_(x_proj_weight.t(), dx_dbl.t())               # in place         (:277)
+        dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
     else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
-        dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dbl.t())
+        dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dblT)
     dconv1d_out = dconv_m.view(dim, batch, L).permute(1, 0, 2)
     dx, dconv1d_weight, dconv1d_bias = causal_conv1d_hip.causal_conv1d_bwd(x, conv1d_weight, conv1d_bias,
                                                                            dconv1d_out, dx, True)

@@ -1,0 +1,37 @@
+"""Steady-state per-step kernel breakdown from a rocprofv3 kernel_trace.csv of bench.py:
+steps are delimited by the fused-AdamW kernel; the first `skip` steps (warm-up, MIOpen find) are dropped.
+usage: python tools/prof_steady.py <dir> [skip_steps=1] [top=45]"""
+import glob, re, sys
+import pandas as pd
+d = sys.argv[1]
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
+f = glob.glob(d + '/*/*kernel_trace.csv')[0]
+df = pd.read_csv(f).sort_values('Start_Timestamp').reset_index(drop=True)
+adam = df.index[df.Kernel_Name.str.contains('FusedAdam')].tolist()
+# the optimizer step launches several multi-tensor kernels back to back; a step ends at the last one of a burst
+ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
+print('optimizer bursts (step ends) at rows', ends, 'of', len(df))
+start = ends[skip - 1] + 1 if skip > 0 else 0
+stop = ends[-1] + 1
+n_steps = len(ends) - skip
+sub = df.iloc[start:stop].copy()
+sub['dur'] = sub.End_Timestamp - sub.Start_Timestamp
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'at::native::', '', n)
+    if n.startswith('Cijk'):
+        m = re.search(r'MT\d+x\d+x\d+', n)
+        return 'GEMM ' + n[:22] + ' ' + (m.group(0) if m else '')
+    return n[:110]
+sub['s'] = sub.Kernel_Name.map(short)
+wall = (sub.End_Timestamp.max() - sub.Start_Timestamp.min()) / 1e6 / n_steps
+g = sub.groupby('s').dur.agg(['sum', 'count']).sort_values('sum', ascending=False)
+print(f'steady steps: {n_steps}; GPU-busy ms/step {sub.dur.sum()/1e6/n_steps:.1f}; span ms/step {wall:.1f}; launches/step {len(sub)/n_steps:.0f}')
+for name, r in g.head(top).iterrows():
+    print(f"{r['sum']/1e6/n_steps:8.2f} ms/step  calls/step {r['count']/n_steps:6.0f}  avg {r['sum']/r['count']/1e3:9.1f} us  {name}")
+cat = lambda pat: sub[sub.s.str.contains(pat)].dur.sum() / 1e6 / n_steps
+print(f"GEMM {cat('^GEMM'):.1f} | conv(MIOpen/ck/igemm) {cat('igemm|miopen|Conv|conv|ck::|_ZN2ck'):.1f} | "
+      f"elementwise/copy/fill/transpose {cat('elementwise|copy|Fill|transpose|SubTensor'):.1f} | "
+      f"scan {cat('chunk_|reduce_partials|reduce_slices'):.1f} | conv1d {cat('conv1d_'):.1f} | morph {cat('morph_'):.1f} | "
+      f"norm {cat('BatchNorm|Rowwise|GroupNorm|ComputeInternal|batch_norm'):.1f}")
