@@ -122,10 +122,10 @@ def test_mmnet_fwd_bwd_vs_reference(mode):
             tol = max(1e-2, 4 * float(g[f"{mode}_sens.{name}"]))
             close(params[name].grad, ref, tol, tol * float(ref.abs().max()), k)
     # every live parameter: |grad| sum within the self-consistency band.  The per-parameter response
-    # stored in the fixture is a single sample, so a floor is added: 0.5 % in eval mode; 25 % in train
-    # mode, where the reference's own encoder gradients move by 16 % under 1e-6 input noise.
+    # stored in the fixture is a single sample, so a floor is added: 2 % in eval mode (the reference's own
+    # encoder gradients move by 2 % under 1e-6 input noise there); 25 % in train mode (16 %).
     names = [str(s) for s in g["gabs_names"]]
-    floor = 5e-3 if mode == "eval" else 0.25
+    floor = 2e-2 if mode == "eval" else 0.25
     bad = []
     for nme, a, s in zip(names, g[f"{mode}_gabs"], g[f"{mode}_gabs_sens"]):
         mine = float(params[nme].grad.double().abs().sum())
