@@ -471,15 +471,15 @@ __global__ __launch_bounds__(1024) void chunk_apply_fwd_kernel(ScanArgs p) {
 }
 
 // Backward work of one or two states for this lane's K tokens (see the math block at the top).
-// dB/dC contributions of this channel go to accB/accC: REG=true -> the caller's register
-// accumulators [NS][K] (summed over the wave's channel loop, flushed once per chunk);
-// REG=false -> LDS float atomics into tiles laid out [n][i][lane] (generic-dstate fallback: the
-// LDS atomic unit retires only ~1 lane per 3.5 cycles per CU, measured, so this path is slow).
+// dB/dC contributions of this channel go to accB/accC: REG=true -> the caller's register accumulators
+// [NS][K] (summed over the wave's channel loop, stored once per chunk); REG=false -> LDS float atomics
+// into tiles laid out [n][i][lane] (generic-dstate fallback; the LDS atomic unit retires only ~1 lane
+// per 3.5 cycles per CU, measured, so that path is slow).  dAtot[s] = wave-uniform sum of the dA terms.
 template <int K, int NS, bool REG>
 __device__ __forceinline__ void bwd_states(const float (&dl)[K], const float (&uv)[K], const float (&dy)[K],
                                            float (&y)[K], float (&duv)[K], float (&ddl)[K], const float *rb,
                                            const float *rc, float *accB, float *accC, int T, const float *a2,
-                                           const float *h0, const float *g0, float *dA_out, int lane) {
+                                           const float *h0, const float *g0, float (&dAtot)[NS], int lane) {
     float a[NS][K], bb[NS][K], hh[NS][K], cc[NS][K], P[NS], S[NS], Q[NS], R[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -546,8 +546,7 @@ __device__ __forceinline__ void bwd_states(const float (&dl)[K], const float (&u
                 atomicAdd(accC + s * T + i * 64, dy[i] * hh[s][i]);
             }
         }
-        dAp = wave_scan_add(dAp);
-        if (lane == 63) dA_out[s] = dAp;
+        dAtot[s] = wave_sum(dAp);
     }
 }
 
@@ -623,12 +622,21 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
         for (int i = 0; i < K; ++i) dDp = fmaf(dy[i], uv[i], dDp);
 
         int n = 0;
-        for (; n + 1 < N; n += 2)
+        for (; n + 1 < N; n += 2) {
+            float t2[2];
             bwd_states<K, 2, false>(dl, uv, dy, y, duv, ddl, sB + n * T + tl, sC + n * T + tl, sdB + n * T + lane,
-                             sdC + n * T + lane, T, sA + n, sH + n, sG + n, sdA + n, lane);
-        if (n < N)
+                                    sdC + n * T + lane, T, sA + n, sH + n, sG + n, t2, lane);
+            if (lane == 0) {
+                sdA[n] = t2[0];
+                sdA[n + 1] = t2[1];
+            }
+        }
+        if (n < N) {
+            float t1[1];
             bwd_states<K, 1, false>(dl, uv, dy, y, duv, ddl, sB + n * T + tl, sC + n * T + tl, sdB + n * T + lane,
-                             sdC + n * T + lane, T, sA + n, sH + n, sG + n, sdA + n, lane);
+                                    sdC + n * T + lane, T, sA + n, sH + n, sG + n, t1, lane);
+            if (lane == 0) sdA[n] = t1[0];
+        }
         // per-channel outputs
         float dbp = 0.f;
 #pragma unroll
@@ -676,66 +684,61 @@ __global__ __launch_bounds__(512) void chunk_apply_bwd_kernel(ScanArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// K4r: backward apply, register-accumulating form for dstate == NST (16 on the MM-UNet path).
-// grid (n_chunks, batch, ngroups), block W*64 with W in {1, 2, 4}: each wave walks dpg / W
-// channels and keeps its dB/dC sums for all NST states x K tokens in registers (the state loop
-// is fully unrolled so the accumulators have static indices).  They leave the wave once per
-// chunk: plain 16-B stores when W == 1, otherwise LDS atomics + one cooperative store.
-// LDS: B[N][T] | C[N][T] | (W > 1: dB[N][T] | dC[N][T]) | A2[W][N] | H0[W][N] | G0[W][N] | dAp[W][N]
+// K4s: backward apply for dstate == 16, state-split form.
+// grid (n_chunks, batch, ngroups), block 256 = 4 waves = the 4 state-quarters of one (b, chunk, g).
+// Every wave walks ALL channels of the group with its 4 states, so its dB/dC sums are 4*K*2 registers
+// (a wave holding all 16 states needs 64 accumulators next to ~18 live registers per unrolled state:
+// >256 VGPRs, scratch spills, 12 % VALU utilisation measured).  Per channel the four partial sums of
+// y / du / d(delta) meet through a double-buffered 3*K*64-float-per-wave LDS exchange (one barrier), and
+// the four output streams are split one per wave: du | ddelta (+dbias) | dz | out_z (+dD).  dB/dC leave
+// the registers with plain stores at the end -- no atomics anywhere, bit-reproducible.
+// LDS: B[16][T] | C[16][T] | xch[2][4][3K][64]
 // ---------------------------------------------------------------------------
-template <typename io_t, int K, int NST, bool FULL>
-__global__ __launch_bounds__(256, 2) void chunk_apply_bwd_reg_kernel(ScanArgs p) {
-    constexpr int T = 64 * K;
-    constexpr int N = NST;
+template <typename io_t, int K, bool FULL>
+__global__ __launch_bounds__(256, 3) void chunk_apply_bwd_ns4_kernel(ScanArgs p) {
+    constexpr int T = 64 * K, N = 16, NS = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = p.seqlen;
     const int c = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = w * NS;
     const int t0 = c * T;
     float *sB = smem;
     float *sC = sB + N * T;
-    float *sdB = sC + N * T;                       // only present when W > 1
-    float *scr = sC + N * T + (W > 1 ? 2 * N * T : 0);
-    float *sA = scr + w * N;
-    float *sH = scr + W * N + w * N;
-    float *sG = scr + 2 * W * N + w * N;
-    float *sdA = scr + 3 * W * N + w * N;
+    float *xch = sC + N * T;  // [parity][wave][3K][64]
 
     stage_tile<io_t, K, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
     stage_tile<io_t, K, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
-    if (W > 1)
-        for (int i = threadIdx.x; i < 2 * N * T; i += blockDim.x) sdB[i] = 0.f;
     __syncthreads();
 
     const int dpg = p.dim / p.ngroups;
     const int tl = lane * K;
     const int nvalid = L - (t0 + tl);
-    float accB[N * K], accC[N * K];
+    float accB[NS * K], accC[NS * K];
 #pragma unroll
-    for (int i = 0; i < N * K; ++i) accB[i] = accC[i] = 0.f;
+    for (int i = 0; i < NS * K; ++i) accB[i] = accC[i] = 0.f;
+    int par = 0;
 
-    for (int d = g * dpg + w; d < (g + 1) * dpg; d += W) {
-        // The B/C tile is invariant in this loop, so LICM would cache all 4*N*K/... of its values in
-        // registers on top of the 2*N*K accumulators (~350 VGPRs -> scratch spills).  Re-reading them
-        // from LDS every iteration is cheap; make the compiler do that.
-        asm volatile("" ::: "memory");
+    for (int d = g * dpg; d < (g + 1) * dpg; ++d) {
         const long bdc = ((long)b * p.dim + d) * p.n_chunks;
-        if (lane < N) {
-            sA[lane] = p.A[(long)d * p.A_ds + (long)lane * p.A_ns] * MMU_LOG2E;
-            sH[lane] = (c > 0) ? p.x[(bdc + c - 1) * 2 * N + 2 * lane + 1] : 0.f;
-            sG[lane] = (c + 1 < p.n_chunks) ? p.gx[(bdc + c + 1) * 2 * N + 2 * lane + 1] : 0.f;
+        // this wave's 4 states: A*log2e, forward carry-in, adjoint carry-in (lanes 0..3, then broadcast)
+        float vA = 0.f, vH = 0.f, vG = 0.f;
+        if (lane < NS) {
+            vA = p.A[(long)d * p.A_ds + (long)(n0 + lane) * p.A_ns] * MMU_LOG2E;
+            if (c > 0) vH = p.x[(bdc + c - 1) * 2 * N + 2 * (n0 + lane) + 1];
+            if (c + 1 < p.n_chunks) vG = p.gx[(bdc + c + 1) * 2 * N + 2 * (n0 + lane) + 1];
         }
         const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
         const float Dv = p.D ? p.D[d] : 0.f;
-        float dl[K], uv[K], dy[K], y[K], dsp[K], duv[K], ddl[K], go[K];
+        float dl[K], uv[K], dy[K], y[K], dsp[K], duv[K], ddl[K], go[K], zv[K], zsig[K];
         load_k<io_t, K, FULL>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
-                        p.vec_io, dl);
+                              p.vec_io, dl);
         load_k<io_t, K, FULL>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io, uv);
-        load_k<io_t, K, FULL>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid, p.vec_io,
-                        go);
-        float zv[K], zsig[K];
+        load_k<io_t, K, FULL>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid,
+                              p.vec_io, go);
         if (p.z) {
-            load_k<io_t, K, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io, zv);
+            load_k<io_t, K, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid, p.vec_io,
+                                  zv);
 #pragma unroll
             for (int i = 0; i < K; ++i) zsig[i] = sigmoidf_(zv[i]);
         }
@@ -745,91 +748,116 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_reg_kernel(ScanArgs p)
             float sp = v, dspv = 1.f;
             if (p.softplus) {
                 sp = softplus_thr(v);
-                dspv = v <= 20.f ? sigmoidf_(v) : 1.f;
+                dspv = v <= 20.f ? sigmoidf_(v) : 1.f;  // d softplus / dx  (bwd_kernel.cuh:439-453)
             }
             dl[i] = (FULL || i < nvalid) ? sp : 0.f;
             dsp[i] = dspv;
             dy[i] = p.z ? go[i] * zv[i] * zsig[i] : go[i];
-            y[i] = Dv * uv[i];
-            duv[i] = Dv * dy[i];
+            y[i] = 0.f;    // partial sums over this wave's states
+            duv[i] = 0.f;
             ddl[i] = 0.f;
         }
-        float dDp = 0.f;
+        float dAq[NS];
 #pragma unroll
-        for (int i = 0; i < K; ++i) dDp = fmaf(dy[i], uv[i], dDp);
+        for (int s2 = 0; s2 < NS; s2 += 2) {
+            float a2v[2], h0v[2], g0v[2], t2[2];
 #pragma unroll
-        for (int n = 0; n < N; n += 2) {
-            bwd_states<K, 2, true>(dl, uv, dy, y, duv, ddl, sB + n * T + tl, sC + n * T + tl, accB + n * K,
-                                   accC + n * K, T, sA + n, sH + n, sG + n, sdA + n, lane);
-            // keep the unrolled state pairs in program order: letting the scheduler hoist the next
-            // pairs' LDS reads across this point costs more registers than the file has
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 2; ++j) {
+                a2v[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vA), s2 + j));
+                h0v[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vH), s2 + j));
+                g0v[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vG), s2 + j));
+            }
+            bwd_states<K, 2, true>(dl, uv, dy, y, duv, ddl, sB + (n0 + s2) * T + tl, sC + (n0 + s2) * T + tl,
+                                   accB + s2 * K, accC + s2 * K, T, a2v, h0v, g0v, t2, lane);
+            dAq[s2] = t2[0];
+            dAq[s2 + 1] = t2[1];
         }
-        float dbp = 0.f;
+        // meet the other three state-quarters
+        float *mine = xch + ((par * 4 + w) * 3 * K) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            ddl[i] *= dsp[i];
-            if (FULL || i < nvalid) dbp += ddl[i];
+            mine[i * 64] = y[i];
+            mine[(K + i) * 64] = duv[i];
+            mine[(2 * K + i) * 64] = ddl[i];
         }
-        store_k<io_t, K, FULL>((io_t *)p.du + (long)b * p.du_bs + (long)d * p.du_ds + t0 + tl, nvalid, p.vec_io, duv);
-        store_k<io_t, K, FULL>((io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)d * p.ddelta_ds + t0 + tl, nvalid, p.vec_io,
-                         ddl);
-        if (p.z) {
-            float dzv[K];
+        __syncthreads();
+        float ty[K], tdu[K], tdd[K];
 #pragma unroll
-            for (int i = 0; i < K; ++i) dzv[i] = go[i] * y[i] * zsig[i] * (1.f + zv[i] * (1.f - zsig[i]));
-            store_k<io_t, K, FULL>((io_t *)p.dz + (long)b * p.dz_bs + (long)d * p.dz_ds + t0 + tl, nvalid, p.vec_io, dzv);
-            if (p.out_z) {
+        for (int i = 0; i < K; ++i) ty[i] = tdu[i] = tdd[i] = 0.f;
 #pragma unroll
-                for (int i = 0; i < K; ++i) dzv[i] = y[i] * zv[i] * zsig[i];
-                store_k<io_t, K, FULL>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
-                                 p.vec_io, dzv);
-            }
-        }
-        dDp = wave_sum(dDp);
-        dbp = wave_sum(dbp);
-        float *part = p.part + (((long)b * p.n_chunks + c) * p.dim + d) * (N + 2);
-        if (lane < N) part[lane] = sdA[lane];
-        if (lane == 0) {
-            part[N] = dDp;
-            part[N + 1] = dbp;
-        }
-    }
-    float *dBg = p.dB + (long)b * p.dB_bs + (long)g * p.dB_gs;
-    float *dCg = p.dC + (long)b * p.dC_bs + (long)g * p.dC_gs;
-    if (W == 1) {
-        const bool vecf = p.vec_dbc;
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            float vb[K], vc[K];
+        for (int q = 0; q < 4; ++q) {
+            const float *o = xch + ((par * 4 + q) * 3 * K) * 64 + lane;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                vb[i] = accB[n * K + i];
-                vc[i] = accC[n * K + i];
+                ty[i] += o[i * 64];
+                tdu[i] += o[(K + i) * 64];
+                tdd[i] += o[(2 * K + i) * 64];
             }
-            store_k<float, K, false>(dBg + (long)n * p.dB_ns + t0 + tl, nvalid, vecf, vb);
-            store_k<float, K, false>(dCg + (long)n * p.dC_ns + t0 + tl, nvalid, vecf, vc);
         }
-        return;
-    }
-    float *sdC = sdB + N * T;
+        par ^= 1;
+        float *part = p.part + (((long)b * p.n_chunks + c) * p.dim + d) * (N + 2);
+        {   // dA of this wave's 4 states
+            float v = dAq[0];
+            v = lane == 1 ? dAq[1] : v;
+            v = lane == 2 ? dAq[2] : v;
+            v = lane == 3 ? dAq[3] : v;
+            if (lane < NS) part[n0 + lane] = v;
+        }
+        if (w == 0) {
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
+            for (int i = 0; i < K; ++i) tdu[i] = fmaf(Dv, dy[i], tdu[i]);
+            store_k<io_t, K, FULL>((io_t *)p.du + (long)b * p.du_bs + (long)d * p.du_ds + t0 + tl, nvalid, p.vec_io,
+                                   tdu);
+        } else if (w == 1) {
+            float dbp = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                tdd[i] *= dsp[i];
+                if (FULL || i < nvalid) dbp += tdd[i];
+            }
+            store_k<io_t, K, FULL>((io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)d * p.ddelta_ds + t0 + tl, nvalid,
+                                   p.vec_io, tdd);
+            dbp = wave_sum(dbp);
+            if (lane == 0) part[N + 1] = dbp;
+        } else if (w == 2) {
+            if (p.z) {
+                float dzv[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float yt = fmaf(Dv, uv[i], ty[i]);
+                    dzv[i] = go[i] * yt * zsig[i] * (1.f + zv[i] * (1.f - zsig[i]));
+                }
+                store_k<io_t, K, FULL>((io_t *)p.dz + (long)b * p.dz_bs + (long)d * p.dz_ds + t0 + tl, nvalid,
+                                       p.vec_io, dzv);
+            }
+        } else {
+            float dDp = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) dDp = fmaf(dy[i], uv[i], dDp);
+            dDp = wave_sum(dDp);
+            if (lane == 0) part[N] = dDp;
+            if (p.z && p.out_z) {
+                float ozv[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) ozv[i] = fmaf(Dv, uv[i], ty[i]) * zv[i] * zsig[i];
+                store_k<io_t, K, FULL>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
+                                       p.vec_io, ozv);
+            }
+        }
+    }
+    // this wave's 4 rows of dB / dC
+    float *dBg = p.dB + (long)b * p.dB_bs + (long)g * p.dB_gs;
+    float *dCg = p.dC + (long)b * p.dC_bs + (long)g * p.dC_gs;
+#pragma unroll
+    for (int s1 = 0; s1 < NS; ++s1) {
+        float vb[K], vc[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            atomicAdd(sdB + n * T + i * 64 + lane, accB[n * K + i]);
-            atomicAdd(sdC + n * T + i * 64 + lane, accC[n * K + i]);
+            vb[i] = accB[s1 * K + i];
+            vc[i] = accC[s1 * K + i];
         }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < N * T; idx += blockDim.x) {
-        const int n = idx / T, j = idx % T;
-        const int t = t0 + j;
-        if (t < L) {
-            const int src = n * T + (j % K) * 64 + j / K;
-            dBg[(long)n * p.dB_ns + t] = sdB[src];
-            dCg[(long)n * p.dC_ns + t] = sdC[src];
-        }
+        store_k<float, K, false>(dBg + (long)(n0 + s1) * p.dB_ns + t0 + tl, nvalid, p.vec_dbc, vb);
+        store_k<float, K, false>(dCg + (long)(n0 + s1) * p.dC_ns + t0 + tl, nvalid, p.vec_dbc, vc);
     }
 }
 
@@ -1040,13 +1068,12 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st) {
         MMU_HIP_LAUNCH_CHECK("chunk_carry(reverse)");
     }
     if (K == 2 && N == 16) {
-        const int W = dpg >= 16 ? 4 : (dpg >= 8 ? 2 : 1);
-        size_t lds = sizeof(float) * ((size_t)(W > 1 ? 4 : 2) * N * T + (size_t)W * N * 4);
+        size_t lds = sizeof(float) * ((size_t)2 * N * T + (size_t)2 * 4 * 3 * 2 * 64);
         MMU_BOOL(full, FULL, {
-            if (int r = set_lds(chunk_apply_bwd_reg_kernel<io_t, 2, 16, FULL>, lds)) return r;
-            chunk_apply_bwd_reg_kernel<io_t, 2, 16, FULL><<<grid, W * 64, lds, st>>>(a);
+            if (int r = set_lds(chunk_apply_bwd_ns4_kernel<io_t, 2, FULL>, lds)) return r;
+            chunk_apply_bwd_ns4_kernel<io_t, 2, FULL><<<grid, 256, lds, st>>>(a);
         });
-        MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd_reg");
+        MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd_ns4");
     } else {
         const int W = dpg < 8 ? dpg : 8;
         size_t lds = sizeof(float) * ((size_t)4 * N * T + (size_t)W * N * 4);
