@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512, help="image side (BASELINE: 512)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="compute dtype; f32 = what the reference's train.py runs (no autocast)")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=512, help="image side of the cpu_baseline sample")
@@ -131,12 +132,13 @@ def main():
     if world > 1:
         broadcast_module_state(model)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
-    step = TrainStep(model, DICE_BCE_Loss(), make_optimizer(model), amp_dtype=amp)
+    graph = not args.no_graph
+    step = TrainStep(model, DICE_BCE_Loss(), make_optimizer(model, capturable=graph), amp_dtype=amp, use_graph=graph)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # rank r owns samples [8r, 8r+8)
     images = torch.randn(args.batch, 3, args.size, args.size, device=dev, generator=gen)
     targets = (torch.rand(args.batch, 1, args.size, args.size, device=dev, generator=gen) > 0.88).float()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + (3 if graph else 0)):   # graph mode: 2 eager warm-up steps + capture
         step(images, targets)
 
     def fence():
@@ -169,6 +171,7 @@ def main():
                                    f"3x{args.size}x{args.size}, bs={args.batch}/GPU, random-init seed 50",
                        "global_batch": args.batch * world, "image": [3, args.size, args.size],
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": step.reducer.payload_bytes(),
+                       "launch": "hip-graph replay" if graph else "eager",
                        "final_loss": round(float(loss), 5)},
         }
         if not args.no_roofline:

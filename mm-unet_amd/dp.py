@@ -10,12 +10,15 @@ for this model and this fabric:
     Stock DDP needs ``find_unused_parameters=True`` (a graph walk every step).  Here the live set is
     discovered ONCE (first backward), is identical on every rank by construction, and only those
     38 MB are ever exchanged.
-  * live gradients are accumulated by autograd directly into a few large flat buffers (``p.grad`` are
-    views), so the collective runs on the buffer with no pack/unpack copies;
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU) and the payload is small, so the exchange is
-    latency-bound: few, large buckets (default 16 MiB -> 3 collectives) rather than DDP's 25 MB x many
-    small tensors; each bucket's all-reduce is issued from a post-accumulate hook on a side stream as
-    soon as its last gradient is ready, overlapping the rest of the backward;
+    latency-bound: few, large buckets (default 16 MiB -> 3 collectives) rather than many small ones.
+    A bucket is packed with ONE multi-tensor copy (``torch._foreach_copy_``) and its all-reduce is
+    issued on a side stream from a post-accumulate hook as soon as its last gradient is ready,
+    overlapping the rest of the backward; after the wait the averaged values are copied back.
+  * autograd ASSIGNS gradients (``zero_grad(set_to_none=True)``): letting it accumulate into
+    pre-existing bucket views costs one ``add_`` launch per parameter per step (1,069 launches, 8 ms
+    of GPU time and as much host time on MI355X, measured).
+  * with a single rank nothing is copied or launched at all;
   * per-replica BatchNorm statistics and per-replica loss, like DDP (no SyncBN in the reference).
 """
 import torch
@@ -33,16 +36,18 @@ class GradAllReducer:
     """Averages the live gradients of ``module`` across the process group.
 
     Usage per step:  loss.backward();  reducer.finish();  optimizer.step();  reducer.zero_grad()
-    The first backward runs un-overlapped (it discovers the live set and builds the flat buckets).
+    The first backward runs un-overlapped (it discovers the live set and builds the buckets).
+    ``static_grads=True``: gradients are persistent tensors (HIP-graph replay) -- never set to None.
     """
 
-    def __init__(self, module, group=None, bucket_bytes=16 << 20, overlap=True):
+    def __init__(self, module, group=None, bucket_bytes=16 << 20, overlap=True, static_grads=False):
         self.module = module
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
-        self.overlap = overlap
-        self.buckets = None          # list of dict(flat=Tensor, params=[...], pending=int, handle)
+        self.overlap = overlap and not static_grads
+        self.static_grads = static_grads
+        self.buckets = None          # list of dict(flat, views, params, pending, handle)
         self._hooks = []
         self._side = None
         self.live_names = None
@@ -62,39 +67,34 @@ class GradAllReducer:
             if not torch.equal(lo, hi):
                 raise RuntimeError("GradAllReducer: ranks disagree on the set of parameters that receive gradients")
         # buckets in reverse registration order ~ the order backward produces gradients
-        self.buckets = []
-        cur, cur_bytes = [], 0
+        groups, cur, cur_bytes = [], [], 0
         for n, p in reversed(live):
             nb = p.numel() * p.element_size()
             if cur and (cur_bytes + nb > self.bucket_bytes or cur[0][1].dtype != p.dtype):
-                self.buckets.append(cur)
+                groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append((n, p))
             cur_bytes += nb
         if cur:
-            self.buckets.append(cur)
-        built = []
-        for members in self.buckets:
+            groups.append(cur)
+        self.buckets = []
+        for members in groups:
             p0 = members[0][1]
             total = sum(p.numel() for _, p in members)
-            flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
-            off = 0
+            flat = torch.zeros(total, dtype=p0.dtype, device=p0.device) if self.world > 1 else None
+            views, off = [], 0
             for _, p in members:
-                view = flat[off:off + p.numel()].view_as(p)
-                view.copy_(p.grad)
-                p.grad = view            # autograd now accumulates straight into the bucket
+                if flat is not None:
+                    views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            built.append(dict(flat=flat, params=[p for _, p in members], pending=len(members), handle=None))
-        self.buckets = built
+            self.buckets.append(dict(flat=flat, views=views, params=[p for _, p in members], nbytes=total * p0.element_size(),
+                                     pending=len(members), handle=None))
         if self.overlap and self.world > 1:
-            index = {}
             for bi, b in enumerate(self.buckets):
                 for p in b["params"]:
-                    index[p] = bi
-            for p, bi in index.items():
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
-            if self.buckets[0]["flat"].is_cuda:
-                self._side = torch.cuda.Stream(device=self.buckets[0]["flat"].device)
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+            if self.buckets[0]["params"][0].is_cuda:
+                self._side = torch.cuda.Stream(device=self.buckets[0]["params"][0].device)
 
     def _make_hook(self, bi):
         def hook(_param):
@@ -105,29 +105,30 @@ class GradAllReducer:
         return hook
 
     def _launch(self, b):
-        flat = b["flat"]
+        """Pack the bucket (one multi-tensor copy) and start its all-reduce."""
+        grads = [p.grad for p in b["params"]]
+
+        def go():
+            torch._foreach_copy_(b["views"], grads)
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
         if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream(flat.device))
+            self._side.wait_stream(torch.cuda.current_stream(b["flat"].device))
             with torch.cuda.stream(self._side):
-                b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                go()
         else:
-            b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            go()
 
     # -- per step -------------------------------------------------------------------------------------
     def finish(self):
-        """Call after ``backward``: completes the exchange; gradients are the mean over ranks."""
-        if self.buckets is None:
+        """Call after ``backward``: on return every live ``p.grad`` holds the mean over ranks."""
+        first = self.buckets is None
+        if first:
             self._build()
-            if self.world > 1:
-                for b in self.buckets:   # first step: nothing was launched from hooks
-                    dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
-                    b["flat"].mul_(1.0 / self.world)
-                    b["pending"] = len(b["params"])
-            return
         if self.world == 1:
             return
         for b in self.buckets:
-            if b["handle"] is None:      # no hook fired (overlap off, or a param got no grad this step)
+            if b["handle"] is None:      # first step / overlap off / hook did not fire
                 self._launch(b)
         for b in self.buckets:
             b["handle"].wait()
@@ -137,19 +138,14 @@ class GradAllReducer:
             torch.cuda.current_stream(self.buckets[0]["flat"].device).wait_stream(self._side)
         for b in self.buckets:
             b["flat"].mul_(1.0 / self.world)
+            torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
 
     def zero_grad(self):
-        """Zeroes the flat buckets in place (keeps ``p.grad`` views alive -- do NOT use
-        ``optimizer.zero_grad(set_to_none=True)`` with this class)."""
-        if self.buckets is None:
+        if not self.static_grads:
             self.module.zero_grad(set_to_none=True)
-            return
-        for b in self.buckets:
-            b["flat"].zero_()
 
     def payload_bytes(self):
-        return 0 if self.buckets is None else sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+        return 0 if self.buckets is None else sum(b["nbytes"] for b in self.buckets)
 
     def live_parameters(self):
-        """Parameters that receive gradients (for building the optimizer after the first step)."""
         return [p for b in (self.buckets or []) for p in b["params"]]

@@ -21,7 +21,7 @@ def nt_splitk(X, Y):
     Tm = S * _SLAB
     Xs = X[:, :Tm].reshape(I, S, _SLAB).transpose(0, 1)          # (S, I, slab) view
     Ys = Y[:, :Tm].reshape(J, S, _SLAB).permute(1, 2, 0)         # (S, slab, J) view
-    out = torch.bmm(Xs, Ys).sum(0)
+    out = torch.bmm(Xs, Ys).float().sum(0)   # slab sums added in fp32 also for bf16 operands
     if Tm < T:
         out = out + X[:, Tm:] @ Y[:, Tm:].t()
     return out
@@ -33,18 +33,25 @@ class _ProjTokensFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, W, Xm):
+        ctx.w_dtype, ctx.x_dtype = W.dtype, Xm.dtype
+        if torch.is_autocast_enabled():          # behave like F.linear under autocast
+            ac = torch.get_autocast_dtype("cuda")
+            W, Xm = W.to(ac), Xm.to(ac)
+        elif W.dtype != Xm.dtype:
+            W = W.to(Xm.dtype)
         ctx.save_for_backward(W, Xm)
         return W @ Xm
 
     @staticmethod
     def backward(ctx, G):
         W, Xm = ctx.saved_tensors
+        G = G.to(W.dtype)
         dW = dX = None
         if ctx.needs_input_grad[0]:
             dW = nt_splitk(G if G.stride(-1) == 1 else G.contiguous(),
-                           Xm if Xm.stride(-1) == 1 else Xm.contiguous()).to(W.dtype)
+                           Xm if Xm.stride(-1) == 1 else Xm.contiguous()).to(ctx.w_dtype)
         if ctx.needs_input_grad[1]:
-            dX = W.t() @ G
+            dX = (W.t() @ G).to(ctx.x_dtype)
         return dW, dX
 
 

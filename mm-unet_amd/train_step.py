@@ -5,13 +5,20 @@ the training batch, train.py:42-48,61) are not part of the step; the loss is ret
 
 ``make_optimizer`` mirrors the reference's ``create_optimizer_v2('adamw', lr 1e-3, weight_decay .05,
 betas (.9,.95))`` (train.py:197-201): decoupled weight decay, none on 1-D parameters / biases.
+
+``use_graph=True`` captures the step into a HIP graph (``torch.cuda.CUDAGraph``): a step is ~7,700
+kernel launches and the host needs as long to issue them (108 ms, measured) as the GPU needs to run
+them, so replaying a graph is what keeps the GPU fed once kernels get faster.  One rank: the whole step
+(forward, loss, backward, AdamW) is one graph.  Several ranks: forward+backward is the graph; the
+gradient exchange (RCCL) and the optimizer run after the replay.  Inputs are copied into static
+buffers; shapes are fixed at capture time.
 """
 import torch
 
 from .dp import GradAllReducer
 
 
-def make_optimizer(module, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.95), fused=None):
+def make_optimizer(module, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.95), fused=None, capturable=False):
     decay, no_decay = [], []
     for name, p in module.named_parameters():
         if not p.requires_grad:
@@ -20,14 +27,20 @@ def make_optimizer(module, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.95), fused=
     if fused is None:
         fused = all(p.is_cuda for p in decay + no_decay)
     return torch.optim.AdamW([{"params": decay, "weight_decay": weight_decay},
-                              {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=betas, fused=fused)
+                              {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=betas, fused=fused,
+                             capturable=capturable and fused)
 
 
 class TrainStep:
-    def __init__(self, model, loss_fn, optimizer, group=None, amp_dtype=None, bucket_bytes=16 << 20, overlap=True):
+    def __init__(self, model, loss_fn, optimizer, group=None, amp_dtype=None, bucket_bytes=16 << 20, overlap=True,
+                 use_graph=False):
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.amp_dtype = amp_dtype
-        self.reducer = GradAllReducer(model, group=group, bucket_bytes=bucket_bytes, overlap=overlap)
+        self.use_graph = use_graph
+        self.reducer = GradAllReducer(model, group=group, bucket_bytes=bucket_bytes, overlap=overlap,
+                                      static_grads=use_graph)
+        self._graph = None
+        self._warm = 0
 
     def forward_backward(self, images, targets):
         if self.amp_dtype is not None:
@@ -39,9 +52,44 @@ class TrainStep:
         loss.backward()
         return loss.detach()
 
-    def __call__(self, images, targets):
+    def _eager(self, images, targets):
         loss = self.forward_backward(images, targets)
         self.reducer.finish()
         self.optimizer.step()
         self.reducer.zero_grad()
         return loss
+
+    def _capture(self, images, targets):
+        dev = images.device
+        self._x = images.clone()
+        self._t = targets.clone()
+        whole = self.reducer.world == 1
+        self.model.zero_grad(set_to_none=True)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._loss = self.forward_backward(self._x, self._t)
+            if whole:
+                self.optimizer.step()
+        self._whole = whole
+        torch.cuda.synchronize(dev)
+
+    def __call__(self, images, targets):
+        if not self.use_graph:
+            return self._eager(images, targets)
+        if self._graph is None:
+            # eager warm-up first: MIOpen kernel selection, lazy optimizer state, live-gradient discovery
+            if self._warm < 2:
+                self._warm += 1
+                loss = self.forward_backward(images, targets)
+                self.reducer.finish()
+                self.optimizer.step()
+                self.model.zero_grad(set_to_none=True)
+                return loss
+            self._capture(images, targets)
+        self._x.copy_(images)
+        self._t.copy_(targets)
+        self._graph.replay()
+        if not self._whole:
+            self.reducer.finish()
+            self.optimizer.step()
+        return self._loss

@@ -211,3 +211,24 @@ def test_morph_sample_vs_grid_sample_composition(shape):
     close(out, ref, 1e-5, 1e-5, "out")
     close(xg.grad, xr.grad, 1e-4, 1e-4, "d input")
     close(yg.grad, yr.grad, 1e-4, 1e-4, "d y")
+
+
+def test_train_step_graph_replay_matches_eager():
+    """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    from mm_unet_amd.train_step import TrainStep, make_optimizer
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, 3, 64, 64, generator=gen).to(DEV) for _ in range(5)]
+    ts = [(torch.rand(2, 1, 64, 64, generator=gen) > 0.88).float().to(DEV) for _ in range(5)]
+    losses = {}
+    for mode in ("eager", "graph"):
+        m = _mmnet().train()          # Dropout2d p = 0 -> no RNG in the step
+        step = TrainStep(m, DICE_BCE_Loss(), make_optimizer(m, capturable=(mode == "graph")),
+                         use_graph=(mode == "graph"))
+        losses[mode] = [float(step(x, t)) for x, t in zip(xs, ts)]
+        assert (mode == "graph") == (step._graph is not None)
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) < 5e-2 * max(1.0, abs(a)), (losses["eager"], losses["graph"])
+    assert all(np.isfinite(v) for v in losses["graph"])
+    # first two steps are eager warm-up in both modes: identical up to float-atomic order in the sampler
+    assert abs(losses["eager"][0] - losses["graph"][0]) < 1e-3
