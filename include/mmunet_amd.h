@@ -183,6 +183,40 @@ typedef struct {
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
 int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
 
+/* ---- MMConv glue around its K-channel Mamba, fused ----------------- */
+/* Replaces ~30 tiny PyTorch kernels per MMConv block and direction (src/UM_Net/MMUNet.py:122-193 +
+ * requirements/mamba_simple.py:201-205,365): zig-zag token flatten + in_proj (A), and out_proj + inverse
+ * zig-zag + coordinate arithmetic y = max(softplus(altho), .01) * seq + row + scope * cumsum-from-centre (B).
+ * taps K in {1, 3}; d_inner = 2K; all tensors contiguous float32; L = height * width.
+ *   A fwd : offset [B, 2K, H, W], in_proj_weight [4K, K]            -> xz [4K][B][L]  (tokens-last)
+ *   A bwd : dxz [4K][B][L]                                          -> doffset [B, 2K, H, W], din_proj_weight
+ *   B fwd : offset, out_z [2K][B][L], out_proj_weight [K, 2K], altho -> y [B, K, H, W]  (row coordinates)
+ *   B bwd : dy [B, K, H, W]                        -> dout_z [2K][B][L], dout_proj_weight, daltho, doffset
+ * Weight / altho gradients are zeroed inside and accumulated with one float atomic per block and entry. */
+typedef struct {
+    int32_t batch, height, width, taps;
+    float extend_scope;
+    const float *offset;
+    const float *in_proj_weight;
+    const float *out_proj_weight;
+    const float *altho;
+    float *xz;
+    const float *dxz;
+    const float *out_z;
+    float *y;
+    const float *dy;
+    float *doffset;
+    float *din_proj_weight;
+    float *dout_z;
+    float *dout_proj_weight;
+    float *daltho;
+} mmu_coords_params;
+
+int mmu_zigzag_inproj_fwd(const mmu_coords_params *p, void *stream);
+int mmu_zigzag_inproj_bwd(const mmu_coords_params *p, void *stream);
+int mmu_coords_outproj_fwd(const mmu_coords_params *p, void *stream);
+int mmu_coords_outproj_bwd(const mmu_coords_params *p, void *stream);
+
 /* ---- test hooks (exercise the wave-level primitives on the GPU) -------- */
 /* Runs the in-wave affine-pair scan on n_waves*64 (P,S) pairs, one wave per 64.
  * reverse=0: forward inclusive; reverse=1: reverse inclusive.  variant 0 = DPP intrinsics,

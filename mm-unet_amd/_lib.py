@@ -68,11 +68,19 @@ class MorphParams(ctypes.Structure):
                 + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")])
 
 
+class CoordsParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
+                + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
+                                      "y", "dy", "doffset", "din_proj_weight", "dout_z", "dout_proj_weight",
+                                      "daltho")])
+
+
 # every symbol include/mmunet_amd.h declares (tests check that the library exports all of them)
 EXPORTS = (
     "mmu_abi_version", "mmu_last_error", "mmu_scan_chunk_len", "mmu_scan_bwd_workspace_bytes",
     "mmu_selective_scan_fwd", "mmu_selective_scan_bwd", "mmu_causal_conv1d_fwd", "mmu_causal_conv1d_bwd",
-    "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_debug_wave_scan",
+    "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
+    "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_debug_wave_scan",
 )
 
 _lib = None
@@ -100,7 +108,9 @@ def lib():
     for name, st in (("mmu_selective_scan_fwd", ScanFwdParams), ("mmu_selective_scan_bwd", ScanBwdParams),
                      ("mmu_causal_conv1d_fwd", Conv1dFwdParams), ("mmu_causal_conv1d_bwd", Conv1dBwdParams),
                      ("mmu_causal_conv1d_update", Conv1dUpdateParams),
-                     ("mmu_morph_sample_fwd", MorphParams), ("mmu_morph_sample_bwd", MorphParams)):
+                     ("mmu_morph_sample_fwd", MorphParams), ("mmu_morph_sample_bwd", MorphParams),
+                     ("mmu_zigzag_inproj_fwd", CoordsParams), ("mmu_zigzag_inproj_bwd", CoordsParams),
+                     ("mmu_coords_outproj_fwd", CoordsParams), ("mmu_coords_outproj_bwd", CoordsParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]

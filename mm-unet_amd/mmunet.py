@@ -20,7 +20,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba
+from . import morph_coords
 from .morph_sample import morph_sample
+from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
 
 class MMConv(nn.Module):
@@ -120,12 +122,28 @@ class MMConv(nn.Module):
         grid = torch.stack([xs, ys], dim=-1)  # (B, H*K, W, 2), last dim = (x, y)
         return F.grid_sample(input_feature, grid, mode=interpolate_mode, padding_mode="zeros", align_corners=True)
 
+    def _rows_fused(self, offset):
+        """get_coordinate_map_2D(rows_only=True) with the tensor glue in two HIP kernels
+        (morph_coords): zig-zag + in_proj -> [conv1d, x_proj, dt_proj, selective scan: the uni-directional
+        Mamba branch, mamba_simple.py:303-318] -> out_proj + inverse zig-zag + coordinate arithmetic."""
+        m = self.mamba
+        with torch.autocast("cuda", enabled=False):  # a 2K-channel fp32 scan; grid_sample is fp32 anyway
+            xz = morph_coords.zigzag_inproj(offset, m.in_proj.weight)
+            out_z = mamba_inner_fn_no_out_proj(xz, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
+                                               m.dt_proj.weight, -torch.exp(m.A_log.float()), None, None,
+                                               m.D.float(), delta_bias=m.dt_proj.bias.float(), delta_softplus=True)
+            return morph_coords.coords_outproj(offset, out_z, m.out_proj.weight, self.altho, self.extend_scope)
+
     def forward(self, input):
         offset = self.tanh(self.gn_offset(self.offset_conv(input)))
         # Fused HIP sampler (morph_sample): the tap columns are the integers w + k - K//2, so only the
         # row coordinates are passed on.  get_interpolated_feature (grid_sample) stays as the
         # reference-shaped method and is what the fused op is tested against.
-        y_rows = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope, rows_only=True)
+        if self.mamba.in_proj.bias is None and self.mamba.out_proj.bias is None and \
+                morph_coords.supported(offset, self.kernel_size):
+            y_rows = self._rows_fused(offset)
+        else:
+            y_rows = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope, rows_only=True)
         deformed = morph_sample(input, y_rows)
         output = self.dsc_conv_x(deformed) if self.morph == 0 else self.dsc_conv_y(deformed)
         return self.gn(output)

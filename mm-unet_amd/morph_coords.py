@@ -1,0 +1,111 @@
+"""Fused glue of MMConv around its K-channel Mamba (HIP kernels in csrc/morph_coords.hip).
+
+``zigzag_inproj(offset, in_proj_weight)``  -> xz as a (B, 4K, L) view of a tokens-last [4K][B][L] buffer:
+    the two-row zig-zag flatten of ``offset[:, :K]`` (MMUNet.py:68-93,178-180) followed by ``Mamba.in_proj``
+    (mamba_simple.py:201-205).
+``coords_outproj(offset, out_z, out_proj_weight, altho, extend_scope)`` -> y (B, K, H, W):
+    ``Mamba.out_proj`` (mamba_simple.py:365), the inverse zig-zag (MMUNet.py:95-121,182-183) and
+    ``y = clamp(softplus(altho), min=.01) * y_keep + row + extend_scope * cumsum-from-centre(offset)``
+    (MMUNet.py:138-188).
+
+float32, K in {1, 3}; anything else takes MMConv's un-fused path.
+"""
+import torch
+
+from . import _lib
+
+
+def supported(offset, K):
+    return offset.is_cuda and offset.dtype == torch.float32 and K in (1, 3)
+
+
+def _params(offset, K, scope=1.0):
+    B, _, H, W = offset.shape
+    p = _lib.CoordsParams()
+    p.batch, p.height, p.width, p.taps = B, H, W, K
+    p.extend_scope = float(scope)
+    p.offset = offset.data_ptr()
+    return p
+
+
+def _dbl(t, rows, B, L):
+    """(B, rows, L) tensor -> its [rows][B][L] tokens-last buffer (copy only if it is not laid out so)."""
+    v = t.permute(1, 0, 2)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+class ZigzagInProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, offset, w_in):
+        offset = offset.contiguous()
+        w = w_in.float().contiguous()
+        B, C2, H, W = offset.shape
+        K = C2 // 2
+        buf = torch.empty((4 * K, B, H * W), device=offset.device, dtype=torch.float32)
+        p = _params(offset, K)
+        p.in_proj_weight, p.xz = w.data_ptr(), buf.data_ptr()
+        with torch.cuda.device(offset.device):
+            _lib.check(_lib.lib().mmu_zigzag_inproj_fwd(p, _lib.stream_of(offset)))
+        ctx.save_for_backward(offset, w)
+        ctx.w_dtype = w_in.dtype
+        return buf.permute(1, 0, 2)
+
+    @staticmethod
+    def backward(ctx, dxz):
+        offset, w = ctx.saved_tensors
+        B, C2, H, W = offset.shape
+        K = C2 // 2
+        g = _dbl(dxz.float(), 4 * K, B, H * W)
+        doff = torch.empty_like(offset)
+        dw = torch.empty_like(w)
+        p = _params(offset, K)
+        p.in_proj_weight, p.dxz, p.doffset, p.din_proj_weight = w.data_ptr(), g.data_ptr(), doff.data_ptr(), \
+            dw.data_ptr()
+        with torch.cuda.device(offset.device):
+            _lib.check(_lib.lib().mmu_zigzag_inproj_bwd(p, _lib.stream_of(offset)))
+        return doff, dw.to(ctx.w_dtype)
+
+
+class CoordsOutProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, offset, out_z, w_out, altho, scope):
+        offset = offset.contiguous()
+        w = w_out.float().contiguous()
+        al = altho.float().reshape(1).contiguous()
+        B, C2, H, W = offset.shape
+        K = C2 // 2
+        oz = _dbl(out_z.float(), 2 * K, B, H * W)
+        y = torch.empty((B, K, H, W), device=offset.device, dtype=torch.float32)
+        p = _params(offset, K, scope)
+        p.out_proj_weight, p.altho, p.out_z, p.y = w.data_ptr(), al.data_ptr(), oz.data_ptr(), y.data_ptr()
+        with torch.cuda.device(offset.device):
+            _lib.check(_lib.lib().mmu_coords_outproj_fwd(p, _lib.stream_of(offset)))
+        ctx.save_for_backward(offset, oz, w, al)
+        ctx.scope, ctx.w_dtype, ctx.a_shape, ctx.a_dtype = scope, w_out.dtype, altho.shape, altho.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        offset, oz, w, al = ctx.saved_tensors
+        B, C2, H, W = offset.shape
+        K = C2 // 2
+        g = dy.float().contiguous()
+        doff = torch.empty_like(offset)
+        doz = torch.empty_like(oz)
+        dw = torch.empty_like(w)
+        da = torch.empty_like(al)
+        p = _params(offset, K, ctx.scope)
+        p.out_proj_weight, p.altho, p.out_z, p.dy = w.data_ptr(), al.data_ptr(), oz.data_ptr(), g.data_ptr()
+        p.doffset, p.dout_z, p.dout_proj_weight, p.daltho = doff.data_ptr(), doz.data_ptr(), dw.data_ptr(), \
+            da.data_ptr()
+        with torch.cuda.device(offset.device):
+            _lib.check(_lib.lib().mmu_coords_outproj_bwd(p, _lib.stream_of(offset)))
+        return doff, doz.permute(1, 0, 2), dw.to(ctx.w_dtype), da.reshape(ctx.a_shape).to(ctx.a_dtype), None
+
+
+def zigzag_inproj(offset, in_proj_weight):
+    return ZigzagInProjFn.apply(offset, in_proj_weight)
+
+
+def coords_outproj(offset, out_z, out_proj_weight, altho, extend_scope=1.0):
+    return CoordsOutProjFn.apply(offset, out_z, out_proj_weight, altho, extend_scope)
