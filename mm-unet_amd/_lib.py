@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmunet_hip.so")
+# MMUNET_HIP_LIB selects another build of the same library (kernel experiments, tools/ablate_scan.py)
+LIB_PATH = os.environ.get("MMUNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libmmunet_hip.so")
 
 MMU_DTYPE_F32 = 0
 MMU_DTYPE_BF16 = 1

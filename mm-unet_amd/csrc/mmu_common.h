@@ -83,6 +83,55 @@ __device__ __forceinline__ void store_k(T *__restrict__ p, int nvalid, bool vec,
     }
 }
 
+// ---- buffer-resource I/O -------------------------------------------------------------------------
+// A stream of rows read by a wave: 128-bit resource descriptor in SGPRs (base = start of the tile in the
+// batch item), row offset in an SGPR (soffset), the lane's byte offset in ONE VGPR shared by every stream.
+// Plain pointers made the compiler keep a per-lane 64-bit address per stream (14 VGPRs, spilled, and every
+// scratch reload is a vmcnt wait in the middle of the prefetch).  Offsets are 32-bit: the host checks that
+// a batch item spans < 2 GiB before taking a kernel that uses these.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <typename T>
+__device__ __forceinline__ void buf_load8(rsrc_t r, unsigned voff, unsigned soff, float (&o)[8]);
+template <>
+__device__ __forceinline__ void buf_load8<float>(rsrc_t r, unsigned voff, unsigned soff, float (&o)[8]) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const v4u b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16, soff, 0);
+    o[0] = __uint_as_float(a.x); o[1] = __uint_as_float(a.y); o[2] = __uint_as_float(a.z); o[3] = __uint_as_float(a.w);
+    o[4] = __uint_as_float(b.x); o[5] = __uint_as_float(b.y); o[6] = __uint_as_float(b.z); o[7] = __uint_as_float(b.w);
+}
+template <>
+__device__ __forceinline__ void buf_load8<bf16_t>(rsrc_t r, unsigned voff, unsigned soff, float (&o)[8]) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = __uint_as_float(w[i] << 16);
+        o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void buf_store8(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void buf_store8<float>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[8]) {
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, r, voff + 16, soff, 0);
+}
+template <>
+__device__ __forceinline__ void buf_store8<bf16_t>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (unsigned)from_f32<bf16_t>(v[2 * i]).bits | ((unsigned)from_f32<bf16_t>(v[2 * i + 1]).bits << 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{w[0], w[1], w[2], w[3]}, r, voff, soff, 0);
+}
+
 // ---------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------
@@ -95,7 +144,9 @@ __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_log
 // round to 1).
 __device__ __forceinline__ float softplus_thr(float x) {
     const float e = fast_exp(fminf(x, 20.f));
-    const float sp = e < 1e-4f ? e * (1.f - 0.5f * e) : fast_log(1.f + e);
+    float lg = fast_log(1.f + e);
+    asm("" : "+v"(lg));  // keep both sides branch-free: an exec-mask branch per token costs more than the log
+    const float sp = e < 1e-4f ? e * fmaf(-0.5f, e, 1.f) : lg;
     return x <= 20.f ? sp : x;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + fast_exp(-x)); }

