@@ -132,6 +132,40 @@ __device__ __forceinline__ void buf_store8<bf16_t>(rsrc_t r, unsigned voff, unsi
     __builtin_amdgcn_raw_buffer_store_b128(v4u{w[0], w[1], w[2], w[3]}, r, voff, soff, 0);
 }
 
+// 4-token forms (one 16-B / 8-B access per lane)
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void buf_load4(rsrc_t r, unsigned voff, unsigned soff, float (&o)[4]);
+template <>
+__device__ __forceinline__ void buf_load4<float>(rsrc_t r, unsigned voff, unsigned soff, float (&o)[4]) {
+    const v4u a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    o[0] = __uint_as_float(a.x); o[1] = __uint_as_float(a.y); o[2] = __uint_as_float(a.z); o[3] = __uint_as_float(a.w);
+}
+template <>
+__device__ __forceinline__ void buf_load4<bf16_t>(rsrc_t r, unsigned voff, unsigned soff, float (&o)[4]) {
+    const v2u a = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+    o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void buf_store4(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void buf_store4<float>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[4]) {
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, voff, soff, 0);
+}
+template <>
+__device__ __forceinline__ void buf_store4<bf16_t>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[4]) {
+    const unsigned w0 = (unsigned)from_f32<bf16_t>(v[0]).bits | ((unsigned)from_f32<bf16_t>(v[1]).bits << 16);
+    const unsigned w1 = (unsigned)from_f32<bf16_t>(v[2]).bits | ((unsigned)from_f32<bf16_t>(v[3]).bits << 16);
+    __builtin_amdgcn_raw_buffer_store_b64(v2u{w0, w1}, r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store1(rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for
+// the next channel's prefetch and the previous channel's stores at every exchange.
+#define MMU_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // ---------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------

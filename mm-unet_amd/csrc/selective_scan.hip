@@ -1097,6 +1097,323 @@ __global__ __launch_bounds__(256, 3) void chunk_apply_bwd_ns4_kernel(ScanArgs p)
 }
 
 // ---------------------------------------------------------------------------
+// K4p: backward apply for dstate == 16 on full, aligned 256-token tiles -- the state-split design of K4s
+// (4 waves = the 4 state-quarters, register dB/dC sums, LDS exchange of the per-token partial sums, one
+// output stream per wave, no atomics) re-cut with what the forward kernels taught:
+//   * 4 tokens per lane (both cross-lane scans amortised over twice the tokens), state PAIRS on packed math;
+//   * buffer-resource addressing and a branch-free channel pipeline (everything a channel needs is one
+//     group of loads issued a channel ahead; no per-stream pointers, no vmcnt(0) in the loop);
+//   * the exchange barrier orders LDS only (MMU_LDS_BARRIER): __syncthreads() would drain the prefetch;
+//   * each wave stages only the B / C rows of ITS four states (private LDS region, no barrier).
+// grid (L / 256, batch, ngroups), block 256.  A tile is two 128-token chunks: carries come from x[2t-1]
+// and gx[2t+2]; the dA/dD/dbias partial row of the second chunk is written as zeros.
+// LDS: BC[4 waves][B|C][2 pairs][2][64] float4 | slots[4][2][16] | xch[4][3][64] float4   (44.5 KiB)
+// ---------------------------------------------------------------------------
+template <typename io_t, bool HAS_Z>
+__global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) {
+    constexpr int N = 16, TT = 256;
+    constexpr unsigned ES = sizeof(io_t);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n0 = w * 4;
+    const int t0 = tile * TT;
+    const int c0 = tile * 2;
+    float4 *sBC = reinterpret_cast<float4 *>(smem) + w * 512;
+    float *slots = smem + 4 * 512 * 4 + w * 32;
+    float4 *xch = reinterpret_cast<float4 *>(smem + 4 * 512 * 4 + 4 * 32);
+
+    {   // this wave's four B rows and four C rows, pair-interleaved: float4 q of lane l =
+        // (row 2p [4l+2q], row 2p+1 [4l+2q], row 2p [4l+2q+1], row 2p+1 [4l+2q+1])
+        const io_t *Bg = (const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs + t0 + lane * 4;
+        const io_t *Cg = (const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs + t0 + lane * 4;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int n = n0 + 2 * pi;
+            float r0[4], r1[4];
+            load_k<io_t, 4, true>(Bg + (long)n * p.B_ns, 4, true, r0);
+            load_k<io_t, 4, true>(Bg + (long)(n + 1) * p.B_ns, 4, true, r1);
+            sBC[(pi * 2 + 0) * 64 + lane] = make_float4(r0[0], r1[0], r0[1], r1[1]);
+            sBC[(pi * 2 + 1) * 64 + lane] = make_float4(r0[2], r1[2], r0[3], r1[3]);
+            load_k<io_t, 4, true>(Cg + (long)n * p.C_ns, 4, true, r0);
+            load_k<io_t, 4, true>(Cg + (long)(n + 1) * p.C_ns, 4, true, r1);
+            sBC[256 + (pi * 2 + 0) * 64 + lane] = make_float4(r0[0], r1[0], r0[1], r1[1]);
+            sBC[256 + (pi * 2 + 1) * 64 + lane] = make_float4(r0[2], r1[2], r0[3], r1[3]);
+        }
+    }
+
+    const int dpg = p.dim / p.ngroups;
+    const int dbeg = g * dpg, dend = dbeg + dpg;
+    const rsrc_t r_delta = make_rsrc((const io_t *)p.delta + (long)b * p.delta_bs + t0);
+    const rsrc_t r_u = make_rsrc((const io_t *)p.u + (long)b * p.u_bs + t0);
+    const rsrc_t r_go = make_rsrc((const io_t *)p.dout + (long)b * p.dout_bs + t0);
+    const rsrc_t r_z = make_rsrc(HAS_Z ? (const io_t *)p.z + (long)b * p.z_bs + t0 : (const io_t *)p.u);
+    const rsrc_t r_part = make_rsrc(p.part + ((long)b * p.n_chunks + c0) * p.dim * (N + 2));
+    // the one output stream this wave owns: du | ddelta | dz | out_z
+    const rsrc_t r_o = make_rsrc(w == 0   ? (io_t *)p.du + (long)b * p.du_bs + t0
+                                 : w == 1 ? (io_t *)p.ddelta + (long)b * p.ddelta_bs + t0
+                                 : w == 2 ? (HAS_Z ? (io_t *)p.dz + (long)b * p.dz_bs + t0 : (io_t *)p.du)
+                                          : (p.out_z ? (io_t *)p.out_z + (long)b * p.out_z_bs + t0 : (io_t *)p.du));
+    const unsigned o_ds = w == 0 ? p.du_ds : w == 1 ? p.ddelta_ds : w == 2 ? p.dz_ds : p.out_z_ds;
+    const bool hasH = c0 > 0, hasG = c0 + 2 < p.n_chunks;
+    const unsigned voff = lane * 4 * ES;
+    // The 14 scalars a channel needs (A, forward and adjoint carry-in of this wave's 4 states, bias, D) come
+    // from ONE gathered load: lane j < 14 owns one of them as a 64-bit base + a per-channel stride (five more
+    // buffer descriptors would not fit the SGPR file next to the six streams; spilled SGPRs are v_readlanes
+    // in the loop).  Lanes 14..63 re-read lane 0's word.
+    const int st = n0 + (lane & 3);
+    const float *gbase = p.A + (long)st * p.A_ns;
+    unsigned gstride = (unsigned)p.A_ds;
+    float gscale = MMU_LOG2E;
+    if (lane >= 4 && lane < 8) {
+        gbase = p.x + ((long)b * p.dim * p.n_chunks + (hasH ? c0 - 1 : 0)) * 2 * N + 2 * st + 1;
+        gstride = (unsigned)p.n_chunks * 2 * N;
+        gscale = hasH ? 1.f : 0.f;
+    } else if (lane >= 8 && lane < 12) {
+        gbase = p.gx + ((long)b * p.dim * p.n_chunks + (hasG ? c0 + 2 : 0)) * 2 * N + 2 * st + 1;
+        gstride = (unsigned)p.n_chunks * 2 * N;
+        gscale = hasG ? 1.f : 0.f;
+    } else if (lane == 12) {
+        gbase = p.delta_bias ? p.delta_bias : p.A;
+        gstride = p.delta_bias ? 1u : 0u;
+        gscale = p.delta_bias ? 1.f : 0.f;
+    } else if (lane == 13) {
+        gbase = p.D ? p.D : p.A;
+        gstride = p.D ? 1u : 0u;
+        gscale = p.D ? 1.f : 0.f;
+    }
+
+    float dl_n[4], u_n[4], go_n[4], z_n[4], gv;
+    auto fetch = [&](int dc) {
+        dc = __builtin_amdgcn_readfirstlane(dc);
+        buf_load4<io_t>(r_delta, voff, dc * (unsigned)p.delta_ds * ES, dl_n);
+        buf_load4<io_t>(r_u, voff, dc * (unsigned)p.u_ds * ES, u_n);
+        buf_load4<io_t>(r_go, voff, dc * (unsigned)p.dout_ds * ES, go_n);
+        if constexpr (HAS_Z) buf_load4<io_t>(r_z, voff, dc * (unsigned)p.z_ds * ES, z_n);
+        gv = gbase[(unsigned long)dc * gstride];
+    };
+    // slots[par][16]: 0..3 A*log2e | 4..7 h0 | 8..11 g0 | 12 bias | 13 D
+    auto put_slots = [&](int par) {
+        if (lane < 14) slots[par * 16 + lane] = gv * gscale;
+    };
+    fetch(dbeg);
+    asm volatile("" : "+v"(gv));  // consume the whole group before the loop (see chunk_apply_fwd8)
+    put_slots(0);
+
+    v2f accB[2][4], accC[2][4];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accB[pi][i] = accC[pi][i] = v2f{0.f, 0.f};
+
+    int par = 0;
+    for (int d = dbeg; d < dend; ++d, par ^= 1) {
+        const float *sl = slots + par * 16;
+        const float bias = sl[12], Dv = sl[13];
+        float vraw[4], dl[4], uv[4], go[4], zv[4], dy[4], zsig[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vraw[i] = dl_n[i] + bias;
+            uv[i] = u_n[i];
+            go[i] = go_n[i];
+            zv[i] = HAS_Z ? z_n[i] : 0.f;
+        }
+        fetch(d + 1 < dend ? d + 1 : d);  // next channel (the last iteration re-reads its own rows: L2 hits)
+        const unsigned dcur = __builtin_amdgcn_readfirstlane(d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dl[i] = vraw[i];
+        if (p.softplus) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dl[i] = softplus_thr(vraw[i]);
+        }
+        float dlsum = 0.f;
+        v2f dl2[2], u2[2], dlu2[2], dy2[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (HAS_Z) {
+                zsig[i] = sigmoidf_(zv[i]);
+                dy[i] = go[i] * zv[i] * zsig[i];
+            } else {
+                zsig[i] = 0.f;
+                dy[i] = go[i];
+            }
+            dlsum += dl[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            dl2[k] = v2f{dl[2 * k], dl[2 * k + 1]};
+            u2[k] = v2f{uv[2 * k], uv[2 * k + 1]};
+            dlu2[k] = dl2[k] * u2[k];
+            dy2[k] = v2f{dy[2 * k], dy[2 * k + 1]};
+        }
+        v2f y2[4], du2[4], dd2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y2[i] = du2[i] = dd2[i] = v2f{0.f, 0.f};
+        float dAq[4];
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const v2f a2 = *reinterpret_cast<const v2f *>(sl + 2 * pi);
+            const v2f h0 = *reinterpret_cast<const v2f *>(sl + 4 + 2 * pi);
+            const v2f g0 = *reinterpret_cast<const v2f *>(sl + 8 + 2 * pi);
+            v2f a[4], bb[4], hh[4];  // bb becomes a_t * h_{t-1} in the forward pass
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                a[2 * k] = exp2_2(mul_bcast<0>(dl2[k], a2));
+                a[2 * k + 1] = exp2_2(mul_bcast<1>(dl2[k], a2));
+            }
+            const v2f P = exp2_2(a2 * dlsum);
+            v2f S, R;
+            {   // local composition of this lane's 4 tokens, forward (S) and adjoint (R, right-to-left:
+                // gamma_out = a_i (c_i + gamma_in)); the B / C values are re-read in the gamma loop below
+                // instead of being kept (16 registers through both scans)
+                const float4 f0 = sBC[(pi * 2 + 0) * 64 + lane], f1 = sBC[(pi * 2 + 1) * 64 + lane];
+                const float4 c0_ = sBC[256 + (pi * 2 + 0) * 64 + lane], c1_ = sBC[256 + (pi * 2 + 1) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                bb[0] = mul_bcast<0>(dlu2[0], v2f{f0.x, f0.y});
+                bb[1] = mul_bcast<1>(dlu2[0], v2f{f0.z, f0.w});
+                bb[2] = mul_bcast<0>(dlu2[1], v2f{f1.x, f1.y});
+                bb[3] = mul_bcast<1>(dlu2[1], v2f{f1.z, f1.w});
+                S = bb[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) S = fma2(a[i], S, bb[i]);
+                R = a[3] * mul_bcast<1>(dy2[1], v2f{c1_.z, c1_.w});
+                R = a[2] * (mul_bcast<0>(dy2[1], v2f{c1_.x, c1_.y}) + R);
+                R = a[1] * (mul_bcast<1>(dy2[0], v2f{c0_.z, c0_.w}) + R);
+                R = a[0] * (mul_bcast<0>(dy2[0], v2f{c0_.x, c0_.y}) + R);
+            }
+            const v2f S_in = fma2(P, h0, S), R_in = fma2(P, g0, R);
+            S = lane == 0 ? S_in : S;
+            R = lane == 63 ? R_in : R;
+            float P0 = P.x, S0 = S.x, P1 = P.y, S1 = S.y;
+            float Q0 = wave_reverse(P.x), R0 = wave_reverse(R.x), Q1 = wave_reverse(P.y), R1 = wave_reverse(R.y);
+            wave_scan_affine_x2(P0, S0, P1, S1);
+            wave_scan_affine_x2(Q0, R0, Q1, R1);
+            v2f h = v2f{wave_shift_up1(S0, h0.x), wave_shift_up1(S1, h0.y)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v2f ah = a[i] * h;  // a_t * h_{t-1}
+                h = ah + bb[i];
+                bb[i] = ah;
+                hh[i] = h;
+            }
+            // gamma entering this lane from the right = reversed-order inclusive R of lane + 1
+            v2f gam;
+            gam.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((62 - lane) << 2, __builtin_bit_cast(int, R0)));
+            gam.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((62 - lane) << 2, __builtin_bit_cast(int, R1)));
+            gam = lane == 63 ? g0 : gam;
+            const v2f An = a2 * MMU_LN2;
+            v2f dAp = v2f{0.f, 0.f};
+#pragma unroll
+            for (int k = 1; k >= 0; --k) {
+                const float4 fb = sBC[(pi * 2 + k) * 64 + lane], fc = sBC[256 + (pi * 2 + k) * 64 + lane];
+#pragma unroll
+                for (int hsel = 1; hsel >= 0; --hsel) {
+                    const int i = 2 * k + hsel;
+                    const v2f Bt = hsel ? v2f{fb.z, fb.w} : v2f{fb.x, fb.y};
+                    const v2f Ct = hsel ? v2f{fc.z, fc.w} : v2f{fc.x, fc.y};
+                    const v2f gt = (hsel ? mul_bcast<1>(dy2[k], Ct) : mul_bcast<0>(dy2[k], Ct)) + gam;
+                    gam = a[i] * gt;
+                    const v2f ahp = bb[i];
+                    const v2f gdl = hsel ? mul_bcast<1>(dl2[k], gt) : mul_bcast<0>(dl2[k], gt);
+                    const v2f uB = hsel ? mul_bcast<1>(u2[k], Bt) : mul_bcast<0>(u2[k], Bt);
+                    du2[i] = fma2(gdl, Bt, du2[i]);
+                    dd2[i] = fma2(gt, fma2(An, ahp, uB), dd2[i]);
+                    dAp = fma2(gdl, ahp, dAp);
+                    y2[i] = fma2(Ct, hh[i], y2[i]);
+                    accB[pi][i] += hsel ? mul_bcast<1>(u2[k], gdl) : mul_bcast<0>(u2[k], gdl);
+                    accC[pi][i] += hsel ? mul_bcast<1>(dy2[k], hh[i]) : mul_bcast<0>(dy2[k], hh[i]);
+                }
+            }
+            dAq[2 * pi] = wave_sum(dAp.x);
+            dAq[2 * pi + 1] = wave_sum(dAp.y);
+            __builtin_amdgcn_sched_barrier(0);  // one pair at a time: interleaving two doubles the live registers
+        }
+        put_slots(par ^ 1);  // (the prefetch group has landed long ago)
+
+        // meet the other three state-quarters: single exchange buffer, so wait until everybody has read
+        // the previous channel's before overwriting it
+        MMU_LDS_BARRIER();
+        xch[(w * 3 + 0) * 64 + lane] = make_float4(y2[0].x + y2[0].y, y2[1].x + y2[1].y, y2[2].x + y2[2].y, y2[3].x + y2[3].y);
+        xch[(w * 3 + 1) * 64 + lane] = make_float4(du2[0].x + du2[0].y, du2[1].x + du2[1].y, du2[2].x + du2[2].y, du2[3].x + du2[3].y);
+        xch[(w * 3 + 2) * 64 + lane] = make_float4(dd2[0].x + dd2[0].y, dd2[1].x + dd2[1].y, dd2[2].x + dd2[2].y, dd2[3].x + dd2[3].y);
+        MMU_LDS_BARRIER();
+        const int arr = w == 0 ? 1 : (w == 1 ? 2 : 0);
+        float tot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 o = xch[(q * 3 + arr) * 64 + lane];
+            tot[0] += o.x; tot[1] += o.y; tot[2] += o.z; tot[3] += o.w;
+        }
+        // partial sums of dA (this wave's 4 states), dD, dbias: row of chunk c0; zeros for chunk c0 + 1
+        const unsigned prow = dcur * (unsigned)(N + 2) * 4u, prow1 = prow + (unsigned)p.dim * (N + 2) * 4u;
+        {
+            float v = dAq[0];
+            v = lane == 1 ? dAq[1] : v;
+            v = lane == 2 ? dAq[2] : v;
+            v = lane == 3 ? dAq[3] : v;
+            if (lane < 4) {
+                buf_store1(r_part, (n0 + lane) * 4u, prow, v);
+                buf_store1(r_part, (n0 + lane) * 4u, prow1, 0.f);
+            }
+        }
+        float ov[4];
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ov[i] = fmaf(Dv, dy[i], tot[i]);
+            buf_store4<io_t>(r_o, voff, dcur * o_ds * ES, ov);
+        } else if (w == 1) {
+            float dbp = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dsp = (p.softplus && vraw[i] <= 20.f) ? sigmoidf_(vraw[i]) : 1.f;  // bwd_kernel.cuh:439-453
+                ov[i] = tot[i] * dsp;
+                dbp += ov[i];
+            }
+            buf_store4<io_t>(r_o, voff, dcur * o_ds * ES, ov);
+            dbp = wave_sum(dbp);
+            if (lane == 0) {
+                buf_store1(r_part, (N + 1) * 4u, prow, dbp);
+                buf_store1(r_part, (N + 1) * 4u, prow1, 0.f);
+            }
+        } else if (w == 2) {
+            if constexpr (HAS_Z) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float yt = fmaf(Dv, uv[i], tot[i]);
+                    ov[i] = go[i] * yt * zsig[i] * (1.f + zv[i] * (1.f - zsig[i]));
+                }
+                buf_store4<io_t>(r_o, voff, dcur * o_ds * ES, ov);
+            }
+        } else {
+            float dDp = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dDp = fmaf(dy[i], uv[i], dDp);
+            dDp = wave_sum(dDp);
+            if (lane == 0) {
+                buf_store1(r_part, N * 4u, prow, dDp);
+                buf_store1(r_part, N * 4u, prow1, 0.f);
+            }
+            if (HAS_Z && p.out_z) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = fmaf(Dv, uv[i], tot[i]) * zv[i] * zsig[i];
+                buf_store4<io_t>(r_o, voff, dcur * o_ds * ES, ov);
+            }
+        }
+    }
+    // this wave's 4 rows of dB / dC
+    float *dBg = p.dB + (long)b * p.dB_bs + (long)g * p.dB_gs + t0 + lane * 4;
+    float *dCg = p.dC + (long)b * p.dC_bs + (long)g * p.dC_gs + t0 + lane * 4;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int n = n0 + 2 * pi;
+        *reinterpret_cast<float4 *>(dBg + (long)n * p.dB_ns) = make_float4(accB[pi][0].x, accB[pi][1].x, accB[pi][2].x, accB[pi][3].x);
+        *reinterpret_cast<float4 *>(dBg + (long)(n + 1) * p.dB_ns) = make_float4(accB[pi][0].y, accB[pi][1].y, accB[pi][2].y, accB[pi][3].y);
+        *reinterpret_cast<float4 *>(dCg + (long)n * p.dC_ns) = make_float4(accC[pi][0].x, accC[pi][1].x, accC[pi][2].x, accC[pi][3].x);
+        *reinterpret_cast<float4 *>(dCg + (long)(n + 1) * p.dC_ns) = make_float4(accC[pi][0].y, accC[pi][1].y, accC[pi][2].y, accC[pi][3].y);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K5: dA[d][n], dD[d], dbias[d] += sum over a slice of (b, chunk) of part[b][c][d][N+2].
 // grid (dim, n_slices = ceil(BC / 512)), block 256.  One slice: results go straight to dA/dD/dbias.
 // Several slices: slice sums go to part2[slice][d][N+2] and reduce_slices_kernel adds them in fixed
@@ -1306,7 +1623,30 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st) {
         chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.gx, total, a.n_chunks, N, 1);
         MMU_HIP_LAUNCH_CHECK("chunk_carry(reverse)");
     }
-    if (K == 2 && N == 16) {
+    const auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    const long span = (long)a.dim * std::max({a.u_ds, a.delta_ds, a.dout_ds, a.du_ds, a.ddelta_ds, a.z ? a.z_ds : 0L,
+                                              a.z ? a.dz_ds : 0L, a.out_z ? a.out_z_ds : 0L}) + a.seqlen;
+    const bool rows4 = mult(a.u_bs, 4) && mult(a.u_ds, 4) && mult(a.delta_bs, 4) && mult(a.delta_ds, 4) &&
+                       mult(a.dout_bs, 4) && mult(a.dout_ds, 4) && mult(a.du_bs, 4) && mult(a.du_ds, 4) &&
+                       mult(a.ddelta_bs, 4) && mult(a.ddelta_ds, 4) &&
+                       (!a.z || (mult(a.z_bs, 4) && mult(a.z_ds, 4) && mult(a.dz_bs, 4) && mult(a.dz_ds, 4))) &&
+                       (!a.out_z || (mult(a.out_z_bs, 4) && mult(a.out_z_ds, 4))) && mult(a.B_bs, 4) &&
+                       mult(a.B_gs, 4) && mult(a.B_ns, 4) && mult(a.C_bs, 4) && mult(a.C_gs, 4) && mult(a.C_ns, 4) &&
+                       mult(a.dB_bs, 4) && mult(a.dB_gs, 4) && mult(a.dB_ns, 4) && mult(a.dC_bs, 4) &&
+                       mult(a.dC_gs, 4) && mult(a.dC_ns, 4);
+    const bool ptrs16 = al16(a.u) && al16(a.delta) && al16(a.dout) && al16(a.z) && al16(a.du) && al16(a.ddelta) &&
+                        al16(a.dz) && al16(a.out_z) && al16(a.B) && al16(a.C) && al16(a.dB) && al16(a.dC);
+    if (K == 2 && N == 16 && a.seqlen % 256 == 0 && rows4 && ptrs16 && span * 4 < (1L << 31) &&
+        (long)a.dim * a.n_chunks * 2 * N * 4 < (1L << 31) && (long)a.n_chunks * a.dim * (N + 2) * 4 < (1L << 31)) {
+        // fast form: full aligned 256-token tiles, packed state pairs, buffer addressing
+        const size_t lds = sizeof(float) * (4 * 512 * 4 + 4 * 32 + 4 * 3 * 64 * 4);
+        dim3 gridp(a.seqlen / 256, a.batch, a.ngroups);
+        MMU_BOOL(a.z != nullptr, HAS_Z, {
+            if (int r = set_lds(chunk_apply_bwd_p4_kernel<io_t, HAS_Z>, lds)) return r;
+            chunk_apply_bwd_p4_kernel<io_t, HAS_Z><<<gridp, 256, lds, st>>>(a);
+        });
+        MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd_p4");
+    } else if (K == 2 && N == 16) {
         size_t lds = sizeof(float) * ((size_t)2 * N * T + (size_t)2 * 4 * 3 * 2 * 64);
         MMU_BOOL(full, FULL, {
             if (int r = set_lds(chunk_apply_bwd_ns4_kernel<io_t, 2, FULL>, lds)) return r;
