@@ -13,9 +13,14 @@
 //     d y[b,k,h,w]        = [0 <= y <= H-1] * sum_c g * (in[b,c,y0+1,col] - in[b,c,y0,col])
 //
 // ATen's generic grid_sampler_2d_backward spends 47 ms per MM-UNet training step at bs 8 (4 atomics per
-// tap-channel, plus the x-gradient nobody uses); this does 2 atomics whose addresses are contiguous
-// along w, no grid tensor, no coordinate tensors.  One thread per (b, k, h, w) walks a slice of the
-// channels; the output / dout rows it touches are contiguous along w (coalesced).
+// tap-channel, plus the x-gradient nobody uses).  Here the input gradient is a GATHER: the thread of input
+// element (yy, col) looks at the sources (k, h, w) that can reach it -- w is fixed by col and k (integer
+// columns), h within REACH rows of yy -- and takes the lerp weight of those whose y0 or y0 + 1 is yy.
+// Plain stores, no memset, bit-reproducible.  A source that lands further than REACH rows away (possible:
+// the row coordinate is unbounded) is not seen by any gatherer; the d(row) kernel, which visits every
+// source anyway, adds exactly those contributions with float atomics afterwards.  (First version: two
+// atomics per tap-channel for everything, 7.6 ms per training step -- the top kernel of the step.)
+// One thread per (b, k, h, w) / (b, yy, col) walks a slice of the channels; rows are contiguous along w.
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
 
@@ -23,6 +28,7 @@ namespace {
 
 struct MorphArgs {
     int B, C, H, W, K, cs;  // cs = channel slices (grid.z = B * cs)
+    int reach;              // gather window in rows (< 0: scatter everything, din pre-zeroed)
     const float *in;        // [B, C, H, W]
     const float *y;         // [B, K, H, W]  row coordinate in pixels (unclamped)
     float *out;             // [B, C, H*K, W]
@@ -88,18 +94,31 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
     float *gin = p.din + ioff;
     const float *g = p.dout + (((long)b * p.C + c0) * p.H * p.K + (long)(h * p.K + k)) * p.W + w;
     const long ostride = (long)p.H * p.K * p.W;
+    // targets the gather kernel does not see (further than `reach` rows from the source row h)
+    const bool far0 = p.reach < 0 || y0 - h > p.reach || h - y0 > p.reach;
+    const bool far1 = has1 && (p.reach < 0 || y0 + 1 - h > p.reach || h - y0 - 1 > p.reach);
     float acc = 0.f;
+    if (!far0 && !far1) {
 #pragma unroll 4
-    for (int c = c0; c < c1; ++c) {
-        const float gv = *g;
-        const float v0 = src[0];
-        const float v1 = has1 ? src[p.W] : 0.f;
-        acc = fmaf(gv, v1 - v0, acc);
-        atomicAdd(gin, gv * (1.f - wy));
-        if (has1) atomicAdd(gin + p.W, gv * wy);
-        src += HW;
-        gin += HW;
-        g += ostride;
+        for (int c = c0; c < c1; ++c) {
+            const float v0 = src[0];
+            const float v1 = has1 ? src[p.W] : 0.f;
+            acc = fmaf(*g, v1 - v0, acc);
+            src += HW;
+            g += ostride;
+        }
+    } else {
+        for (int c = c0; c < c1; ++c) {
+            const float gv = *g;
+            const float v0 = src[0];
+            const float v1 = has1 ? src[p.W] : 0.f;
+            acc = fmaf(gv, v1 - v0, acc);
+            if (far0) atomicAdd(gin, gv * (1.f - wy));
+            if (far1) atomicAdd(gin + p.W, gv * wy);
+            src += HW;
+            gin += HW;
+            g += ostride;
+        }
     }
     // d clamp: gradient passes where 0 <= y <= H-1 (torch.clamp)
     if (!(yr >= 0.f && yr <= (float)(p.H - 1))) acc = 0.f;
@@ -107,6 +126,56 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
         atomicAdd(p.dy + yi, acc);
     else
         p.dy[yi] = acc;
+}
+
+// d input as a gather (see the header).  grid (ceil(H*W / 256), 1, B * ceil(C / CS)); thread = (yy, col).
+template <int CS>
+__global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int HW = p.H * p.W;
+    if (pos >= HW) return;
+    const int yy = pos / p.W, col = pos - yy * p.W;
+    const int nsl = (p.C + CS - 1) / CS;
+    const int b = blockIdx.z / nsl;
+    const int c0 = (blockIdx.z - b * nsl) * CS;
+    const int nc = p.C - c0 < CS ? p.C - c0 : CS;
+    float acc[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) acc[c] = 0.f;
+    const int hlo = yy - p.reach > 0 ? yy - p.reach : 0;
+    const int hhi = yy + p.reach < p.H - 1 ? yy + p.reach : p.H - 1;
+    const long ostride = (long)p.H * p.K * p.W;
+    for (int k = 0; k < p.K; ++k) {
+        // source columns w with clamp(w + k - K/2, 0, W-1) == col
+        const int we = col - k + p.K / 2;
+        int wlo = col == 0 ? 0 : we, whi = col == p.W - 1 ? p.W - 1 : we;
+        wlo = wlo < 0 ? 0 : wlo;
+        whi = whi > p.W - 1 ? p.W - 1 : whi;
+        for (int w = wlo; w <= whi; ++w) {
+            const float *yp = p.y + ((long)(b * p.K + k) * p.H + hlo) * p.W + w;
+            const float *gp = p.dout + (((long)b * p.C + c0) * p.H * p.K + (long)(hlo * p.K + k)) * p.W + w;
+            for (int h = hlo; h <= hhi; ++h, yp += p.W, gp += (long)p.K * p.W) {
+                const float yc = fminf(fmaxf(*yp, 0.f), (float)(p.H - 1));
+                const int y0 = (int)floorf(yc);
+                const float wy = yc - (float)y0;
+                const float coef = y0 == yy ? 1.f - wy : (y0 + 1 == yy ? wy : 0.f);
+                if (coef != 0.f) {
+                    if (nc == CS) {
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) acc[c] = fmaf(coef, gp[c * ostride], acc[c]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CS; ++c)
+                            if (c < nc) acc[c] = fmaf(coef, gp[c * ostride], acc[c]);
+                    }
+                }
+            }
+        }
+    }
+    float *dst = p.din + ((long)b * p.C + c0) * HW + pos;
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+        if (c < nc) dst[(long)c * HW] = acc[c];
 }
 
 int channel_slices(int B, int C, int positions) {
@@ -152,9 +221,17 @@ extern "C" int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream) {
     const int positions = a.K * a.H * a.W;
     a.cs = channel_slices(a.B, a.C, positions);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(a.din, 0, sizeof(float) * (size_t)a.B * a.C * a.H * a.W, st);
-    if (e == hipSuccess && a.cs > 1) e = hipMemsetAsync(a.dy, 0, sizeof(float) * (size_t)a.B * positions, st);
-    if (e != hipSuccess) return mmu_fail("morph_sample_bwd: memset: %s", hipGetErrorString(e));
+    a.reach = 2;  // rows; anything further goes through the atomics of the d(row) kernel
+    {
+        constexpr int CS = 16;
+        dim3 gg((a.H * a.W + 255) / 256, 1, a.B * ((a.C + CS - 1) / CS));
+        morph_gather_din_kernel<CS><<<gg, 256, 0, st>>>(a);
+        MMU_HIP_LAUNCH_CHECK("morph_gather_din");
+    }
+    if (a.cs > 1) {
+        hipError_t e = hipMemsetAsync(a.dy, 0, sizeof(float) * (size_t)a.B * positions, st);
+        if (e != hipSuccess) return mmu_fail("morph_sample_bwd: memset: %s", hipGetErrorString(e));
+    }
     dim3 grid((positions + 255) / 256, 1, a.B * a.cs);
     morph_sample_bwd_kernel<<<grid, 256, 0, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("morph_sample_bwd");
