@@ -191,6 +191,17 @@ __device__ __forceinline__ v2f mul_bcast(v2f s, v2f x) {
     return r;
 }
 
+// x * s[HI] + c in one v_pk_fma_f32 (same rule: no fresh transcendental results as inputs)
+template <int HI>
+__device__ __forceinline__ v2f fma_bcast(v2f s, v2f x, v2f c) {
+    v2f r;
+    if constexpr (HI)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(s), "v"(x), "v"(c));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(s), "v"(x), "v"(c));
+    return r;
+}
+
 template <typename io_t, bool FULL>
 __device__ __forceinline__ void stage_pair8(float *__restrict__ s, const io_t *__restrict__ g, long row_stride,
                                             int N, int t0, int L, bool vec) {
@@ -407,6 +418,72 @@ __global__ __launch_bounds__(256) void chunk_carry_kernel(float *__restrict__ bu
             if (c < n_chunks) p[(long)cc * N] = v[j];
         }
     }
+}
+
+// K2, parallel form for power-of-two dstate <= 64: one 256-thread workgroup per (batch, channel); thread =
+// (segment of 32 consecutive chunks, state).  Each thread composes its segment in registers, the 256/N
+// segment maps meet in LDS, every thread picks up the state entering its segment and rewrites its 32
+// records -- one read and one write of the records (134 MB at the headline shape) with 4 waves per SIMD,
+// where the serial form has B*D*N threads = one wave per CU walking 512 dependent steps.
+template <int N>
+__global__ __launch_bounds__(256) void chunk_carry_par_kernel(float *__restrict__ buf, int n_chunks, int reverse) {
+    constexpr int SEG = 256 / N, CPT = 32;
+    __shared__ float2 agg[SEG][N];
+    const int n = threadIdx.x % N, seg = threadIdx.x / N;
+    float2 *p = reinterpret_cast<float2 *>(buf) + (long)blockIdx.x * n_chunks * N + n;
+    float Hblk = 0.f;  // state entering the current super-block of SEG * CPT chunks
+    for (int base = 0; base < n_chunks; base += SEG * CPT) {
+        const int cs = base + seg * CPT;
+        float2 v[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = cs + j;
+            const int cc = reverse ? n_chunks - 1 - c : c;
+            v[j] = c < n_chunks ? p[(long)cc * N] : make_float2(1.f, 0.f);
+        }
+        float P = 1.f, S = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            S = fmaf(v[j].x, S, v[j].y);
+            P *= v[j].x;
+        }
+        agg[seg][n] = make_float2(P, S);
+        __syncthreads();
+        float H = Hblk, Hnext = 0.f;
+        for (int sgm = 0; sgm < SEG; ++sgm) {
+            if (sgm == seg) Hnext = H;  // (H entering this thread's segment)
+            const float2 a = agg[sgm][n];
+            H = fmaf(a.x, H, a.y);
+        }
+        Hblk = H;  // state leaving the super-block
+        H = Hnext;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = cs + j;
+            const int cc = reverse ? n_chunks - 1 - c : c;
+            H = fmaf(v[j].x, H, v[j].y);
+            if (c < n_chunks) p[(long)cc * N] = make_float2(v[j].x, H);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_carry(float *buf, int batch, int dim, int N, int n_chunks, int reverse, hipStream_t st) {
+    const long rows = (long)batch * dim;
+    if (n_chunks >= 64 && rows < (1L << 31) && (N == 4 || N == 8 || N == 16 || N == 32 || N == 64)) {
+        switch (N) {
+            case 4: chunk_carry_par_kernel<4><<<(unsigned)rows, 256, 0, st>>>(buf, n_chunks, reverse); break;
+            case 8: chunk_carry_par_kernel<8><<<(unsigned)rows, 256, 0, st>>>(buf, n_chunks, reverse); break;
+            case 16: chunk_carry_par_kernel<16><<<(unsigned)rows, 256, 0, st>>>(buf, n_chunks, reverse); break;
+            case 32: chunk_carry_par_kernel<32><<<(unsigned)rows, 256, 0, st>>>(buf, n_chunks, reverse); break;
+            default: chunk_carry_par_kernel<64><<<(unsigned)rows, 256, 0, st>>>(buf, n_chunks, reverse); break;
+        }
+    } else {
+        const long total = rows * N;
+        chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(buf, total, n_chunks, N, reverse);
+    }
+    MMU_HIP_LAUNCH_CHECK(reverse ? "chunk_carry(reverse)" : "chunk_carry");
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1107,7 +1184,8 @@ __global__ __launch_bounds__(256, 3) void chunk_apply_bwd_ns4_kernel(ScanArgs p)
 //   * each wave stages only the B / C rows of ITS four states (private LDS region, no barrier).
 // grid (L / 256, batch, ngroups), block 256.  A tile is two 128-token chunks: carries come from x[2t-1]
 // and gx[2t+2]; the dA/dD/dbias partial row of the second chunk is written as zeros.
-// LDS: BC[4 waves][B|C][2 pairs][2][64] float4 | slots[4][2][16] | xch[4][3][64] float4   (44.5 KiB)
+// LDS: BC[4 waves][B|C][2 pairs][2][64] float4 | slots[4][2][16] | xch[2][4][3][64] float4   (56.5 KiB;
+// two workgroups per CU either way: 247 VGPRs)
 // ---------------------------------------------------------------------------
 template <typename io_t, bool HAS_Z>
 __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) {
@@ -1277,9 +1355,9 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
 #pragma unroll
                 for (int i = 1; i < 4; ++i) S = fma2(a[i], S, bb[i]);
                 R = a[3] * mul_bcast<1>(dy2[1], v2f{c1_.z, c1_.w});
-                R = a[2] * (mul_bcast<0>(dy2[1], v2f{c1_.x, c1_.y}) + R);
-                R = a[1] * (mul_bcast<1>(dy2[0], v2f{c0_.z, c0_.w}) + R);
-                R = a[0] * (mul_bcast<0>(dy2[0], v2f{c0_.x, c0_.y}) + R);
+                R = a[2] * fma_bcast<0>(dy2[1], v2f{c1_.x, c1_.y}, R);
+                R = a[1] * fma_bcast<1>(dy2[0], v2f{c0_.z, c0_.w}, R);
+                R = a[0] * fma_bcast<0>(dy2[0], v2f{c0_.x, c0_.y}, R);
             }
             const v2f S_in = fma2(P, h0, S), R_in = fma2(P, g0, R);
             S = lane == 0 ? S_in : S;
@@ -1311,7 +1389,7 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
                     const int i = 2 * k + hsel;
                     const v2f Bt = hsel ? v2f{fb.z, fb.w} : v2f{fb.x, fb.y};
                     const v2f Ct = hsel ? v2f{fc.z, fc.w} : v2f{fc.x, fc.y};
-                    const v2f gt = (hsel ? mul_bcast<1>(dy2[k], Ct) : mul_bcast<0>(dy2[k], Ct)) + gam;
+                    const v2f gt = hsel ? fma_bcast<1>(dy2[k], Ct, gam) : fma_bcast<0>(dy2[k], Ct, gam);
                     gam = a[i] * gt;
                     const v2f ahp = bb[i];
                     const v2f gdl = hsel ? mul_bcast<1>(dl2[k], gt) : mul_bcast<0>(dl2[k], gt);
@@ -1320,8 +1398,8 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
                     dd2[i] = fma2(gt, fma2(An, ahp, uB), dd2[i]);
                     dAp = fma2(gdl, ahp, dAp);
                     y2[i] = fma2(Ct, hh[i], y2[i]);
-                    accB[pi][i] += hsel ? mul_bcast<1>(u2[k], gdl) : mul_bcast<0>(u2[k], gdl);
-                    accC[pi][i] += hsel ? mul_bcast<1>(dy2[k], hh[i]) : mul_bcast<0>(dy2[k], hh[i]);
+                    accB[pi][i] = hsel ? fma_bcast<1>(u2[k], gdl, accB[pi][i]) : fma_bcast<0>(u2[k], gdl, accB[pi][i]);
+                    accC[pi][i] = hsel ? fma_bcast<1>(dy2[k], hh[i], accC[pi][i]) : fma_bcast<0>(dy2[k], hh[i], accC[pi][i]);
                 }
             }
             dAq[2 * pi] = wave_sum(dAp.x);
@@ -1330,18 +1408,17 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
         }
         put_slots(par ^ 1);  // (the prefetch group has landed long ago)
 
-        // meet the other three state-quarters: single exchange buffer, so wait until everybody has read
-        // the previous channel's before overwriting it
-        MMU_LDS_BARRIER();
-        xch[(w * 3 + 0) * 64 + lane] = make_float4(y2[0].x + y2[0].y, y2[1].x + y2[1].y, y2[2].x + y2[2].y, y2[3].x + y2[3].y);
-        xch[(w * 3 + 1) * 64 + lane] = make_float4(du2[0].x + du2[0].y, du2[1].x + du2[1].y, du2[2].x + du2[2].y, du2[3].x + du2[3].y);
-        xch[(w * 3 + 2) * 64 + lane] = make_float4(dd2[0].x + dd2[0].y, dd2[1].x + dd2[1].y, dd2[2].x + dd2[2].y, dd2[3].x + dd2[3].y);
+        // meet the other three state-quarters (exchange buffer double-buffered by channel parity: one barrier)
+        float4 *xc = xch + par * (4 * 3 * 64);
+        xc[(w * 3 + 0) * 64 + lane] = make_float4(y2[0].x + y2[0].y, y2[1].x + y2[1].y, y2[2].x + y2[2].y, y2[3].x + y2[3].y);
+        xc[(w * 3 + 1) * 64 + lane] = make_float4(du2[0].x + du2[0].y, du2[1].x + du2[1].y, du2[2].x + du2[2].y, du2[3].x + du2[3].y);
+        xc[(w * 3 + 2) * 64 + lane] = make_float4(dd2[0].x + dd2[0].y, dd2[1].x + dd2[1].y, dd2[2].x + dd2[2].y, dd2[3].x + dd2[3].y);
         MMU_LDS_BARRIER();
         const int arr = w == 0 ? 1 : (w == 1 ? 2 : 0);
         float tot[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 o = xch[(q * 3 + arr) * 64 + lane];
+            const float4 o = xc[(q * 3 + arr) * 64 + lane];
             tot[0] += o.x; tot[1] += o.y; tot[2] += o.z; tot[3] += o.w;
         }
         // partial sums of dA (this wave's 4 states), dD, dbias: row of chunk c0; zeros for chunk c0 + 1
@@ -1570,11 +1647,7 @@ int launch_fwd(const ScanArgs &a, hipStream_t st) {
     dim3 grid(a.n_chunks, a.batch, a.ngroups);
     const bool full = a.vec_io && a.vec_bc && a.seqlen % T == 0;  // no ragged tail, everything aligned
     if (int r = launch_reduce<io_t, K, false>(a, W, st)) return r;
-    {
-        const long total = (long)a.batch * a.dim * N;
-        chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.x, total, a.n_chunks, N, 0);
-        MMU_HIP_LAUNCH_CHECK("chunk_carry");
-    }
+    if (int r = launch_carry(a.x, a.batch, a.dim, N, a.n_chunks, 0, st)) return r;
     {
         // 512-token tiles on packed state pairs (buffer addressing: 32-bit offsets inside a batch item)
         const long span = (long)a.dim * std::max({a.u_ds, a.delta_ds, a.z ? a.z_ds : 0L, a.out ? a.out_ds : 0L,
@@ -1613,16 +1686,10 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st) {
     if (!have_x) {
         a.x = ws + xs + (size_t)a.batch * a.n_chunks * a.dim * (N + 2);
         if (int r = launch_reduce<io_t, K, false>(a, W16, st)) return r;
-        const long total = (long)a.batch * a.dim * N;
-        chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.x, total, a.n_chunks, N, 0);
-        MMU_HIP_LAUNCH_CHECK("chunk_carry (bwd recompute)");
+        if (int r = launch_carry(a.x, a.batch, a.dim, N, a.n_chunks, 0, st)) return r;
     }
     if (int r = launch_reduce<io_t, K, true>(a, W16, st)) return r;
-    {
-        const long total = (long)a.batch * a.dim * N;
-        chunk_carry_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.gx, total, a.n_chunks, N, 1);
-        MMU_HIP_LAUNCH_CHECK("chunk_carry(reverse)");
-    }
+    if (int r = launch_carry(a.gx, a.batch, a.dim, N, a.n_chunks, 1, st)) return r;
     const auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
     const long span = (long)a.dim * std::max({a.u_ds, a.delta_ds, a.dout_ds, a.du_ds, a.ddelta_ds, a.z ? a.z_ds : 0L,
                                               a.z ? a.dz_ds : 0L, a.out_z ? a.out_z_ds : 0L}) + a.seqlen;
@@ -1639,7 +1706,7 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st) {
     if (K == 2 && N == 16 && a.seqlen % 256 == 0 && rows4 && ptrs16 && span * 4 < (1L << 31) &&
         (long)a.dim * a.n_chunks * 2 * N * 4 < (1L << 31) && (long)a.n_chunks * a.dim * (N + 2) * 4 < (1L << 31)) {
         // fast form: full aligned 256-token tiles, packed state pairs, buffer addressing
-        const size_t lds = sizeof(float) * (4 * 512 * 4 + 4 * 32 + 4 * 3 * 64 * 4);
+        const size_t lds = sizeof(float) * (4 * 512 * 4 + 4 * 32 + 2 * 4 * 3 * 64 * 4);
         dim3 gridp(a.seqlen / 256, a.batch, a.ngroups);
         MMU_BOOL(a.z != nullptr, HAS_Z, {
             if (int r = set_lds(chunk_apply_bwd_p4_kernel<io_t, HAS_Z>, lds)) return r;

@@ -135,7 +135,10 @@ def _rand_case(b, d, l, n, seed, device=DEV):
 
 
 @pytest.mark.parametrize("shape", [(2, 6, 1024, 16), (2, 6, 4099, 16), (1, 128, 2048, 16), (2, 2, 256, 16),
-                                   (1, 8, 777, 64), (1, 4, 300, 128), (3, 5, 130, 8)])
+                                   (1, 8, 777, 64), (1, 4, 300, 128), (3, 5, 130, 8),
+                                   # full 512-token tiles with an odd dstate (zero partner state of the packed
+                                   # pairs), and >= 64 chunks (parallel chunk-carry kernel) for dstate 8 and 16
+                                   (1, 3, 1024, 5), (1, 4, 8192, 8), (1, 3, 16384, 16)])
 def test_scan_fwd_bwd_vs_oracle_mamba_layout(shape):
     """Seeded inputs in the layout mamba_inner hands over: u, delta, z are physically [D][B][L]
     (strides (L, B*L, 1)), SURVEY.md section 8a-5."""
