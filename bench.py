@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the roofline leg (the command profiles/r01_roofline_leg_kernel_stats.csv is taken from)")
     ap.add_argument("--cpu-size", type=int, default=512, help="image side of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -79,7 +81,9 @@ def scan_roofline(dev, iters=20):
             traffic = None
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-            "kernel": "mmu_selective_scan_fwd (chunk_reduce + chunk_carry + chunk_apply_fwd)",
+            "kernel": "mmu_selective_scan_fwd = chunk_reduce8 + chunk_carry_par + chunk_apply_fwd8 (one call)",
+            "binding": "VALU / transcendental issue, not HBM: SQ_ACTIVE_INST_VALU 85-87 % of kernel cycles in "
+                       "chunk_reduce8 / chunk_apply_fwd8 (DESIGN.md 4.1)",
             "shape": {"batch": b, "dim": d, "seqlen": l, "dstate": n, "dtype": "f32"},
             "algorithmic_bytes": alg_bytes, "ms_per_launch": round(ms, 4)}
 
@@ -121,6 +125,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.roofline_only:
+        print(json.dumps({"roofline": scan_roofline(dev)}), flush=True)
+        return
 
     from mm_unet_amd.dp import broadcast_module_state
     from mm_unet_amd.loss import DICE_BCE_Loss
