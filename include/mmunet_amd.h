@@ -169,9 +169,15 @@ int mmu_causal_conv1d_update(const mmu_conv1d_update_params *p, void *stream);
  * w + k - K/2, only the row coordinate y is learned, so the gather is a 2-tap vertical lerp.
  * All tensors contiguous float32.
  *   fwd: out[b,c,h*K+k,w] from input[b,c,:,:] and y[b,k,h,w] (pixels, unclamped)
- *   bwd: dinput (zeroed inside, accumulated with float atomics) and dy (clamp mask applied) */
+ *   bwd: dinput (written in full: gathered, far outliers added with float atomics) and dy (clamp mask applied)
+ * out_layout MMU_MORPH_TOKENS_LAST stores the samples as [channels, taps, batch, height, width], i.e. the
+ * (channels*taps) x (batch*height*width) matrix the K x 1 / stride K x 1 convolution that follows
+ * (MMUNet.py:262, dsc_conv_x) multiplies by its weight viewed as [Cout, Cin*K]: that conv is then one GEMM. */
+#define MMU_MORPH_BCHW 0
+#define MMU_MORPH_TOKENS_LAST 1
 typedef struct {
     int32_t batch, channels, height, width, taps;
+    int32_t out_layout;  /* MMU_MORPH_BCHW or MMU_MORPH_TOKENS_LAST (layout of out and dout) */
     const float *input;  /* [batch, channels, height, width] */
     const float *y;      /* [batch, taps, height, width] */
     float *out;          /* fwd: [batch, channels, height*taps, width] */

@@ -65,7 +65,7 @@ class Conv1dUpdateParams(ctypes.Structure):
 
 
 class MorphParams(ctypes.Structure):
-    _fields_ = ([(n, _i32) for n in ("batch", "channels", "height", "width", "taps")]
+    _fields_ = ([(n, _i32) for n in ("batch", "channels", "height", "width", "taps", "out_layout")]
                 + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")])
 
 

@@ -29,10 +29,11 @@ namespace {
 struct MorphArgs {
     int B, C, H, W, K, cs;  // cs = channel slices (grid.z = B * cs)
     int reach;              // gather window in rows (< 0: scatter everything, din pre-zeroed)
+    long so_b, so_c, so_h, so_k;  // element strides of out / dout (unit stride along w)
     const float *in;        // [B, C, H, W]
     const float *y;         // [B, K, H, W]  row coordinate in pixels (unclamped)
-    float *out;             // [B, C, H*K, W]
-    const float *dout;      // [B, C, H*K, W]
+    float *out;             // [B, C, H*K, W] or [C, K, B, H, W] (so_* strides)
+    const float *dout;      // same layout as out
     float *din;             // [B, C, H, W]  zero-initialised by the caller (atomics)
     float *dy;              // [B, K, H, W]  zero-initialised when cs > 1
 };
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(256) void morph_sample_fwd_kernel(MorphArgs p) {
     int col = w + k - p.K / 2;
     col = col < 0 ? 0 : (col > p.W - 1 ? p.W - 1 : col);
     const float *src = p.in + ((long)b * p.C + c0) * HW + (long)y0 * p.W + col;
-    float *dst = p.out + (((long)b * p.C + c0) * p.H * p.K + (long)(h * p.K + k)) * p.W + w;
-    const long ostride = (long)p.H * p.K * p.W;
+    float *dst = p.out + b * p.so_b + c0 * p.so_c + h * p.so_h + k * p.so_k + w;
+    const long ostride = p.so_c;
 #pragma unroll 4
     for (int c = c0; c < c1; ++c) {
         const float v0 = src[0];
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
     const long ioff = ((long)b * p.C + c0) * HW + (long)y0 * p.W + col;
     const float *src = p.in + ioff;
     float *gin = p.din + ioff;
-    const float *g = p.dout + (((long)b * p.C + c0) * p.H * p.K + (long)(h * p.K + k)) * p.W + w;
-    const long ostride = (long)p.H * p.K * p.W;
+    const float *g = p.dout + b * p.so_b + c0 * p.so_c + h * p.so_h + k * p.so_k + w;
+    const long ostride = p.so_c;
     // targets the gather kernel does not see (further than `reach` rows from the source row h)
     const bool far0 = p.reach < 0 || y0 - h > p.reach || h - y0 > p.reach;
     const bool far1 = has1 && (p.reach < 0 || y0 + 1 - h > p.reach || h - y0 - 1 > p.reach);
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
     for (int c = 0; c < CS; ++c) acc[c] = 0.f;
     const int hlo = yy - p.reach > 0 ? yy - p.reach : 0;
     const int hhi = yy + p.reach < p.H - 1 ? yy + p.reach : p.H - 1;
-    const long ostride = (long)p.H * p.K * p.W;
+    const long ostride = p.so_c;
     for (int k = 0; k < p.K; ++k) {
         // source columns w with clamp(w + k - K/2, 0, W-1) == col
         const int we = col - k + p.K / 2;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
         whi = whi > p.W - 1 ? p.W - 1 : whi;
         for (int w = wlo; w <= whi; ++w) {
             const float *yp = p.y + ((long)(b * p.K + k) * p.H + hlo) * p.W + w;
-            const float *gp = p.dout + (((long)b * p.C + c0) * p.H * p.K + (long)(hlo * p.K + k)) * p.W + w;
-            for (int h = hlo; h <= hhi; ++h, yp += p.W, gp += (long)p.K * p.W) {
+            const float *gp = p.dout + b * p.so_b + c0 * p.so_c + hlo * p.so_h + k * p.so_k + w;
+            for (int h = hlo; h <= hhi; ++h, yp += p.W, gp += p.so_h) {
                 const float yc = fminf(fmaxf(*yp, 0.f), (float)(p.H - 1));
                 const int y0 = (int)floorf(yc);
                 const float wy = yc - (float)y0;
@@ -186,12 +187,23 @@ int channel_slices(int B, int C, int positions) {
     return cs;
 }
 
+void set_out_strides(MorphArgs &a, int layout) {
+    const long HW = (long)a.H * a.W;
+    if (layout == MMU_MORPH_TOKENS_LAST) {  // [C][K][B][H][W]
+        a.so_c = (long)a.K * a.B * HW; a.so_k = (long)a.B * HW; a.so_b = HW; a.so_h = a.W;
+    } else {                                // [B][C][H*K][W]
+        a.so_b = (long)a.C * a.K * HW; a.so_c = (long)a.K * HW; a.so_h = (long)a.K * a.W; a.so_k = a.W;
+    }
+}
+
 int check(const mmu_morph_params *p, const char *name) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
     MMU_CHECK(p->batch > 0 && p->channels > 0 && p->height > 1 && p->width > 0 && p->taps > 0 && (p->taps & 1),
               "%s: need batch, channels > 0, height >= 2, odd number of taps", name);
     MMU_CHECK((long)p->batch * p->channels * p->height * p->taps * p->width < (1L << 31),
               "%s: tensor too large for 32-bit positions", name);
+    MMU_CHECK(p->out_layout == MMU_MORPH_BCHW || p->out_layout == MMU_MORPH_TOKENS_LAST, "%s: unknown out_layout %d",
+              name, p->out_layout);
     return 0;
 }
 
@@ -203,6 +215,7 @@ extern "C" int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream) {
     MorphArgs a = {};
     a.B = p->batch; a.C = p->channels; a.H = p->height; a.W = p->width; a.K = p->taps;
     a.in = p->input; a.y = p->y; a.out = p->out;
+    set_out_strides(a, p->out_layout);
     const int positions = a.K * a.H * a.W;
     a.cs = channel_slices(a.B, a.C, positions);
     dim3 grid((positions + 255) / 256, 1, a.B * a.cs);
@@ -218,6 +231,7 @@ extern "C" int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream) {
     MorphArgs a = {};
     a.B = p->batch; a.C = p->channels; a.H = p->height; a.W = p->width; a.K = p->taps;
     a.in = p->input; a.y = p->y; a.dout = p->dout; a.din = p->dinput; a.dy = p->dy;
+    set_out_strides(a, p->out_layout);
     const int positions = a.K * a.H * a.W;
     a.cs = channel_slices(a.B, a.C, positions);
     hipStream_t st = (hipStream_t)stream;

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from .mamba_simple import Mamba
 from . import morph_coords
 from .morph_sample import morph_sample
+from .tall_gemm import proj_tokens
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
 
@@ -144,8 +145,20 @@ class MMConv(nn.Module):
             y_rows = self._rows_fused(offset)
         else:
             y_rows = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope, rows_only=True)
-        deformed = morph_sample(input, y_rows)
-        output = self.dsc_conv_x(deformed) if self.morph == 0 else self.dsc_conv_y(deformed)
+        if self.morph == 0:
+            # dsc_conv_x (K x 1, stride K x 1) as ONE GEMM: the sampler writes the (Cin*K, B*H*W) matrix
+            # [c][k][b][h][w] directly, the conv weight [Cout, Cin, K, 1] viewed as [Cout, Cin*K] multiplies
+            # it (split-K weight gradient: the reduction runs over all B*H*W pixels).  MIOpen's implicit GEMM
+            # for this conv spent as long in NCHW<->NHWC transposes of the K x inflated tensor as in the math.
+            B, _, H, W = input.shape
+            conv = self.dsc_conv_x
+            samples = morph_sample(input, y_rows, tokens_last=True)
+            out2 = proj_tokens(conv.weight.view(conv.out_channels, -1), samples)
+            output = out2.view(conv.out_channels, B, H, W).permute(1, 0, 2, 3)
+            if conv.bias is not None:
+                output = output + conv.bias.view(1, -1, 1, 1)
+        else:
+            output = self.dsc_conv_y(morph_sample(input, y_rows))
         return self.gn(output)
 
 

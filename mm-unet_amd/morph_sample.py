@@ -9,9 +9,13 @@ coordinate map alone:
     out[b, c, h*K + k, w] = lerp(input[b, c, floor(yc), col], input[b, c, floor(yc)+1, col], frac(yc))
     yc = clamp(y[b, k, h, w], 0, H-1),  col = clamp(w + k - K//2, 0, W-1)
 
-Gradients: d input (float atomics, like ATen's grid_sampler backward) and d y (zero where y was
-clamped, like torch.clamp).  float32 only -- ``F.grid_sample`` is on autocast's fp32 list, so the
-reference computes this step in fp32 under autocast as well.
+Gradients: d input (a gather over the reachable sources; float atomics only for far outliers) and d y
+(zero where y was clamped, like torch.clamp).  float32 only -- ``F.grid_sample`` is on autocast's fp32
+list, so the reference computes this step in fp32 under autocast as well.
+
+``tokens_last=True`` returns the samples as the ``(C*K, B*H*W)`` matrix ``[c][k][b][h][w]``: the K x 1 /
+stride K x 1 ``dsc_conv_x`` that consumes them (MMUNet.py:262) is then ``weight.view(Cout, Cin*K) @ samples``
+-- one GEMM instead of an implicit-GEMM convolution with layout transposes around it.
 """
 import torch
 
@@ -20,7 +24,7 @@ from . import _lib
 
 class MorphSampleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, input, y):
+    def forward(ctx, input, y, tokens_last=False):
         _lib.require_gpu(input, y)
         if input.dim() != 4 or y.dim() != 4 or y.shape[0] != input.shape[0] or y.shape[2:] != input.shape[2:]:
             raise RuntimeError("morph_sample: input must be (B, C, H, W) and y (B, K, H, W)")
@@ -30,14 +34,16 @@ class MorphSampleFn(torch.autograd.Function):
         yy = y.float().contiguous()
         B, C, H, W = x.shape
         K = yy.shape[1]
-        out = torch.empty((B, C, H * K, W), device=x.device, dtype=torch.float32)
+        shape = (C * K, B * H * W) if tokens_last else (B, C, H * K, W)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
         p = _lib.MorphParams()
         p.batch, p.channels, p.height, p.width, p.taps = B, C, H, W, K
+        p.out_layout = int(tokens_last)
         p.input, p.y, p.out = x.data_ptr(), yy.data_ptr(), out.data_ptr()
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_morph_sample_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, yy)
-        ctx.in_dtype, ctx.y_dtype = input.dtype, y.dtype
+        ctx.in_dtype, ctx.y_dtype, ctx.tokens_last = input.dtype, y.dtype, bool(tokens_last)
         return out
 
     @staticmethod
@@ -50,13 +56,15 @@ class MorphSampleFn(torch.autograd.Function):
         dy = torch.empty_like(yy)
         p = _lib.MorphParams()
         p.batch, p.channels, p.height, p.width, p.taps = B, C, H, W, K
+        p.out_layout = int(ctx.tokens_last)
         p.input, p.y, p.dout = x.data_ptr(), yy.data_ptr(), g.data_ptr()
         p.dinput, p.dy = dinput.data_ptr(), dy.data_ptr()
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_morph_sample_bwd(p, _lib.stream_of(x)))
-        return dinput.to(ctx.in_dtype), dy.to(ctx.y_dtype)
+        return dinput.to(ctx.in_dtype), dy.to(ctx.y_dtype), None
 
 
-def morph_sample(input, y):
-    """input (B, C, H, W), y (B, K, H, W) row coordinates in pixels -> (B, C, H*K, W)."""
-    return MorphSampleFn.apply(input, y)
+def morph_sample(input, y, tokens_last=False):
+    """input (B, C, H, W), y (B, K, H, W) row coordinates in pixels -> (B, C, H*K, W), or the
+    (C*K, B*H*W) matrix ``[c][k][b][h][w]`` with ``tokens_last=True``."""
+    return MorphSampleFn.apply(input, y, tokens_last)

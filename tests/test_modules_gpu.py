@@ -213,6 +213,37 @@ def test_morph_sample_vs_grid_sample_composition(shape):
     close(yg.grad, yr.grad, 1e-4, 1e-4, "d y")
 
 
+def test_morph_sample_tokens_last_layout():
+    """tokens_last=True is the same samples as the (Cin*K, B*H*W) matrix [c][k][b][h][w], and the GEMM with
+    the conv weight viewed as [Cout, Cin*K] is dsc_conv_x (MMUNet.py:262) -- values and all gradients."""
+    from mm_unet_amd.morph_sample import morph_sample
+    from mm_unet_amd.tall_gemm import proj_tokens
+    B, C, H, W, K, CO = 2, 12, 20, 17, 3, 8
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    y = (torch.arange(H, dtype=torch.float32).view(1, 1, H, 1) + 1.2 * torch.randn(B, K, H, W, generator=gen)).to(DEV)
+    conv = torch.nn.Conv2d(C, CO, kernel_size=(K, 1), stride=(K, 1)).to(DEV)
+    g = torch.randn(B, CO, H, W, generator=gen).to(DEV)
+
+    xa, ya = x.clone().requires_grad_(), y.clone().requires_grad_()
+    ref = conv(morph_sample(xa, ya))
+    ref.backward(g)
+    gw_ref, gb_ref = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.zero_grad()
+
+    xb, yb = x.clone().requires_grad_(), y.clone().requires_grad_()
+    s2 = morph_sample(xb, yb, tokens_last=True)
+    assert s2.shape == (C * K, B * H * W)
+    close(s2.view(C, K, B, H, W).permute(2, 0, 3, 1, 4).reshape(B, C, H * K, W), morph_sample(x, y), 0, 0, "layout")
+    out = proj_tokens(conv.weight.view(CO, -1), s2).view(CO, B, H, W).permute(1, 0, 2, 3) + conv.bias.view(1, -1, 1, 1)
+    out.backward(g)
+    close(out, ref, 1e-4, 1e-4, "conv as GEMM")
+    close(xb.grad, xa.grad, 1e-4, 1e-4, "d input")
+    close(yb.grad, ya.grad, 1e-4, 1e-4, "d y")
+    close(conv.weight.grad, gw_ref, 1e-4, 1e-3, "d weight")
+    close(conv.bias.grad, gb_ref, 1e-4, 1e-3, "d bias")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
