@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .mamba_simple import Mamba
 from . import morph_coords
 from .morph_sample import morph_sample
-from .tall_gemm import proj_tokens
+from .tall_gemm import dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
 
@@ -153,8 +153,7 @@ class MMConv(nn.Module):
             B, _, H, W = input.shape
             conv = self.dsc_conv_x
             samples = morph_sample(input, y_rows, tokens_last=True)
-            out2 = proj_tokens(conv.weight.view(conv.out_channels, -1), samples)
-            output = out2.view(conv.out_channels, B, H, W).permute(1, 0, 2, 3)
+            output = dsc_gemm(conv.weight.view(conv.out_channels, -1), samples, B).view(B, conv.out_channels, H, W)
             if conv.bias is not None:
                 output = output + conv.bias.view(1, -1, 1, 1)
         else:

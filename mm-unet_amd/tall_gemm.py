@@ -58,3 +58,38 @@ class _ProjTokensFn(torch.autograd.Function):
 def proj_tokens(W, Xm):
     """W @ Xm for Xm of shape (in_features, tokens) -- tall-K-safe autograd."""
     return _ProjTokensFn.apply(W, Xm)
+
+
+class _DscGemmFn(torch.autograd.Function):
+    """The K x 1 / stride K x 1 ``dsc_conv_x`` of MMConv (MMUNet.py:262) on the tokens-last sampler output:
+    W2 (Cout, Cin*K) times samples (Cin*K, B*T) -> (B, Cout, T) **batch-major** (what GroupNorm wants), as
+    a strided batched GEMM -- batch b's operand is rows of ``samples`` with leading dimension B*T, so
+    neither the K x inflated samples nor the output are ever copied.  Backward: the (small) output
+    gradient is brought to tokens-last once; dX = W2^T @ G lands in the samples' layout, dW uses split-K."""
+
+    @staticmethod
+    def forward(ctx, W2, samples, batch):
+        O, I = W2.shape
+        T = samples.shape[1] // batch
+        ctx.save_for_backward(W2, samples)
+        ctx.batch = batch
+        Xb = samples.view(I, batch, T).permute(1, 0, 2)                   # (B, I, T) view, ld = B*T
+        return torch.bmm(W2.unsqueeze(0).expand(batch, O, I), Xb)         # (B, O, T) contiguous
+
+    @staticmethod
+    def backward(ctx, G):
+        W2, samples = ctx.saved_tensors
+        B = ctx.batch
+        O = W2.shape[0]
+        G2 = G.permute(1, 0, 2).reshape(O, -1)                             # (O, B*T): the one small copy
+        dW = dX = None
+        if ctx.needs_input_grad[0]:
+            dW = nt_splitk(G2, samples).to(W2.dtype)
+        if ctx.needs_input_grad[1]:
+            dX = W2.t() @ G2
+        return dW, dX, None
+
+
+def dsc_gemm(W2, samples, batch):
+    """(Cout, Cin*K) x (Cin*K, B*T) tokens-last samples -> (B, Cout, T)."""
+    return _DscGemmFn.apply(W2, samples, batch)

@@ -217,7 +217,7 @@ def test_morph_sample_tokens_last_layout():
     """tokens_last=True is the same samples as the (Cin*K, B*H*W) matrix [c][k][b][h][w], and the GEMM with
     the conv weight viewed as [Cout, Cin*K] is dsc_conv_x (MMUNet.py:262) -- values and all gradients."""
     from mm_unet_amd.morph_sample import morph_sample
-    from mm_unet_amd.tall_gemm import proj_tokens
+    from mm_unet_amd.tall_gemm import dsc_gemm
     B, C, H, W, K, CO = 2, 12, 20, 17, 3, 8
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(B, C, H, W, generator=gen).to(DEV)
@@ -235,7 +235,7 @@ def test_morph_sample_tokens_last_layout():
     s2 = morph_sample(xb, yb, tokens_last=True)
     assert s2.shape == (C * K, B * H * W)
     close(s2.view(C, K, B, H, W).permute(2, 0, 3, 1, 4).reshape(B, C, H * K, W), morph_sample(x, y), 0, 0, "layout")
-    out = proj_tokens(conv.weight.view(CO, -1), s2).view(CO, B, H, W).permute(1, 0, 2, 3) + conv.bias.view(1, -1, 1, 1)
+    out = dsc_gemm(conv.weight.view(CO, -1), s2, B).view(B, CO, H, W) + conv.bias.view(1, -1, 1, 1)
     out.backward(g)
     close(out, ref, 1e-4, 1e-4, "conv as GEMM")
     close(xb.grad, xa.grad, 1e-4, 1e-4, "d input")
