@@ -189,6 +189,20 @@ typedef struct {
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
 int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
 
+/* ---- bilinear resize, align_corners=True (a11: DecoderBlock x2, RCG edge map, side outputs) -------- */
+/* F.interpolate(mode="bilinear", align_corners=True) on contiguous float32 [planes = batch*channels, h, w]
+ * (src/UM_Net/MMUNet.py:362,384,571-575).  Backward is a gather (no atomics, dinput written in full). */
+typedef struct {
+    int32_t planes, in_h, in_w, out_h, out_w;
+    const float *input;  /* fwd: [planes, in_h, in_w] */
+    float *out;          /* fwd: [planes, out_h, out_w] */
+    const float *dout;   /* bwd: [planes, out_h, out_w] */
+    float *dinput;       /* bwd: [planes, in_h, in_w] */
+} mmu_resize_params;
+
+int mmu_bilinear_resize_fwd(const mmu_resize_params *p, void *stream);
+int mmu_bilinear_resize_bwd(const mmu_resize_params *p, void *stream);
+
 /* ---- MMConv glue around its K-channel Mamba, fused ----------------- */
 /* Replaces ~30 tiny PyTorch kernels per MMConv block and direction (src/UM_Net/MMUNet.py:122-193 +
  * requirements/mamba_simple.py:201-205,365): zig-zag token flatten + in_proj (A), and out_proj + inverse

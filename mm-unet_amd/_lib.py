@@ -69,6 +69,11 @@ class MorphParams(ctypes.Structure):
                 + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")])
 
 
+class ResizeParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("planes", "in_h", "in_w", "out_h", "out_w")]
+                + [(n, _vp) for n in ("input", "out", "dout", "dinput")])
+
+
 class CoordsParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
@@ -81,7 +86,8 @@ EXPORTS = (
     "mmu_abi_version", "mmu_last_error", "mmu_scan_chunk_len", "mmu_scan_bwd_workspace_bytes",
     "mmu_selective_scan_fwd", "mmu_selective_scan_bwd", "mmu_causal_conv1d_fwd", "mmu_causal_conv1d_bwd",
     "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
-    "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_debug_wave_scan",
+    "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
+    "mmu_bilinear_resize_bwd", "mmu_debug_wave_scan",
 )
 
 _lib = None
@@ -111,7 +117,8 @@ def lib():
                      ("mmu_causal_conv1d_update", Conv1dUpdateParams),
                      ("mmu_morph_sample_fwd", MorphParams), ("mmu_morph_sample_bwd", MorphParams),
                      ("mmu_zigzag_inproj_fwd", CoordsParams), ("mmu_zigzag_inproj_bwd", CoordsParams),
-                     ("mmu_coords_outproj_fwd", CoordsParams), ("mmu_coords_outproj_bwd", CoordsParams)):
+                     ("mmu_coords_outproj_fwd", CoordsParams), ("mmu_coords_outproj_bwd", CoordsParams),
+                     ("mmu_bilinear_resize_fwd", ResizeParams), ("mmu_bilinear_resize_bwd", ResizeParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]

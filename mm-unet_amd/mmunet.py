@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from .mamba_simple import Mamba
 from . import morph_coords
 from .morph_sample import morph_sample
+from .resize import bilinear_resize
 from .tall_gemm import dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
@@ -239,7 +240,7 @@ class RCG(nn.Module):
 
     def forward(self, pre, edge, f):
         r = (1 - torch.sigmoid(pre)) * f
-        edge1 = F.interpolate(edge, size=f.size()[2:], mode="bilinear", align_corners=True)
+        edge1 = bilinear_resize(edge, size=f.size()[2:])
         x2 = self.conv1(torch.cat((edge1, r), 1))
         # tri-directional Mamba at 2x resolution (MMUNet.py:398-412)
         x0 = self.upsample(x2)
@@ -260,7 +261,7 @@ class DecoderBlock(nn.Module):
                                    nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        return F.interpolate(self.conv2(self.conv1(x)), scale_factor=2, mode="bilinear", align_corners=True)
+        return bilinear_resize(self.conv2(self.conv1(x)), scale_factor=2)
 
 
 class ResidualBlock(nn.Module):
@@ -330,7 +331,7 @@ class MM_Net(nn.Module):
 
     def forward(self, x):
         size = x.size()[2:]
-        up = lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=True)  # noqa: E731
+        up = lambda t: bilinear_resize(t, size=size)  # noqa: E731
         e1 = self.encoder1(x)
         e2 = self.encoder2(self.maxpool(e1))
         e3 = self.encoder3(e2)

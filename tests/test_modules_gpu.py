@@ -244,6 +244,31 @@ def test_morph_sample_tokens_last_layout():
     close(conv.bias.grad, gb_ref, 1e-4, 1e-3, "d bias")
 
 
+@pytest.mark.parametrize("case", [((2, 5, 16, 16), (32, 32)), ((1, 3, 17, 9), (40, 33)), ((2, 2, 64, 64), (16, 16)),
+                                  ((1, 2, 8, 8), (64, 64)), ((1, 1, 1, 7), (5, 1)), ((1, 2, 33, 20), (33, 20)),
+                                  ((2, 3, 31, 29), (12, 50))])
+def test_bilinear_resize_vs_interpolate(case):
+    """bilinear_resize == F.interpolate(mode="bilinear", align_corners=True) evaluated on CPU
+    (MMUNet.py:362,384,571-575), forward and input gradient, up- and down-sampling, degenerate sizes."""
+    import torch.nn.functional as F
+    from mm_unet_amd.resize import bilinear_resize
+    shape, size = case
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(*shape, generator=gen)
+    g = torch.randn(shape[0], shape[1], *size, generator=gen)
+    xr = x.clone().requires_grad_()
+    ref = F.interpolate(xr, size=size, mode="bilinear", align_corners=True)
+    ref.backward(g)
+    xg = x.to(DEV).requires_grad_()
+    out = bilinear_resize(xg, size=size)
+    out.backward(g.to(DEV))
+    close(out, ref, 1e-5, 1e-5, "resize")
+    close(xg.grad, xr.grad, 1e-5, 1e-4, "d input")
+    # scale_factor form (DecoderBlock)
+    if size == (2 * shape[2], 2 * shape[3]):
+        close(bilinear_resize(x.to(DEV), scale_factor=2), ref, 1e-5, 1e-5, "scale_factor=2")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
