@@ -203,6 +203,30 @@ typedef struct {
 int mmu_bilinear_resize_fwd(const mmu_resize_params *p, void *stream);
 int mmu_bilinear_resize_bwd(const mmu_resize_params *p, void *stream);
 
+/* ---- 3x3 / stride 1 / pad 1 convolution with few output channels (a9: MMConv.offset_conv) ------------ */
+/* nn.Conv2d(Cin, CO, 3, padding=1) for CO in {1, 2, 6, 8} (src/UM_Net/MMUNet.py:46,250: Cin -> 2K = 6), contiguous
+ * float32 NCHW.  weight_t is the weight transposed to [Cin][3][3][CO] (a channel's CO*9 weights contiguous).
+ *   fwd : out[b,co,h,w] = bias[co] + sum_{ci,ky,kx} W[co][ci][ky][kx] * in[b,ci,h+ky-1,w+kx-1]
+ *   bwd : dinput (if non-NULL), dweight [CO][Cin][3][3] and dbias [CO] (if non-NULL; zeroed inside, float atomics) */
+typedef struct {
+    int32_t batch, in_channels, out_channels, height, width;
+    const float *input;     /* [batch, in_channels, height, width] */
+    const float *weight_t;  /* [in_channels, 3, 3, out_channels] */
+    const float *bias;      /* [out_channels] or NULL */
+    float *out;             /* fwd: [batch, out_channels, height, width] */
+    const float *dout;      /* bwd: same shape as out */
+    float *dinput;          /* bwd, optional */
+    float *dweight;         /* bwd, optional: [out_channels, in_channels, 3, 3] */
+    float *dbias;           /* bwd, optional (only with dweight) */
+    float *workspace;       /* fwd: mmu_conv3x3_small_fwd_splits() x (elements of out) floats when splits > 1 */
+} mmu_conv3x3s_params;
+
+/* small images have too few pixels to fill the chip: the forward then slices the input channels and sums the
+ * slices' partial outputs in a fixed order (reproducible); returns the number of slices (1 = no workspace) */
+int mmu_conv3x3_small_fwd_splits(int batch, int in_channels, int height, int width);
+int mmu_conv3x3_small_fwd(const mmu_conv3x3s_params *p, void *stream);
+int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream);
+
 /* ---- MMConv glue around its K-channel Mamba, fused ----------------- */
 /* Replaces ~30 tiny PyTorch kernels per MMConv block and direction (src/UM_Net/MMUNet.py:122-193 +
  * requirements/mamba_simple.py:201-205,365): zig-zag token flatten + in_proj (A), and out_proj + inverse

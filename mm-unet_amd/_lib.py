@@ -74,6 +74,12 @@ class ResizeParams(ctypes.Structure):
                 + [(n, _vp) for n in ("input", "out", "dout", "dinput")])
 
 
+class Conv3x3sParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "in_channels", "out_channels", "height", "width")]
+                + [(n, _vp) for n in ("input", "weight_t", "bias", "out", "dout", "dinput", "dweight", "dbias",
+                                      "workspace")])
+
+
 class CoordsParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
@@ -87,7 +93,8 @@ EXPORTS = (
     "mmu_selective_scan_fwd", "mmu_selective_scan_bwd", "mmu_causal_conv1d_fwd", "mmu_causal_conv1d_bwd",
     "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
-    "mmu_bilinear_resize_bwd", "mmu_debug_wave_scan",
+    "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
+    "mmu_debug_wave_scan",
 )
 
 _lib = None
@@ -118,10 +125,13 @@ def lib():
                      ("mmu_morph_sample_fwd", MorphParams), ("mmu_morph_sample_bwd", MorphParams),
                      ("mmu_zigzag_inproj_fwd", CoordsParams), ("mmu_zigzag_inproj_bwd", CoordsParams),
                      ("mmu_coords_outproj_fwd", CoordsParams), ("mmu_coords_outproj_bwd", CoordsParams),
-                     ("mmu_bilinear_resize_fwd", ResizeParams), ("mmu_bilinear_resize_bwd", ResizeParams)):
+                     ("mmu_bilinear_resize_fwd", ResizeParams), ("mmu_bilinear_resize_bwd", ResizeParams),
+                     ("mmu_conv3x3_small_fwd", Conv3x3sParams), ("mmu_conv3x3_small_bwd", Conv3x3sParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
+    L.mmu_conv3x3_small_fwd_splits.restype = ctypes.c_int
+    L.mmu_conv3x3_small_fwd_splits.argtypes = [ctypes.c_int] * 4
     L.mmu_debug_wave_scan.restype = ctypes.c_int
     L.mmu_debug_wave_scan.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]
     _lib = L

@@ -1,0 +1,79 @@
+"""``conv3x3_small`` -- ``nn.Conv2d(Cin, CO, 3, padding=1)`` with CO in {1, 2, 6, 8} as direct HIP kernels.
+
+MMConv's ``offset_conv`` (Cin -> 2K = 6 channels, src/UM_Net/MMUNet.py:46,250) runs 44 times per MM-UNet
+forward.  Six output channels leave a matrix core nothing to do; MIOpen's Winograd / implicit-GEMM kernels
+take 60 us forward and 140 us backward for [8, 64, 128, 128] (5.3 ms per training step in total).  float32,
+contiguous NCHW; anything else is the caller's ``F.conv2d``.
+"""
+import torch
+
+from . import _lib
+
+SUPPORTED_CO = (1, 2, 6, 8)
+WEIGHT_GRAD_NATIVE = False   # True: mmu_conv3x3_small_bwd also computes dweight / dbias (tests cover both)
+
+
+def supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and weight.shape[2:] == (3, 3) and weight.shape[0] in SUPPORTED_CO and not torch.is_autocast_enabled())
+
+
+class Conv3x3SmallFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_gpu(x, weight)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        CO = weight.shape[0]
+        wt = weight.permute(1, 2, 3, 0).contiguous()          # [Cin][3][3][CO]
+        out = torch.empty((B, CO, H, W), device=x.device, dtype=torch.float32)
+        p = _lib.Conv3x3sParams()
+        p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
+        p.input, p.weight_t, p.bias, p.out = x.data_ptr(), wt.data_ptr(), _lib.ptr(bias), out.data_ptr()
+        splits = _lib.lib().mmu_conv3x3_small_fwd_splits(B, Cin, H, W)
+        ws = torch.empty((splits,) + tuple(out.shape), device=x.device, dtype=torch.float32) if splits > 1 else None
+        p.workspace = _lib.ptr(ws)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_conv3x3_small_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, wt)
+        ctx.has_bias = bias is not None
+        ctx.wshape = tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wt = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        CO = ctx.wshape[0]
+        g = dout.contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        if need_x:
+            dx = torch.empty_like(x)
+            p = _lib.Conv3x3sParams()
+            p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
+            p.input, p.weight_t, p.dout, p.dinput = x.data_ptr(), wt.data_ptr(), g.data_ptr(), dx.data_ptr()
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
+        if need_w or need_b:
+            if WEIGHT_GRAD_NATIVE:
+                dw = torch.empty(ctx.wshape, device=x.device, dtype=torch.float32)
+                db = torch.empty(CO, device=x.device, dtype=torch.float32) if need_b else None
+                p = _lib.Conv3x3sParams()
+                p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
+                p.input, p.weight_t, p.dout = x.data_ptr(), wt.data_ptr(), g.data_ptr()
+                p.dweight, p.dbias = dw.data_ptr(), _lib.ptr(db)
+                with torch.cuda.device(x.device):
+                    _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
+            else:
+                # the reduction over all pixels is where MIOpen's implicit-GEMM weight-gradient kernel is still
+                # ahead of the direct one (45 us vs 60-250 us on the larger maps)
+                w = wt.permute(3, 0, 1, 2)
+                _, dw, db = torch.ops.aten.convolution_backward(
+                    g, x, w, [CO] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                    [False, bool(need_w), bool(need_b)])
+        return dx, dw, db
+
+
+def conv3x3_small(x, weight, bias=None):
+    return Conv3x3SmallFn.apply(x, weight, bias)

@@ -1,0 +1,341 @@
+// conv3x3_small.hip -- 3x3 / stride 1 / pad 1 convolution with FEW output channels (CO <= 8) for gfx950:
+// MMConv's offset_conv (Cin -> 2K = 6, src/UM_Net/MMUNet.py:46,250), 44 of them per MM-UNet forward.
+//
+// With 6 output channels there is nothing for a matrix core to chew on (an MFMA tile would be >80 % padding)
+// and MIOpen's Winograd / implicit-GEMM kernels take 60 us forward and 140 us backward for
+// [8,64,128,128] (5.3 ms per training step over the 44 layers).  These are direct kernels whose weights are
+// wave-uniform scalars (the weight tensor is passed transposed, [Cin][3][3][CO], so a channel's CO*9
+// weights are one contiguous scalar load) and whose activations stream through once:
+//   fwd : thread = 4 consecutive pixels of a row; per input channel 9 loads (3 rows x (16 B + 2 halo)),
+//         4*9*CO FMAs.
+//   bwd data : thread = 2 pixels; loads the CO x 3 x 4 neighbourhood of dout ONCE, then per input channel
+//         2*9*CO FMAs against scalar weights and one 8-byte store.
+//   bwd weight/bias : wave = (input channel, 2048-pixel chunk); lane = pixel (coalesced), CO*9 register
+//         accumulators, wave reduction at the end, one float atomic per (wave, weight).
+#include "mmu_common.h"
+#include "../../include/mmunet_amd.h"
+
+namespace {
+
+// Every border case is handled by clamping the address and multiplying by a 0/1 mask: a conditional load
+// compiles to an exec-mask branch with its own s_waitcnt, which serialises the nine neighbour loads (the
+// first version of the weight-gradient kernel ran 8x slower than its instruction count for that reason).
+
+// fwd.  grid (ceil(B*H*ceil(W/4) / 256), splits): split s handles input channels [s*cps, (s+1)*cps) and
+// writes its partial sums to part[s] ([B][CO][H][W]); with one split `part` is the output itself.
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3s_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                           const float *__restrict__ bias, float *__restrict__ part,
+                                                           int B, int Cin, int H, int W, int cps) {
+    const int wq = (W + 3) / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * H * wq) return;
+    const int q = (int)(idx % wq);
+    const long r = idx / wq;
+    const int h = (int)(r % H), b = (int)(r / H);
+    const int w0 = q * 4;
+    const long HW = (long)H * W;
+    const int c_lo = blockIdx.y * cps, c_hi = c_lo + cps < Cin ? c_lo + cps : Cin;
+    float acc[CO][4];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const float bv = (bias && blockIdx.y == 0) ? bias[co] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[co][j] = bv;
+    }
+    // clamped neighbourhood: rows h-1..h+1, columns w0-1..w0+4
+    int roff[3], coff[6];
+    float rm[3], cm[6];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int hh = h + dy - 1;
+        rm[dy] = (hh >= 0 && hh < H) ? 1.f : 0.f;
+        roff[dy] = (hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh)) * W;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int ww = w0 + j - 1;
+        cm[j] = (ww >= 0 && ww < W) ? 1.f : 0.f;
+        coff[j] = ww < 0 ? 0 : (ww > W - 1 ? W - 1 : ww);
+    }
+    const bool vec = (W & 3) == 0;  // then columns w0..w0+3 are in range and 16-byte aligned
+    const float *xp = x + ((long)b * Cin + c_lo) * HW;
+    for (int ci = c_lo; ci < c_hi; ++ci, xp += HW) {
+        float v[3][6];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const float *rp = xp + roff[dy];
+            if (vec) {
+                const float4 c = *reinterpret_cast<const float4 *>(rp + w0);
+                v[dy][1] = c.x * rm[dy]; v[dy][2] = c.y * rm[dy]; v[dy][3] = c.z * rm[dy]; v[dy][4] = c.w * rm[dy];
+                v[dy][0] = rp[coff[0]] * (rm[dy] * cm[0]);
+                v[dy][5] = rp[coff[5]] * (rm[dy] * cm[5]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[dy][j] = rp[coff[j]] * (rm[dy] * cm[j]);
+            }
+        }
+        const float *wc = wt + (long)ci * 9 * CO;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float wv = wc[(dy * 3 + dx) * CO + co];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(wv, v[dy][j + dx], acc[co][j]);
+                }
+    }
+    float *op = part + ((long)blockIdx.y * B + b) * CO * HW + (long)h * W + w0;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (vec) {
+            *reinterpret_cast<float4 *>(op + co * HW) = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w0 + j < W) op[co * HW + j] = acc[co][j];
+        }
+    }
+}
+
+// out = sum over splits of part[s]  (fixed order: reproducible)
+__global__ __launch_bounds__(256) void conv3x3s_sum_splits_kernel(const float *__restrict__ part, float *__restrict__ out,
+                                                                  long n, int splits) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int k = 1; k < splits; ++k) s += part[(long)k * n + i];
+    out[i] = s;
+}
+
+// dx[b,ci,y,x] = sum_co sum_{ky,kx} W[co][ci][ky][kx] * g[b,co,y-ky+1,x-kx+1]
+// grid (ceil(B*H*ceil(W/2) / 256), channel slices): every slice re-reads the (small) dout neighbourhood
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__restrict__ g, const float *__restrict__ wt,
+                                                                float *__restrict__ dx, int B, int Cin, int H, int W,
+                                                                int cps) {
+    const int wq = (W + 1) / 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * H * wq) return;
+    const int q = (int)(idx % wq);
+    const long r = idx / wq;
+    const int h = (int)(r % H), b = (int)(r / H);
+    const int w0 = q * 2;
+    const long HW = (long)H * W;
+    const int c_lo = blockIdx.y * cps, c_hi = c_lo + cps < Cin ? c_lo + cps : Cin;
+    // gv[co][dy][j]: g at row h+dy-1, col w0+j-1 (0 outside the image)
+    float gv[CO][3][4];
+    const float *gp = g + (long)b * CO * HW;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int hh = h + dy - 1;
+        const float rmask = (hh >= 0 && hh < H) ? 1.f : 0.f;
+        const int ro = (hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh)) * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ww = w0 + j - 1;
+            const float m = (ww >= 0 && ww < W) ? rmask : 0.f;
+            const int off = ro + (ww < 0 ? 0 : (ww > W - 1 ? W - 1 : ww));
+#pragma unroll
+            for (int co = 0; co < CO; ++co) gv[co][dy][j] = gp[co * HW + off] * m;
+        }
+    }
+    float *dp = dx + ((long)b * Cin + c_lo) * HW + (long)h * W + w0;
+    const bool two = (W & 1) == 0;
+    for (int ci = c_lo; ci < c_hi; ++ci, dp += HW) {
+        const float *wc = wt + (long)ci * 9 * CO;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float wv = wc[(ky * 3 + kx) * CO + co];
+                    // pixel (h, w0 + p): g row h-ky+1 -> dy = 2-ky ; col w0+p-kx+1 -> j = p - kx + 2
+                    a0 = fmaf(wv, gv[co][2 - ky][2 - kx], a0);
+                    a1 = fmaf(wv, gv[co][2 - ky][3 - kx], a1);
+                }
+        if (two) {
+            *reinterpret_cast<float2 *>(dp) = make_float2(a0, a1);
+        } else {
+            dp[0] = a0;
+            if (w0 + 1 < W) dp[1] = a1;
+        }
+    }
+}
+
+// dW[co][ci][ky][kx] += sum_{b,y,x} g[b,co,y,x] * x[b,ci,y+ky-1,x+kx-1] ;  dbias[co] += sum g
+// grid (chunks of 64*gpl groups over B*H*ceil(W/4), ceil(Cin / 4)); block 256 = 4 waves = 4 input channels;
+// lane = group of 4 consecutive pixels of a row (the 3 x 6 input neighbourhood is shared by the 4 pixels:
+// 9 + 6 load instructions per 216 FMAs), CO*9 register accumulators, wave reduction + one atomic per weight.
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3s_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                                  float *__restrict__ dW, float *__restrict__ dbias,
+                                                                  int B, int Cin, int H, int W, int gpl) {
+    const int lane = threadIdx.x & 63;
+    const int ci = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ci >= Cin) return;
+    const int wq = (W + 3) / 4;
+    const long HW = (long)H * W, NG = (long)B * H * wq;
+    const long base = (long)blockIdx.x * 64 * gpl;
+    const bool vec = (W & 3) == 0;
+    float acc[CO][9], gs[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        gs[co] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[co][t] = 0.f;
+    }
+#pragma unroll 2
+    for (int it = 0; it < gpl; ++it) {
+        long gidx = base + (long)it * 64 + lane;
+        const float live = gidx < NG ? 1.f : 0.f;  // lanes past the end re-read the last group with weight 0
+        gidx = gidx < NG ? gidx : NG - 1;
+        const int q = (int)(gidx % wq);
+        const long r = gidx / wq;
+        const int h = (int)(r % H), b = (int)(r / H);
+        const int w0 = q * 4;
+        const float *xp = x + ((long)b * Cin + ci) * HW;
+        float xv[3][6];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hh = h + dy - 1;
+            const float rmask = (hh >= 0 && hh < H) ? 1.f : 0.f;
+            const float *rp = xp + (hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh)) * W;
+            if (vec) {
+                const float4 c = *reinterpret_cast<const float4 *>(rp + w0);
+                xv[dy][1] = c.x * rmask; xv[dy][2] = c.y * rmask; xv[dy][3] = c.z * rmask; xv[dy][4] = c.w * rmask;
+                xv[dy][0] = rp[w0 > 0 ? w0 - 1 : 0] * (w0 > 0 ? rmask : 0.f);
+                xv[dy][5] = rp[w0 + 4 < W ? w0 + 4 : W - 1] * (w0 + 4 < W ? rmask : 0.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int ww = w0 + j - 1;
+                    xv[dy][j] = rp[ww < 0 ? 0 : (ww > W - 1 ? W - 1 : ww)] * ((ww >= 0 && ww < W) ? rmask : 0.f);
+                }
+            }
+        }
+        const float *gp = g + (long)b * CO * HW + (long)h * W;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float gq[4];
+            if (vec) {
+                const float4 c = *reinterpret_cast<const float4 *>(gp + co * HW + w0);
+                gq[0] = c.x * live; gq[1] = c.y * live; gq[2] = c.z * live; gq[3] = c.w * live;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gq[j] = gp[co * HW + (w0 + j < W ? w0 + j : W - 1)] * (w0 + j < W ? live : 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gs[co] += gq[j];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[co][ky * 3 + kx] = fmaf(gq[j], xv[ky][j + kx], acc[co][ky * 3 + kx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float s = wave_sum(acc[co][t]);
+            if (lane == 0) atomicAdd(dW + ((long)co * Cin + ci) * 9 + t, s);
+        }
+        if (dbias != nullptr && ci == 0) {
+            const float s = wave_sum(gs[co]);
+            if (lane == 0) atomicAdd(dbias + co, s);
+        }
+    }
+}
+
+// how many input-channel slices so that the chip sees >= ~8192 waves (8 per SIMD: the channel loop is a
+// load -> FMA chain per iteration, latency hiding comes from other waves)
+int channel_splits(long threads, int cin) {
+    int s = 1;
+    while (threads * s < 524288 && cin / (s * 2) >= 4) s *= 2;
+    return s;
+}
+
+int check(const mmu_conv3x3s_params *p, const char *name) {
+    MMU_CHECK(p != nullptr, "%s: null params", name);
+    MMU_CHECK(p->batch > 0 && p->in_channels > 0 && p->height > 0 && p->width > 0, "%s: empty tensor", name);
+    MMU_CHECK(p->out_channels == 1 || p->out_channels == 2 || p->out_channels == 6 || p->out_channels == 8,
+              "%s: out_channels must be 1, 2, 6 or 8 (got %d)", name, p->out_channels);
+    MMU_CHECK((long)p->batch * p->in_channels * p->height * p->width < (1L << 40), "%s: tensor too large", name);
+    return 0;
+}
+
+#define CO_DISPATCH(co, ...)                                          \
+    switch (co) {                                                     \
+        case 1: { constexpr int CO = 1; __VA_ARGS__ } break;          \
+        case 2: { constexpr int CO = 2; __VA_ARGS__ } break;          \
+        case 6: { constexpr int CO = 6; __VA_ARGS__ } break;          \
+        default: { constexpr int CO = 8; __VA_ARGS__ } break;         \
+    }
+
+}  // namespace
+
+extern "C" int mmu_conv3x3_small_fwd_splits(int batch, int in_channels, int height, int width) {
+    return channel_splits((long)batch * height * ((width + 3) / 4), in_channels);
+}
+
+extern "C" int mmu_conv3x3_small_fwd(const mmu_conv3x3s_params *p, void *stream) {
+    if (int r = check(p, "conv3x3_small_fwd")) return r;
+    MMU_CHECK(p->input && p->weight_t && p->out, "conv3x3_small_fwd: input, weight_t, out are required");
+    const long total = (long)p->batch * p->height * ((p->width + 3) / 4);
+    const int splits = channel_splits(total, p->in_channels);
+    MMU_CHECK(splits == 1 || p->workspace != nullptr,
+              "conv3x3_small_fwd: workspace of mmu_conv3x3_small_fwd_splits() x out elements is required");
+    const int cps = (p->in_channels + splits - 1) / splits;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = splits == 1 ? p->out : p->workspace;
+    dim3 grid((unsigned)((total + 255) / 256), splits);
+    CO_DISPATCH(p->out_channels, conv3x3s_fwd_kernel<CO><<<grid, 256, 0, st>>>(
+                                     p->input, p->weight_t, p->bias, part, p->batch, p->in_channels, p->height,
+                                     p->width, cps);)
+    MMU_HIP_LAUNCH_CHECK("conv3x3_small_fwd");
+    if (splits > 1) {
+        const long n = (long)p->batch * p->out_channels * p->height * p->width;
+        conv3x3s_sum_splits_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, p->out, n, splits);
+        MMU_HIP_LAUNCH_CHECK("conv3x3_small_fwd(sum)");
+    }
+    return 0;
+}
+
+extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream) {
+    if (int r = check(p, "conv3x3_small_bwd")) return r;
+    MMU_CHECK(p->dout && p->weight_t, "conv3x3_small_bwd: dout and weight_t are required");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dinput) {
+        const long total = (long)p->batch * p->height * ((p->width + 1) / 2);
+        const int splits = channel_splits(total, p->in_channels);
+        const int cps = (p->in_channels + splits - 1) / splits;
+        dim3 grid((unsigned)((total + 255) / 256), splits);
+        CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO><<<grid, 256, 0, st>>>(
+                                         p->dout, p->weight_t, p->dinput, p->batch, p->in_channels, p->height,
+                                         p->width, cps);)
+        MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(data)");
+    }
+    if (p->dweight) {
+        MMU_CHECK(p->input, "conv3x3_small_bwd: input is required for dweight");
+        hipError_t e = hipMemsetAsync(p->dweight, 0, sizeof(float) * (size_t)p->out_channels * p->in_channels * 9, st);
+        if (e == hipSuccess && p->dbias) e = hipMemsetAsync(p->dbias, 0, sizeof(float) * p->out_channels, st);
+        if (e != hipSuccess) return mmu_fail("conv3x3_small_bwd: memset: %s", hipGetErrorString(e));
+        const long NG = (long)p->batch * p->height * ((p->width + 3) / 4);
+        // groups per lane: ~4096 waves in total (the 54-value wave reduction + atomics at the end of a wave
+        // cost as much as two iterations, so not more waves than the chip needs)
+        long gpl_ = NG * p->in_channels / 64 / 4096;
+        const int gpl = gpl_ < 2 ? 2 : (gpl_ > 32 ? 32 : (int)gpl_);
+        dim3 grid((unsigned)((NG + 64L * gpl - 1) / (64L * gpl)), (p->in_channels + 3) / 4);
+        CO_DISPATCH(p->out_channels, conv3x3s_bwd_weight_kernel<CO><<<grid, 256, 0, st>>>(
+                                         p->input, p->dout, p->dweight, p->dbias, p->batch, p->in_channels,
+                                         p->height, p->width, gpl);)
+        MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight)");
+    }
+    return 0;
+}

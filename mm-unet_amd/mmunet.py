@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba
-from . import morph_coords
+from . import conv3x3_small, morph_coords
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
 from .tall_gemm import dsc_gemm
@@ -136,8 +136,15 @@ class MMConv(nn.Module):
                                                m.D.float(), delta_bias=m.dt_proj.bias.float(), delta_softplus=True)
             return morph_coords.coords_outproj(offset, out_z, m.out_proj.weight, self.altho, self.extend_scope)
 
+    def _offset_conv(self, input):
+        c = self.offset_conv
+        if conv3x3_small.supported(input, c.weight) and c.stride == (1, 1) and c.padding == (1, 1) and \
+                c.dilation == (1, 1) and c.groups == 1:
+            return conv3x3_small.conv3x3_small(input, c.weight, c.bias)   # 6 output channels: direct kernels
+        return c(input)
+
     def forward(self, input):
-        offset = self.tanh(self.gn_offset(self.offset_conv(input)))
+        offset = self.tanh(self.gn_offset(self._offset_conv(input)))
         # Fused HIP sampler (morph_sample): the tap columns are the integers w + k - K//2, so only the
         # row coordinates are passed on.  get_interpolated_feature (grid_sample) stays as the
         # reference-shaped method and is what the fused op is tested against.

@@ -269,6 +269,36 @@ def test_bilinear_resize_vs_interpolate(case):
         close(bilinear_resize(x.to(DEV), scale_factor=2), ref, 1e-5, 1e-5, "scale_factor=2")
 
 
+@pytest.mark.parametrize("case", [(2, 16, 6, 32, 32), (1, 7, 6, 13, 10), (2, 5, 1, 9, 17), (1, 64, 8, 16, 16),
+                                  (3, 3, 2, 1, 5), (1, 12, 6, 64, 128)])
+@pytest.mark.parametrize("native_wgrad", [False, True])
+def test_conv3x3_small_vs_conv2d(case, native_wgrad, monkeypatch):
+    """conv3x3_small == F.conv2d(x, w, b, padding=1) evaluated on CPU: output and all three gradients
+    (MMConv.offset_conv, MMUNet.py:46,250), including odd widths and single-row images."""
+    import torch.nn.functional as F
+    import mm_unet_amd.conv3x3_small as c3
+    from mm_unet_amd.conv3x3_small import conv3x3_small
+    monkeypatch.setattr(c3, "WEIGHT_GRAD_NATIVE", native_wgrad)
+    B, Cin, CO, H, W = case
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(CO, Cin, 3, 3, generator=gen) * 0.2
+    b = torch.randn(CO, generator=gen)
+    g = torch.randn(B, CO, H, W, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, br, padding=1)
+    ref.backward(g)
+    xg, wg, bg = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    out = conv3x3_small(xg, wg, bg)
+    out.backward(g.to(DEV))
+    close(out, ref, 1e-4, 1e-4, "out")
+    close(xg.grad, xr.grad, 1e-4, 1e-4, "d input")
+    close(wg.grad, wr.grad, 1e-4, 1e-3, "d weight")
+    close(bg.grad, br.grad, 1e-4, 1e-3, "d bias")
+    # no bias
+    close(conv3x3_small(x.to(DEV), w.to(DEV)), F.conv2d(x, w, None, padding=1), 1e-4, 1e-4, "no bias")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
