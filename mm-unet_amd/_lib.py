@@ -80,6 +80,10 @@ class Conv3x3sParams(ctypes.Structure):
                                       "workspace")])
 
 
+class TriParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("rows", "seqlen", "nslices")] + [(n, _vp) for n in ("a", "flip", "slice", "out")])
+
+
 class CoordsParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
@@ -94,7 +98,7 @@ EXPORTS = (
     "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
-    "mmu_debug_wave_scan",
+    "mmu_tri_split", "mmu_tri_combine", "mmu_debug_wave_scan",
 )
 
 _lib = None
@@ -126,7 +130,8 @@ def lib():
                      ("mmu_zigzag_inproj_fwd", CoordsParams), ("mmu_zigzag_inproj_bwd", CoordsParams),
                      ("mmu_coords_outproj_fwd", CoordsParams), ("mmu_coords_outproj_bwd", CoordsParams),
                      ("mmu_bilinear_resize_fwd", ResizeParams), ("mmu_bilinear_resize_bwd", ResizeParams),
-                     ("mmu_conv3x3_small_fwd", Conv3x3sParams), ("mmu_conv3x3_small_bwd", Conv3x3sParams)):
+                     ("mmu_conv3x3_small_fwd", Conv3x3sParams), ("mmu_conv3x3_small_bwd", Conv3x3sParams),
+                     ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]

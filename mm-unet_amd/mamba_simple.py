@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from .causal_conv1d_interface import causal_conv1d_fn
 from .selective_scan_interface import _dbl_view, mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn
+from . import tri_order
 from .tall_gemm import proj_tokens
 
 
@@ -98,6 +99,9 @@ class Mamba(nn.Module):
         self.dt_proj_s = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
         self.D_s = skip()
         self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
+        # v3 returns (out, o_1, o_2, o_3) like the reference; a caller that drops the three branch outputs
+        # (RCG, MMUNet.py:409) can switch them off and save the re-ordering copy of o_3
+        self.return_branch_outputs = True
 
     def _branch(self, xz, suffix):
         g = lambda n: getattr(self, n + suffix)  # noqa: E731
@@ -130,16 +134,26 @@ class Mamba(nn.Module):
             if self.bimamba_type == "v3":
                 if seqlen % self.nslices != 0:
                     raise RuntimeError(f"Mamba v3: seqlen {seqlen} must be divisible by nslices {self.nslices}")
-                out = self._branch(xz, "")
-                out_b = self._branch(xz.flip([-1]), "_b")
-                # token i of slice s -> position i*nslices + s   (mamba_simple.py:245-247)
                 ns = self.nslices
-                xz_s = xz.reshape(batch, 2 * self.d_inner, ns, seqlen // ns).transpose(-1, -2) \
-                    .reshape(batch, 2 * self.d_inner, seqlen)
-                out_s = self._branch(xz_s, "_s")
-                out_s = out_s.reshape(batch, self.d_inner, seqlen // ns, ns).permute(0, 1, 3, 2).flatten(-2)
-                o_1, o_2, o_3 = out, out_b, out_s
-                out = self._out_proj(out + out_b.flip([-1]) + out_s)
+                fused = tri_order.supported(xz)
+                if fused:   # flip + slice-interleave in one pass; the three input gradients meet in one kernel
+                    xz_a, xz_f, xz_s = tri_order.tri_split(xz, ns)
+                else:
+                    xz_a, xz_f = xz, xz.flip([-1])
+                    # token i of slice s -> position i*nslices + s   (mamba_simple.py:245-247)
+                    xz_s = xz.reshape(batch, 2 * self.d_inner, ns, seqlen // ns).transpose(-1, -2) \
+                        .reshape(batch, 2 * self.d_inner, seqlen)
+                out = self._branch(xz_a, "")
+                out_b = self._branch(xz_f, "_b")
+                out_sp = self._branch(xz_s, "_s")          # still in slice-interleaved order
+                unslice = lambda t: t.reshape(batch, self.d_inner, seqlen // ns, ns).permute(0, 1, 3, 2).flatten(-2)  # noqa: E731
+                if self.return_branch_outputs:             # (out, o_1, o_2, o_3) of mamba_simple.py:267-270,362
+                    o_1, o_2, o_3 = out, out_b, unslice(out_sp)
+                if fused and tri_order.supported(out, out_b, out_sp):
+                    total = tri_order.tri_combine(out, out_b, out_sp, ns)
+                else:
+                    total = out + out_b.flip([-1]) + (o_3 if o_3 is not None else unslice(out_sp))
+                out = self._out_proj(total)
             elif self.bimamba_type == "v2":
                 out = self._branch(xz, "")
                 out_b = self._branch(xz.flip([-1]), "_b")

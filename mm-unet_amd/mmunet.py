@@ -243,6 +243,7 @@ class RCG(nn.Module):
         self.downsample = nn.Conv2d(64, 64, kernel_size=4, stride=2, padding=1)
         self.mamba = Mamba(d_model=64, d_state=d_state, d_conv=d_conv, expand=expand, bimamba_type="v3",
                            nslices=num_slices)
+        self.mamba.return_branch_outputs = False   # forward() below keeps only the block output (MMUNet.py:409)
         self.mlp = nn.Sequential(nn.Conv2d(64, 1, kernel_size=1), nn.Sigmoid())
 
     def forward(self, pre, edge, f):

@@ -299,6 +299,38 @@ def test_conv3x3_small_vs_conv2d(case, native_wgrad, monkeypatch):
     close(conv3x3_small(x.to(DEV), w.to(DEV)), F.conv2d(x, w, None, padding=1), 1e-4, 1e-4, "no bias")
 
 
+@pytest.mark.parametrize("case", [(2, 6, 64, 4, "cb"), (1, 3, 96, 8, "bc"), (2, 4, 4096, 4, "cb"), (1, 2, 60, 3, "bc"),
+                                  (2, 3, 4096, 64, "cb"), (1, 5, 16 * 70, 16, "bc"), (1, 2, 32 * 130, 32, "cb"),
+                                  (1, 2, 130 * 65, 65, "bc")])
+def test_tri_order_split_combine(case):
+    """tri_split / tri_combine == the tensor ops of mamba_simple.py:212-270 (flip, slice interleave, their
+    inverses and the three-way sum), values and gradients, in both dense row layouts."""
+    from mm_unet_amd import tri_order
+    B, C, L, ns, layout = case
+    gen = torch.Generator().manual_seed(31)
+    mk = (lambda: torch.randn(C, B, L, generator=gen).to(DEV).permute(1, 0, 2)) if layout == "cb" else \
+        (lambda: torch.randn(B, C, L, generator=gen).to(DEV))
+    slice_ = lambda t: t.reshape(B, C, ns, L // ns).transpose(-1, -2).reshape(B, C, L)      # noqa: E731
+    unslice = lambda t: t.reshape(B, C, L // ns, ns).permute(0, 1, 3, 2).flatten(-2)        # noqa: E731
+    x = mk()
+    assert tri_order.supported(x)
+    xr = x.clone().requires_grad_()
+    xa, xf, xs = tri_order.tri_split(xr, ns)
+    close(xf, x.flip([-1]), 0, 0, "flip")
+    close(xs, slice_(x), 0, 0, "slice")
+    ga, gf, gs = mk(), mk(), mk()
+    (xa * ga + xf * gf + xs * gs).sum().backward()
+    close(xr.grad, ga + gf.flip([-1]) + unslice(gs), 1e-6, 1e-6, "split backward")
+    a, b, c = (mk().requires_grad_() for _ in range(3))
+    out = tri_order.tri_combine(a, b, c, ns)
+    close(out, a + b.flip([-1]) + unslice(c), 1e-6, 1e-6, "combine")
+    g = mk()
+    out.backward(g)
+    close(a.grad, g, 0, 0, "d a")
+    close(b.grad, g.flip([-1]), 0, 0, "d b")
+    close(c.grad, slice_(g), 0, 0, "d c")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
