@@ -245,6 +245,38 @@ typedef struct {
 int mmu_tri_split(const mmu_tri_params *p, void *stream);
 int mmu_tri_combine(const mmu_tri_params *p, void *stream);
 
+/* ---- GroupNorm [-> BatchNorm2d] [-> ReLU | tanh] as one normalisation (a9/a11 blocks) ------------------ */
+/* nn.GroupNorm(groups, C) optionally followed by nn.BatchNorm2d(C) (training or eval statistics) and an
+ * activation (src/UM_Net/MMUNet.py:250,265 + :344-349,357-359,424-430,436-452), contiguous float32 NCHW.
+ * Both normalisations are affine in x per (batch, channel) once the statistics are known, and the statistics
+ * follow from the per-(batch, channel) moments of x: two passes forward, two backward.
+ * Buffers the caller owns: s1, s2, scale, shift [batch*channels]; mu, rstd [batch*groups]; bn_mean, bn_rstd
+ * [channels]; all written by fwd and read by bwd.  workspace (bwd): mmu_norm_fused_workspace_floats() floats. */
+#define MMU_ACT_NONE 0
+#define MMU_ACT_RELU 1
+#define MMU_ACT_TANH 2
+typedef struct {
+    int32_t batch, channels, groups, hw, has_bn, training, act;
+    float gn_eps, bn_eps, momentum;
+    const float *input;       /* [batch, channels, hw] */
+    const float *gn_weight;   /* [channels] or NULL */
+    const float *gn_bias;     /* [channels] or NULL */
+    const float *bn_weight;   /* [channels] or NULL */
+    const float *bn_bias;     /* [channels] or NULL */
+    float *running_mean;      /* [channels]: updated in training mode (may be NULL), used in eval mode */
+    float *running_var;
+    float *out;               /* fwd */
+    float *s1, *s2, *mu, *rstd, *bn_mean, *bn_rstd, *scale, *shift;   /* saved statistics */
+    const float *dout;        /* bwd */
+    float *dinput;            /* bwd */
+    float *dgn_weight, *dgn_bias, *dbn_weight, *dbn_bias;             /* bwd, each optional */
+    float *workspace;         /* bwd */
+} mmu_norm_params;
+
+size_t mmu_norm_fused_workspace_floats(int batch, int channels, int groups);
+int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream);
+int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream);
+
 /* ---- MMConv glue around its K-channel Mamba, fused ----------------- */
 /* Replaces ~30 tiny PyTorch kernels per MMConv block and direction (src/UM_Net/MMUNet.py:122-193 +
  * requirements/mamba_simple.py:201-205,365): zig-zag token flatten + in_proj (A), and out_proj + inverse

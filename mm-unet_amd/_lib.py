@@ -84,6 +84,15 @@ class TriParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("rows", "seqlen", "nslices")] + [(n, _vp) for n in ("a", "flip", "slice", "out")])
 
 
+class NormParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "channels", "groups", "hw", "has_bn", "training", "act")]
+                + [(n, ctypes.c_float) for n in ("gn_eps", "bn_eps", "momentum")]
+                + [(n, _vp) for n in ("input", "gn_weight", "gn_bias", "bn_weight", "bn_bias", "running_mean",
+                                      "running_var", "out", "s1", "s2", "mu", "rstd", "bn_mean", "bn_rstd", "scale",
+                                      "shift", "dout", "dinput", "dgn_weight", "dgn_bias", "dbn_weight", "dbn_bias",
+                                      "workspace")])
+
+
 class CoordsParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
@@ -98,7 +107,8 @@ EXPORTS = (
     "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
-    "mmu_tri_split", "mmu_tri_combine", "mmu_debug_wave_scan",
+    "mmu_tri_split", "mmu_tri_combine", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
+    "mmu_debug_wave_scan",
 )
 
 _lib = None
@@ -131,12 +141,15 @@ def lib():
                      ("mmu_coords_outproj_fwd", CoordsParams), ("mmu_coords_outproj_bwd", CoordsParams),
                      ("mmu_bilinear_resize_fwd", ResizeParams), ("mmu_bilinear_resize_bwd", ResizeParams),
                      ("mmu_conv3x3_small_fwd", Conv3x3sParams), ("mmu_conv3x3_small_bwd", Conv3x3sParams),
-                     ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams)):
+                     ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
+                     ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
     L.mmu_conv3x3_small_fwd_splits.restype = ctypes.c_int
     L.mmu_conv3x3_small_fwd_splits.argtypes = [ctypes.c_int] * 4
+    L.mmu_norm_fused_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_norm_fused_workspace_floats.argtypes = [ctypes.c_int] * 3
     L.mmu_debug_wave_scan.restype = ctypes.c_int
     L.mmu_debug_wave_scan.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]
     _lib = L

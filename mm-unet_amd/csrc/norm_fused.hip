@@ -1,0 +1,387 @@
+// norm_fused.hip -- GroupNorm [-> BatchNorm2d] [-> ReLU | tanh] as ONE normalisation, for gfx950.
+//
+// Every MMConv ends in GroupNorm (MMUNet.py:265 `self.gn`) and is followed, in the blocks that use it, by
+// BatchNorm2d and usually ReLU (MMUNet.py:344-349, 357-359, 424-430, 436-452); its offset branch is
+// GroupNorm -> tanh (:250).  As separate ATen/MIOpen ops that is 8 passes over the activation forward and
+// 13 backward (GN, BN and ReLU each re-read and re-write it; 8 ms per training step).  Both normalisations
+// are affine in x once the statistics are known, and both statistics follow from the per-(batch, channel)
+// moments  s1 = sum_hw x,  s2 = sum_hw x^2 :
+//     GroupNorm      y1 = a_bc x + d_bc        a = gamma_g r_bg,  d = beta_g - a mu_bg     (mu, r from s1, s2)
+//     BatchNorm      y2 = A_bc x + D_bc        mean_c(y1), E_c(y1^2) in closed form from a, d, s1, s2
+//     out = act(y2)
+// so the forward is one moments pass + one apply pass, and the backward -- which needs only
+// t1 = sum_hw g2, t2 = sum_hw g2 x  (g2 = dout * act'(y2)) per (batch, channel) -- one pass for those and one
+// for  dx = c0_bc g2 + c1_bc x + c2_bc  (derivation in norm_fused.py).  The per-(b, c) algebra runs in a
+// single small workgroup in double precision.
+#include "mmu_common.h"
+#include "../../include/mmunet_amd.h"
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+__device__ __forceinline__ float act_fwd(float y, int act) {
+    if (act == ACT_RELU) return fmaxf(y, 0.f);
+    if (act == ACT_TANH) {
+        const float e = __builtin_amdgcn_exp2f(-2.f * MMU_LOG2E * fabsf(y));  // e^{-2|y|}
+        const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+        return y < 0.f ? -t : t;
+    }
+    return y;
+}
+// d act / d y expressed through y (pre-activation)
+__device__ __forceinline__ float act_grad(float y, int act) {
+    if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == ACT_TANH) {
+        const float t = act_fwd(y, ACT_TANH);
+        return 1.f - t * t;
+    }
+    return 1.f;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// moments per (b, c): grid (B*C), block 256.  BWD: t1 = sum g2, t2 = sum g2 x with g2 = dout * act'(A x + D)
+template <bool BWD>
+__global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict__ x, const float *__restrict__ dout,
+                                                         const float *__restrict__ A, const float *__restrict__ D,
+                                                         float *__restrict__ m1, float *__restrict__ m2, int HW,
+                                                         int act) {
+    __shared__ float red[8];
+    const long base = (long)blockIdx.x * HW;
+    const float Av = BWD ? A[blockIdx.x] : 0.f, Dv = BWD ? D[blockIdx.x] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0) {
+        const float4 *xp = reinterpret_cast<const float4 *>(x + base);
+        const float4 *gp = BWD ? reinterpret_cast<const float4 *>(dout + base) : nullptr;
+        for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+            const float4 v = xp[i];
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            if (BWD) {
+                const float4 g = gp[i];
+                const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g2 = gv[j] * act_grad(fmaf(Av, xv[j], Dv), act);
+                    s1 += g2;
+                    s2 = fmaf(g2, xv[j], s2);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s1 += xv[j];
+                    s2 = fmaf(xv[j], xv[j], s2);
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const float xv = x[base + i];
+            if (BWD) {
+                const float g2 = dout[base + i] * act_grad(fmaf(Av, xv, Dv), act);
+                s1 += g2;
+                s2 = fmaf(g2, xv, s2);
+            } else {
+                s1 += xv;
+                s2 = fmaf(xv, xv, s2);
+            }
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        m1[blockIdx.x] = s1;
+        m2[blockIdx.x] = s2;
+    }
+}
+
+struct FinArgs {
+    int B, C, G, HW, has_bn, training;
+    float eps_g, eps_b, momentum;
+    const float *s1, *s2;          // [B*C] moments of x
+    const float *gn_w, *gn_b;      // [C] or NULL (1 / 0)
+    const float *bn_w, *bn_b;      // [C] or NULL
+    float *run_mean, *run_var;     // [C] (updated when training) or NULL
+    float *mu, *rstd;              // [B*G] GroupNorm statistics (saved)
+    float *bmean, *brstd;          // [C] BatchNorm statistics used (saved)
+    float *A, *D;                  // [B*C] out = act(A x + D)
+    // backward
+    const float *t1, *t2;          // [B*C]
+    float *c0, *c1, *c2;           // [B*C] dx = c0 g2 + c1 x + c2
+    float *dgn_w, *dgn_b, *dbn_w, *dbn_b;  // [C] parameter gradients (may be NULL)
+    float *scratch;                // [2*B*C + 2*B*G + 3*C] floats of workspace for the backward algebra
+};
+
+// one workgroup; all per-(b,c) algebra in double
+__global__ __launch_bounds__(256) void nf_finalize_fwd_kernel(FinArgs p) {
+    const int cpg = p.C / p.G;
+    const double n = (double)cpg * p.HW, N = (double)p.B * p.HW;
+    for (int bg = threadIdx.x; bg < p.B * p.G; bg += blockDim.x) {
+        const int b = bg / p.G, g = bg - b * p.G;
+        double a1 = 0, a2 = 0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            a1 += p.s1[b * p.C + c];
+            a2 += p.s2[b * p.C + c];
+        }
+        const double mu = a1 / n;
+        double var = a2 / n - mu * mu;
+        var = var < 0 ? 0 : var;
+        p.mu[bg] = (float)mu;
+        p.rstd[bg] = (float)(1.0 / sqrt(var + (double)p.eps_g));
+    }
+    __syncthreads();
+    if (p.has_bn) {
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            double m, rb;
+            if (p.training) {
+                const int g = c / cpg;
+                const double gw = p.gn_w ? p.gn_w[c] : 1.0, gb = p.gn_b ? p.gn_b[c] : 0.0;
+                double sm = 0, sq = 0;
+                for (int b = 0; b < p.B; ++b) {
+                    const double a = gw * p.rstd[b * p.G + g], d = gb - a * p.mu[b * p.G + g];
+                    const double s1 = p.s1[b * p.C + c], s2 = p.s2[b * p.C + c];
+                    sm += a * s1 + d * p.HW;
+                    sq += a * a * s2 + 2 * a * d * s1 + d * d * p.HW;
+                }
+                m = sm / N;
+                double v = sq / N - m * m;
+                v = v < 0 ? 0 : v;
+                rb = 1.0 / sqrt(v + (double)p.eps_b);
+                if (p.run_mean) {
+                    p.run_mean[c] = (float)((1.0 - p.momentum) * p.run_mean[c] + p.momentum * m);
+                    p.run_var[c] = (float)((1.0 - p.momentum) * p.run_var[c] + p.momentum * v * (N > 1 ? N / (N - 1) : 1.0));
+                }
+            } else {
+                m = p.run_mean[c];
+                rb = 1.0 / sqrt((double)p.run_var[c] + (double)p.eps_b);
+            }
+            p.bmean[c] = (float)m;
+            p.brstd[c] = (float)rb;
+        }
+    }
+    __syncthreads();
+    for (int bc = threadIdx.x; bc < p.B * p.C; bc += blockDim.x) {
+        const int b = bc / p.C, c = bc - b * p.C, g = c / cpg;
+        const double gw = p.gn_w ? p.gn_w[c] : 1.0, gb = p.gn_b ? p.gn_b[c] : 0.0;
+        double a = gw * p.rstd[b * p.G + g], d = gb - a * p.mu[b * p.G + g];
+        if (p.has_bn) {
+            const double k = (p.bn_w ? p.bn_w[c] : 1.0) * p.brstd[c];
+            d = (d - p.bmean[c]) * k + (p.bn_b ? p.bn_b[c] : 0.0);
+            a = a * k;
+        }
+        p.A[bc] = (float)a;
+        p.D[bc] = (float)d;
+    }
+}
+
+__global__ __launch_bounds__(256) void nf_finalize_bwd_kernel(FinArgs p) {
+    const int cpg = p.C / p.G;
+    const double n = (double)cpg * p.HW, N = (double)p.B * p.HW, HW = p.HW;
+    // workspace: mexact[C] (double) | u1[B*C] u2[B*C] M1[B*G] M2[B*G] kk[C] ee[C] ff[C]
+    // mexact: the batch mean of y1 recomputed in double from the moments.  The float copy saved by the forward
+    // is good enough for the output, but here sum_b (p s1 + q HW) must cancel to zero (BatchNorm removes any
+    // per-channel shift, so d(gn bias) is analytically 0); with the rounded mean it leaves 1e-5 of noise.
+    double *mexact = reinterpret_cast<double *>(p.scratch);
+    float *u1 = p.scratch + 2 * p.C, *u2 = u1 + p.B * p.C, *M1 = u2 + p.B * p.C, *M2 = M1 + p.B * p.G;
+    float *kk = M2 + p.B * p.G, *ee = kk + p.C, *ff = ee + p.C;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        double k = 1, e = 0, f = 0;
+        if (p.has_bn) {
+            const int g = c / cpg;
+            const double gw = p.gn_w ? p.gn_w[c] : 1.0, gb = p.gn_b ? p.gn_b[c] : 0.0;
+            const double rb = p.brstd[c];
+            double m = p.bmean[c];
+            if (p.training) {
+                double sm = 0;
+                for (int b = 0; b < p.B; ++b) {
+                    const double a = gw * p.rstd[b * p.G + g], d = gb - a * p.mu[b * p.G + g];
+                    sm += a * p.s1[b * p.C + c] + d * p.HW;
+                }
+                m = sm / N;
+            }
+            mexact[c] = m;
+            double db = 0, dg = 0;
+            for (int b = 0; b < p.B; ++b) {
+                const double a = gw * p.rstd[b * p.G + g], d = gb - a * p.mu[b * p.G + g];
+                const double pq = a * rb, qq = (d - m) * rb;
+                db += p.t1[b * p.C + c];
+                dg += pq * p.t2[b * p.C + c] + qq * p.t1[b * p.C + c];
+            }
+            if (p.dbn_w) p.dbn_w[c] = (float)dg;
+            if (p.dbn_b) p.dbn_b[c] = (float)db;
+            k = (p.bn_w ? p.bn_w[c] : 1.0) * rb;
+            if (p.training) {
+                e = db / N;
+                f = dg / N;
+            }
+        }
+        kk[c] = (float)k;
+        ee[c] = (float)e;
+        ff[c] = (float)f;
+    }
+    __syncthreads();
+    for (int bc = threadIdx.x; bc < p.B * p.C; bc += blockDim.x) {
+        const int b = bc / p.C, c = bc - b * p.C, g = c / cpg;
+        const double gw = p.gn_w ? p.gn_w[c] : 1.0, gb = p.gn_b ? p.gn_b[c] : 0.0;
+        const double a = gw * p.rstd[b * p.G + g], d = gb - a * p.mu[b * p.G + g];
+        double pq = 0, qq = 0;
+        if (p.has_bn) {
+            pq = a * p.brstd[c];
+            qq = (d - mexact[c]) * p.brstd[c];
+        }
+        const double s1 = p.s1[bc], s2 = p.s2[bc], t1 = p.t1[bc], t2 = p.t2[bc];
+        const double k = kk[c], e = ee[c], f = ff[c];
+        u1[bc] = (float)(k * (t1 - e * HW - f * (pq * s1 + qq * HW)));
+        u2[bc] = (float)(k * (t2 - e * s1 - f * (pq * s2 + qq * s1)));
+    }
+    __syncthreads();
+    for (int bg = threadIdx.x; bg < p.B * p.G; bg += blockDim.x) {
+        const int b = bg / p.G, g = bg - b * p.G;
+        const double mu = p.mu[bg], r = p.rstd[bg];
+        double a1 = 0, a2 = 0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const double gw = p.gn_w ? p.gn_w[c] : 1.0;
+            a1 += gw * u1[b * p.C + c];
+            a2 += gw * r * (u2[b * p.C + c] - mu * u1[b * p.C + c]);
+        }
+        M1[bg] = (float)(a1 / n);
+        M2[bg] = (float)(a2 / n);
+    }
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        const int g = c / cpg;
+        double dw = 0, dbv = 0;
+        for (int b = 0; b < p.B; ++b) {
+            const double mu = p.mu[b * p.G + g], r = p.rstd[b * p.G + g];
+            dw += r * (u2[b * p.C + c] - mu * u1[b * p.C + c]);
+            dbv += u1[b * p.C + c];
+        }
+        if (p.dgn_w) p.dgn_w[c] = (float)dw;
+        if (p.dgn_b) p.dgn_b[c] = (float)dbv;
+    }
+    __syncthreads();
+    for (int bc = threadIdx.x; bc < p.B * p.C; bc += blockDim.x) {
+        const int b = bc / p.C, c = bc - b * p.C, g = c / cpg;
+        const double gw = p.gn_w ? p.gn_w[c] : 1.0, gb = p.gn_b ? p.gn_b[c] : 0.0;
+        const double mu = p.mu[b * p.G + g], r = p.rstd[b * p.G + g];
+        const double a = gw * r, d = gb - a * mu;
+        double pq = 0, qq = 0;
+        if (p.has_bn) {
+            pq = a * p.brstd[c];
+            qq = (d - mexact[c]) * p.brstd[c];
+        }
+        const double k = kk[c], e = ee[c], f = ff[c];
+        const double m1 = M1[b * p.G + g], m2 = M2[b * p.G + g];
+        const double rgk = r * gw * k;
+        p.c0[bc] = (float)rgk;
+        p.c1[bc] = (float)(-rgk * f * pq - r * r * m2);
+        p.c2[bc] = (float)(-rgk * e - rgk * f * qq - r * m1 + r * r * mu * m2);
+    }
+}
+
+// out = act(A x + D)  |  dx = c0 * dout * act'(A x + D) + c1 x + c2 ;  grid (ceil(HW/1024), B*C), block 256
+template <bool BWD>
+__global__ __launch_bounds__(256) void nf_apply_kernel(const float *__restrict__ x, const float *__restrict__ dout,
+                                                       const float *__restrict__ A, const float *__restrict__ D,
+                                                       const float *__restrict__ c0, const float *__restrict__ c1,
+                                                       const float *__restrict__ c2, float *__restrict__ out, int HW,
+                                                       int act) {
+    const int bc = blockIdx.y;
+    const float Av = A[bc], Dv = D[bc];
+    const float k0 = BWD ? c0[bc] : 0.f, k1 = BWD ? c1[bc] : 0.f, k2 = BWD ? c2[bc] : 0.f;
+    const long base = (long)bc * HW;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= HW) return;
+    if ((HW & 3) == 0) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+        if (BWD) {
+            const float4 g = *reinterpret_cast<const float4 *>(dout + base + i);
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(k0 * gv[j], act_grad(fmaf(Av, xv[j], Dv), act), fmaf(k1, xv[j], k2));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xv[j], Dv), act);
+        }
+        *reinterpret_cast<float4 *>(out + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int j = 0; j < 4 && i + j < HW; ++j) {
+            const float xv = x[base + i + j];
+            out[base + i + j] = BWD ? fmaf(k0 * dout[base + i + j], act_grad(fmaf(Av, xv, Dv), act), fmaf(k1, xv, k2))
+                                    : act_fwd(fmaf(Av, xv, Dv), act);
+        }
+    }
+}
+
+int fill(const mmu_norm_params *p, FinArgs &a, const char *name) {
+    MMU_CHECK(p != nullptr, "%s: null params", name);
+    MMU_CHECK(p->batch > 0 && p->channels > 0 && p->hw > 0 && p->groups > 0 && p->channels % p->groups == 0,
+              "%s: need batch, channels, hw > 0 and channels divisible by groups", name);
+    MMU_CHECK(p->act >= 0 && p->act <= 2, "%s: unknown activation %d", name, p->act);
+    MMU_CHECK((long)p->batch * p->channels < 65536, "%s: batch * channels must be < 65536", name);
+    a = FinArgs{};
+    a.B = p->batch; a.C = p->channels; a.G = p->groups; a.HW = p->hw; a.has_bn = p->has_bn; a.training = p->training;
+    a.eps_g = p->gn_eps; a.eps_b = p->bn_eps; a.momentum = p->momentum;
+    a.s1 = p->s1; a.s2 = p->s2; a.gn_w = p->gn_weight; a.gn_b = p->gn_bias; a.bn_w = p->bn_weight; a.bn_b = p->bn_bias;
+    a.run_mean = p->running_mean; a.run_var = p->running_var; a.mu = p->mu; a.rstd = p->rstd;
+    a.bmean = p->bn_mean; a.brstd = p->bn_rstd; a.A = p->scale; a.D = p->shift;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
+    FinArgs a;
+    if (int r = fill(p, a, "norm_fused_fwd")) return r;
+    MMU_CHECK(p->input && p->out && p->s1 && p->s2 && p->mu && p->rstd && p->scale && p->shift,
+              "norm_fused_fwd: input, out, s1, s2, mu, rstd, scale, shift are required");
+    MMU_CHECK(!p->has_bn || (p->bn_mean && p->bn_rstd), "norm_fused_fwd: bn_mean / bn_rstd buffers are required");
+    MMU_CHECK(!p->has_bn || p->training || (p->running_mean && p->running_var),
+              "norm_fused_fwd: eval-mode BatchNorm needs running statistics");
+    hipStream_t st = (hipStream_t)stream;
+    const int BC = a.B * a.C;
+    nf_moments_kernel<false><<<BC, 256, 0, st>>>(p->input, nullptr, nullptr, nullptr, p->s1, p->s2, a.HW, 0);
+    nf_finalize_fwd_kernel<<<1, 256, 0, st>>>(a);
+    dim3 grid((a.HW + 1023) / 1024, BC);
+    nf_apply_kernel<false><<<grid, 256, 0, st>>>(p->input, nullptr, a.A, a.D, nullptr, nullptr, nullptr, p->out, a.HW,
+                                                  p->act);
+    MMU_HIP_LAUNCH_CHECK("norm_fused_fwd");
+    return 0;
+}
+
+extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
+    FinArgs a;
+    if (int r = fill(p, a, "norm_fused_bwd")) return r;
+    MMU_CHECK(p->input && p->dout && p->dinput && p->s1 && p->s2 && p->mu && p->rstd && p->scale && p->shift &&
+                  p->workspace,
+              "norm_fused_bwd: input, dout, dinput, saved statistics and workspace are required");
+    hipStream_t st = (hipStream_t)stream;
+    const int BC = a.B * a.C;
+    // workspace: t1[BC] t2[BC] c0[BC] c1[BC] c2[BC] (+1 float if needed for 8-byte alignment) | scratch
+    float *ws = p->workspace;
+    float *t1 = ws, *t2 = ws + BC;
+    a.t1 = t1; a.t2 = t2; a.c0 = ws + 2 * BC; a.c1 = ws + 3 * BC; a.c2 = ws + 4 * BC;
+    a.scratch = ws + 5 * BC;
+    if ((uintptr_t)a.scratch & 7) a.scratch += 1;  // the first entry of the scratch area is a double array
+    a.dgn_w = p->dgn_weight; a.dgn_b = p->dgn_bias; a.dbn_w = p->dbn_weight; a.dbn_b = p->dbn_bias;
+    nf_moments_kernel<true><<<BC, 256, 0, st>>>(p->input, p->dout, a.A, a.D, t1, t2, a.HW, p->act);
+    nf_finalize_bwd_kernel<<<1, 256, 0, st>>>(a);
+    dim3 grid((a.HW + 1023) / 1024, BC);
+    nf_apply_kernel<true><<<grid, 256, 0, st>>>(p->input, p->dout, a.A, a.D, a.c0, a.c1, a.c2, p->dinput, a.HW, p->act);
+    MMU_HIP_LAUNCH_CHECK("norm_fused_bwd");
+    return 0;
+}
+
+extern "C" size_t mmu_norm_fused_workspace_floats(int batch, int channels, int groups) {
+    return (size_t)7 * batch * channels + (size_t)2 * batch * groups + (size_t)5 * channels + 2;
+}

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba
-from . import conv3x3_small, morph_coords
+from . import conv3x3_small, morph_coords, norm_fused
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
 from .tall_gemm import dsc_gemm
@@ -144,7 +144,20 @@ class MMConv(nn.Module):
         return c(input)
 
     def forward(self, input):
-        offset = self.tanh(self.gn_offset(self._offset_conv(input)))
+        """GroupNorm(K x 1 DSC conv(deformable samples)) -- MMUNet.py:244-265."""
+        pre = self.forward_pre_gn(input)
+        if norm_fused.supported(pre, self.gn):
+            return norm_fused.gn_bn_act(pre, self.gn)
+        return self.gn(pre)
+
+    def forward_pre_gn(self, input):
+        """Everything of forward() before the final GroupNorm (run_fused joins that GroupNorm with the
+        BatchNorm2d / ReLU that follow the block in its nn.Sequential)."""
+        raw = self._offset_conv(input)
+        if norm_fused.supported(raw, self.gn_offset):
+            offset = norm_fused.gn_bn_act(raw, self.gn_offset, None, "tanh")   # GroupNorm -> tanh in 2 passes
+        else:
+            offset = self.tanh(self.gn_offset(raw))
         # Fused HIP sampler (morph_sample): the tap columns are the integers w + k - K//2, so only the
         # row coordinates are passed on.  get_interpolated_feature (grid_sample) stays as the
         # reference-shaped method and is what the fused op is tested against.
@@ -166,7 +179,31 @@ class MMConv(nn.Module):
                 output = output + conv.bias.view(1, -1, 1, 1)
         else:
             output = self.dsc_conv_y(morph_sample(input, y_rows))
-        return self.gn(output)
+        return output
+
+
+def run_fused(seq, x):
+    """``seq(x)`` for an nn.Sequential, with every ``MMConv -> BatchNorm2d [-> ReLU]`` run as the MMConv up
+    to its final GroupNorm followed by ONE fused GroupNorm + BatchNorm + ReLU (norm_fused): 2 passes over the
+    activation instead of 8 forward, 2 instead of 13 backward.  Module structure / state_dict are untouched."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, MMConv) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+            pre = m.forward_pre_gn(x)
+            bn = mods[i + 1]
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            if norm_fused.supported(pre, m.gn, bn):
+                x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if relu else None)
+                i += 3 if relu else 2
+                continue
+            x = m.gn(pre)
+            i += 1
+            continue
+        x = m(x)
+        i += 1
+    return x
 
 
 class HPPF(nn.Module):
@@ -231,7 +268,7 @@ class SideoutBlock(nn.Module):
         self.conv2 = nn.Conv2d(in_channels // 4, out_channels, kernel_size=1)
 
     def forward(self, x):
-        return self.conv2(self.dropout(self.conv1(x)))
+        return self.conv2(self.dropout(run_fused(self.conv1, x)))
 
 
 class RCG(nn.Module):
@@ -249,7 +286,7 @@ class RCG(nn.Module):
     def forward(self, pre, edge, f):
         r = (1 - torch.sigmoid(pre)) * f
         edge1 = bilinear_resize(edge, size=f.size()[2:])
-        x2 = self.conv1(torch.cat((edge1, r), 1))
+        x2 = run_fused(self.conv1, torch.cat((edge1, r), 1))
         # tri-directional Mamba at 2x resolution (MMUNet.py:398-412)
         x0 = self.upsample(x2)
         B, C, H, W = x0.shape
@@ -269,7 +306,7 @@ class DecoderBlock(nn.Module):
                                    nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        return bilinear_resize(self.conv2(self.conv1(x)), scale_factor=2)
+        return bilinear_resize(run_fused(self.conv2, run_fused(self.conv1, x)), scale_factor=2)
 
 
 class ResidualBlock(nn.Module):
@@ -293,7 +330,7 @@ class ResidualBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        x1 = self.block1(x)
+        x1 = run_fused(self.block1, x)
         if self.downsample:
             return self.relu(self.block2(x) + x1)
         return self.relu(x1 + x)
@@ -345,7 +382,7 @@ class MM_Net(nn.Module):
         e3 = self.encoder3(e2)
         e4 = self.encoder4(e3)
         e5 = self.encoder5(e4)
-        e3, e4, e5 = self.down3(e3), self.down4(e4), self.down5(e5)
+        e3, e4, e5 = run_fused(self.down3, e3), run_fused(self.down4, e4), run_fused(self.down5, e5)
         d5 = self.decoder5(e5)
         out5 = self.side5(d5)
         c1 = self.cbam(e1)          # contour branch on the stride-2 stem features

@@ -1,0 +1,114 @@
+"""``gn_bn_act`` -- GroupNorm [-> BatchNorm2d] [-> ReLU | tanh] as one normalisation (HIP, fwd + bwd).
+
+Every MMConv ends in GroupNorm (MMUNet.py:265) and is followed by BatchNorm2d and usually ReLU in the
+blocks that use it (:344-349, 357-359, 424-430, 436-452); its offset branch is GroupNorm -> tanh (:250).
+Both normalisations are affine in x per (batch, channel) once their statistics are known,
+
+    GroupNorm   y1 = a x + d          a = gamma_g r_bg,  d = beta_g - a mu_bg
+    BatchNorm   y2 = A x + D          mean_c(y1) = 1/N sum_b (a s1 + d HW),  E_c(y1^2) = 1/N sum_b (a^2 s2 + 2 a d s1 + d^2 HW)
+
+with s1 = sum_hw x, s2 = sum_hw x^2 per (batch, channel): ONE moments pass gives both sets of statistics and
+one apply pass writes act(A x + D).  Backward, with g2 = dout * act'(y2), t1 = sum_hw g2, t2 = sum_hw g2 x:
+
+    BatchNorm (training)   g1 = k (g2 - e - (p x + q) f),   k = gamma_b r_b, e = dbeta_b / N, f = dgamma_b / N,
+                           p = a r_b, q = (d - m_c) r_b,  dbeta_b = sum_b t1,  dgamma_b = sum_b (p t2 + q t1)
+    per (b, c)             u1 = sum_hw g1 = k (t1 - e HW - f (p s1 + q HW)),  u2 = sum_hw g1 x = k (t2 - e s1 - f (p s2 + q s1))
+    GroupNorm              M1 = mean_g(gamma_g g1),  M2 = mean_g(gamma_g g1 xhat)   from u1, u2
+                           dx = r [gamma_g g1 - M1 - xhat M2]  =  c0 g2 + c1 x + c2    (per-(b, c) constants)
+
+so the backward is one pass for (t1, t2) and one for dx.  As separate ATen / MIOpen ops the chain makes 8
+passes over the activation forward and 13 backward.  float32 NCHW contiguous.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+
+
+class GnBnActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gn_w, gn_b, bn_w, bn_b, run_mean, run_var, groups, gn_eps, has_bn, training, bn_eps, momentum,
+                act):
+        _lib.require_gpu(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        dev, f32 = x.device, torch.float32
+        out = torch.empty_like(x)
+        stats = torch.empty(4 * B * C + 2 * B * groups + 2 * C, device=dev, dtype=f32)
+        s1, s2, scale, shift = (stats[i * B * C:(i + 1) * B * C] for i in range(4))
+        mu = stats[4 * B * C:4 * B * C + B * groups]
+        rstd = stats[4 * B * C + B * groups:4 * B * C + 2 * B * groups]
+        bn_mean = stats[4 * B * C + 2 * B * groups:4 * B * C + 2 * B * groups + C]
+        bn_rstd = stats[4 * B * C + 2 * B * groups + C:]
+        p = _lib.NormParams()
+        p.batch, p.channels, p.groups, p.hw = B, C, groups, H * W
+        p.has_bn, p.training, p.act = int(has_bn), int(training), act
+        p.gn_eps, p.bn_eps, p.momentum = gn_eps, bn_eps, momentum
+        p.input, p.out = x.data_ptr(), out.data_ptr()
+        p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
+        p.running_mean, p.running_var = _lib.ptr(run_mean), _lib.ptr(run_var)
+        p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
+        p.bn_mean, p.bn_rstd, p.scale, p.shift = bn_mean.data_ptr(), bn_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mmu_norm_fused_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, gn_w, gn_b, bn_w, bn_b, stats)
+        ctx.cfg = (groups, gn_eps, has_bn, training, bn_eps, momentum, act)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gn_w, gn_b, bn_w, bn_b, stats = ctx.saved_tensors
+        groups, gn_eps, has_bn, training, bn_eps, momentum, act = ctx.cfg
+        B, C, H, W = x.shape
+        dev, f32 = x.device, torch.float32
+        g = dout.contiguous()
+        dx = torch.empty_like(x)
+        L = _lib.lib()
+        ws = torch.empty(L.mmu_norm_fused_workspace_floats(B, C, groups), device=dev, dtype=f32)
+        grads = torch.empty(4 * C, device=dev, dtype=f32)
+        s1, s2, scale, shift = (stats[i * B * C:(i + 1) * B * C] for i in range(4))
+        mu = stats[4 * B * C:4 * B * C + B * groups]
+        rstd = stats[4 * B * C + B * groups:4 * B * C + 2 * B * groups]
+        bn_mean = stats[4 * B * C + 2 * B * groups:4 * B * C + 2 * B * groups + C]
+        bn_rstd = stats[4 * B * C + 2 * B * groups + C:]
+        p = _lib.NormParams()
+        p.batch, p.channels, p.groups, p.hw = B, C, groups, H * W
+        p.has_bn, p.training, p.act = int(has_bn), int(training), act
+        p.gn_eps, p.bn_eps, p.momentum = gn_eps, bn_eps, momentum
+        p.input, p.dout, p.dinput = x.data_ptr(), g.data_ptr(), dx.data_ptr()
+        p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
+        p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
+        p.bn_mean, p.bn_rstd, p.scale, p.shift = bn_mean.data_ptr(), bn_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        dgw, dgb, dbw, dbb = (grads[i * C:(i + 1) * C] for i in range(4))
+        p.dgn_weight, p.dgn_bias = dgw.data_ptr(), dgb.data_ptr()
+        if has_bn:
+            p.dbn_weight, p.dbn_bias = dbw.data_ptr(), dbb.data_ptr()
+        p.workspace = ws.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.mmu_norm_fused_bwd(p, _lib.stream_of(x)))
+        return (dx, dgw if gn_w is not None else None, dgb if gn_b is not None else None,
+                dbw if (has_bn and bn_w is not None) else None, dbb if (has_bn and bn_b is not None) else None,
+                None, None, None, None, None, None, None, None, None)
+
+
+def supported(x, gn, bn=None):
+    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled() and \
+        x.shape[0] * x.shape[1] < 65536 and isinstance(gn, nn.GroupNorm)
+    if bn is not None:
+        ok = ok and isinstance(bn, nn.BatchNorm2d) and (bn.track_running_stats or bn.training) and \
+            bn.momentum is not None
+    return ok
+
+
+def gn_bn_act(x, gn, bn=None, act=None):
+    """``act(bn(gn(x)))`` with ``gn`` an ``nn.GroupNorm``, ``bn`` an optional ``nn.BatchNorm2d`` (its running
+    statistics are updated in training mode exactly as the module would), ``act`` in {None, "relu", "tanh"}."""
+    has_bn = bn is not None
+    training = bool(has_bn and (bn.training or not bn.track_running_stats))
+    if has_bn and bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return GnBnActFn.apply(x, gn.weight, gn.bias, bn.weight if has_bn else None, bn.bias if has_bn else None,
+                           bn.running_mean if has_bn else None, bn.running_var if has_bn else None, gn.num_groups,
+                           gn.eps, has_bn, training, bn.eps if has_bn else 0.0, bn.momentum if has_bn else 0.0, ACT[act])

@@ -124,12 +124,17 @@ def test_mmnet_fwd_bwd_vs_reference(mode):
     # every live parameter: |grad| sum within the self-consistency band.  The per-parameter response
     # stored in the fixture is a single sample, so a floor is added: 2 % in eval mode (the reference's own
     # encoder gradients move by 2 % under 1e-6 input noise there); 25 % in train mode (16 %).
+    # Absolute floor 2e-4 on the |grad| sum: in train mode the GroupNorm bias of an MMConv that feeds a
+    # BatchNorm has an analytically ZERO gradient (BatchNorm removes any per-channel shift); the reference's
+    # value there (1e-5 .. 1e-4) is fp32 cancellation noise of ATen's separate GN / BN backward kernels, the
+    # fused normalisation (norm_fused) cancels it in double and returns 1e-6 -- closer to the truth, and
+    # 90 % away from the reference's noise.
     names = [str(s) for s in g["gabs_names"]]
     floor = 2e-2 if mode == "eval" else 0.25
     bad = []
     for nme, a, s in zip(names, g[f"{mode}_gabs"], g[f"{mode}_gabs_sens"]):
         mine = float(params[nme].grad.double().abs().sum())
-        if abs(mine - a) > max(floor, 6 * s) * max(a, 1e-12) + 1e-10:
+        if abs(mine - a) > max(floor, 6 * s) * max(a, 1e-12) + 2e-4:
             bad.append((nme, a, mine))
     assert len(bad) <= len(names) // 50, f"{len(bad)} of {len(names)} gradient checksums off: {bad[:5]}"
 
@@ -329,6 +334,58 @@ def test_tri_order_split_combine(case):
     close(a.grad, g, 0, 0, "d a")
     close(b.grad, g.flip([-1]), 0, 0, "d b")
     close(c.grad, slice_(g), 0, 0, "d c")
+
+
+@pytest.mark.parametrize("cfg", [dict(shape=(2, 8, 12, 10), groups=2, bn=True, act="relu", train=True),
+                                 dict(shape=(3, 6, 16, 16), groups=3, bn=False, act="tanh", train=True),
+                                 dict(shape=(2, 16, 9, 7), groups=4, bn=True, act=None, train=True),
+                                 dict(shape=(2, 8, 8, 8), groups=2, bn=True, act="relu", train=False),
+                                 dict(shape=(1, 64, 32, 32), groups=16, bn=True, act="relu", train=True),
+                                 dict(shape=(2, 4, 5, 3), groups=4, bn=False, act=None, train=True)])
+def test_gn_bn_act_vs_modules(cfg):
+    """gn_bn_act == act(BatchNorm2d(GroupNorm(x))) evaluated with the torch modules on CPU: output, input
+    gradient, all four parameter gradients and the BatchNorm running statistics, training and eval mode
+    (MMUNet.py:250,265 + :344-349,424-430)."""
+    import copy
+    from mm_unet_amd.norm_fused import gn_bn_act
+    B, C, H, W = cfg["shape"]
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.7 + 0.4
+    g = torch.randn(B, C, H, W, generator=gen)
+    gn = torch.nn.GroupNorm(cfg["groups"], C)
+    bn = torch.nn.BatchNorm2d(C) if cfg["bn"] else None
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=gen) * 0.5 + 1)
+        gn.bias.copy_(torch.randn(C, generator=gen) * 0.3)
+        if bn is not None:
+            bn.weight.copy_(torch.randn(C, generator=gen) * 0.5 + 1)
+            bn.bias.copy_(torch.randn(C, generator=gen) * 0.3)
+            bn.running_mean.copy_(torch.randn(C, generator=gen) * 0.2)
+            bn.running_var.copy_(torch.rand(C, generator=gen) + 0.5)
+    gn_d, bn_d = copy.deepcopy(gn).to(DEV), (copy.deepcopy(bn).to(DEV) if bn is not None else None)
+    for m in (gn, bn, gn_d, bn_d):
+        if m is not None:
+            m.train(cfg["train"])
+    act = {None: lambda t: t, "relu": torch.relu, "tanh": torch.tanh}[cfg["act"]]
+    xr = x.clone().requires_grad_()
+    y = gn(xr)
+    if bn is not None:
+        y = bn(y)
+    ref = act(y)
+    ref.backward(g)
+    xg = x.to(DEV).requires_grad_()
+    out = gn_bn_act(xg, gn_d, bn_d, cfg["act"])
+    out.backward(g.to(DEV))
+    close(out, ref, 1e-4, 1e-4, "out")
+    close(xg.grad, xr.grad, 1e-3, 1e-4, "d input")
+    close(gn_d.weight.grad, gn.weight.grad, 1e-3, 1e-3, "d gn weight")
+    close(gn_d.bias.grad, gn.bias.grad, 1e-3, 1e-3, "d gn bias")
+    if bn is not None:
+        close(bn_d.weight.grad, bn.weight.grad, 1e-3, 1e-3, "d bn weight")
+        close(bn_d.bias.grad, bn.bias.grad, 1e-3, 1e-3, "d bn bias")
+        close(bn_d.running_mean, bn.running_mean, 1e-5, 1e-5, "running_mean")
+        close(bn_d.running_var, bn.running_var, 1e-4, 1e-5, "running_var")
+        assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked)
 
 
 def test_train_step_graph_replay_matches_eager():
