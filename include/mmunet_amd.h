@@ -263,13 +263,14 @@ typedef struct {
     const float *gn_bias;     /* [channels] or NULL */
     const float *bn_weight;   /* [channels] or NULL */
     const float *bn_bias;     /* [channels] or NULL */
+    const float *pre_bias;    /* [channels] or NULL: normalise input + pre_bias[c] (the bias of the conv before) */
     float *running_mean;      /* [channels]: updated in training mode (may be NULL), used in eval mode */
     float *running_var;
     float *out;               /* fwd */
     float *s1, *s2, *mu, *rstd, *bn_mean, *bn_rstd, *scale, *shift;   /* saved statistics */
     const float *dout;        /* bwd */
     float *dinput;            /* bwd */
-    float *dgn_weight, *dgn_bias, *dbn_weight, *dbn_bias;             /* bwd, each optional */
+    float *dgn_weight, *dgn_bias, *dbn_weight, *dbn_bias, *dpre_bias; /* bwd, each optional */
     float *workspace;         /* bwd */
 } mmu_norm_params;
 

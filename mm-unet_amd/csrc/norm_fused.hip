@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict
 struct FinArgs {
     int B, C, G, HW, has_bn, training;
     float eps_g, eps_b, momentum;
-    const float *s1, *s2;          // [B*C] moments of x
+    float *s1, *s2;                // [B*C] moments of x (+ pre_bias: rewritten in place by the forward finalize)
+    const float *pre_bias;         // [C] or NULL: the normalisation sees x + pre_bias[c]
+    float *dpre_bias;              // [C] or NULL
     const float *gn_w, *gn_b;      // [C] or NULL (1 / 0)
     const float *bn_w, *bn_b;      // [C] or NULL
     float *run_mean, *run_var;     // [C] (updated when training) or NULL
@@ -115,7 +117,7 @@ struct FinArgs {
     float *bmean, *brstd;          // [C] BatchNorm statistics used (saved)
     float *A, *D;                  // [B*C] out = act(A x + D)
     // backward
-    const float *t1, *t2;          // [B*C]
+    float *t1, *t2;                // [B*C]
     float *c0, *c1, *c2;           // [B*C] dx = c0 g2 + c1 x + c2
     float *dgn_w, *dgn_b, *dbn_w, *dbn_b;  // [C] parameter gradients (may be NULL)
     float *scratch;                // [2*B*C + 2*B*G + 3*C] floats of workspace for the backward algebra
@@ -125,6 +127,14 @@ struct FinArgs {
 __global__ __launch_bounds__(256) void nf_finalize_fwd_kernel(FinArgs p) {
     const int cpg = p.C / p.G;
     const double n = (double)cpg * p.HW, N = (double)p.B * p.HW;
+    if (p.pre_bias) {  // moments of x + bias from the moments of x
+        for (int bc = threadIdx.x; bc < p.B * p.C; bc += blockDim.x) {
+            const double bv = p.pre_bias[bc % p.C], s1 = p.s1[bc], s2 = p.s2[bc];
+            p.s1[bc] = (float)(s1 + bv * p.HW);
+            p.s2[bc] = (float)(s2 + 2 * bv * s1 + bv * bv * p.HW);
+        }
+        __syncthreads();
+    }
     for (int bg = threadIdx.x; bg < p.B * p.G; bg += blockDim.x) {
         const int b = bg / p.G, g = bg - b * p.G;
         double a1 = 0, a2 = 0;
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(256) void nf_finalize_fwd_kernel(FinArgs p) {
             d = (d - p.bmean[c]) * k + (p.bn_b ? p.bn_b[c] : 0.0);
             a = a * k;
         }
+        if (p.pre_bias) d += a * p.pre_bias[c];  // act(A (x + bias) + D) as act(A x + D')
         p.A[bc] = (float)a;
         p.D[bc] = (float)d;
     }
@@ -190,6 +201,10 @@ __global__ __launch_bounds__(256) void nf_finalize_bwd_kernel(FinArgs p) {
     // mexact: the batch mean of y1 recomputed in double from the moments.  The float copy saved by the forward
     // is good enough for the output, but here sum_b (p s1 + q HW) must cancel to zero (BatchNorm removes any
     // per-channel shift, so d(gn bias) is analytically 0); with the rounded mean it leaves 1e-5 of noise.
+    if (p.pre_bias) {  // sum_hw g2 (x + bias)
+        for (int bc = threadIdx.x; bc < p.B * p.C; bc += blockDim.x) p.t2[bc] += p.pre_bias[bc % p.C] * p.t1[bc];
+        __syncthreads();
+    }
     double *mexact = reinterpret_cast<double *>(p.scratch);
     float *u1 = p.scratch + 2 * p.C, *u2 = u1 + p.B * p.C, *M1 = u2 + p.B * p.C, *M2 = M1 + p.B * p.G;
     float *kk = M2 + p.B * p.G, *ee = kk + p.C, *ff = ee + p.C;
@@ -281,9 +296,20 @@ __global__ __launch_bounds__(256) void nf_finalize_bwd_kernel(FinArgs p) {
         const double k = kk[c], e = ee[c], f = ff[c];
         const double m1 = M1[b * p.G + g], m2 = M2[b * p.G + g];
         const double rgk = r * gw * k;
-        p.c0[bc] = (float)rgk;
-        p.c1[bc] = (float)(-rgk * f * pq - r * r * m2);
-        p.c2[bc] = (float)(-rgk * e - rgk * f * qq - r * m1 + r * r * mu * m2);
+        const double k0 = rgk, k1 = -rgk * f * pq - r * r * m2, k2 = -rgk * e - rgk * f * qq - r * m1 + r * r * mu * m2;
+        p.c0[bc] = (float)k0;
+        p.c1[bc] = (float)k1;
+        // in terms of the raw x: c1 (x + bias) + c2
+        p.c2[bc] = (float)(k2 + (p.pre_bias ? k1 * p.pre_bias[c] : 0.0));
+        if (p.dpre_bias) u1[bc] = (float)(k0 * p.t1[bc] + k1 * p.s1[bc] + k2 * HW);  // sum_hw dx of this (b, c)
+    }
+    if (p.dpre_bias) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            double sacc = 0;
+            for (int b = 0; b < p.B; ++b) sacc += u1[b * p.C + c];
+            p.dpre_bias[c] = (float)sacc;
+        }
     }
 }
 
@@ -332,6 +358,7 @@ int fill(const mmu_norm_params *p, FinArgs &a, const char *name) {
     a = FinArgs{};
     a.B = p->batch; a.C = p->channels; a.G = p->groups; a.HW = p->hw; a.has_bn = p->has_bn; a.training = p->training;
     a.eps_g = p->gn_eps; a.eps_b = p->bn_eps; a.momentum = p->momentum;
+    a.pre_bias = p->pre_bias;
     a.s1 = p->s1; a.s2 = p->s2; a.gn_w = p->gn_weight; a.gn_b = p->gn_bias; a.bn_w = p->bn_weight; a.bn_b = p->bn_bias;
     a.run_mean = p->running_mean; a.run_var = p->running_var; a.mu = p->mu; a.rstd = p->rstd;
     a.bmean = p->bn_mean; a.brstd = p->bn_rstd; a.A = p->scale; a.D = p->shift;
@@ -374,6 +401,7 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     a.scratch = ws + 5 * BC;
     if ((uintptr_t)a.scratch & 7) a.scratch += 1;  // the first entry of the scratch area is a double array
     a.dgn_w = p->dgn_weight; a.dgn_b = p->dgn_bias; a.dbn_w = p->dbn_weight; a.dbn_b = p->dbn_bias;
+    a.dpre_bias = p->pre_bias ? p->dpre_bias : nullptr;
     nf_moments_kernel<true><<<BC, 256, 0, st>>>(p->input, p->dout, a.A, a.D, t1, t2, a.HW, p->act);
     nf_finalize_bwd_kernel<<<1, 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);

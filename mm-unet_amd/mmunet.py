@@ -145,14 +145,15 @@ class MMConv(nn.Module):
 
     def forward(self, input):
         """GroupNorm(K x 1 DSC conv(deformable samples)) -- MMUNet.py:244-265."""
-        pre = self.forward_pre_gn(input)
+        pre, bias = self.forward_pre_gn(input)
         if norm_fused.supported(pre, self.gn):
-            return norm_fused.gn_bn_act(pre, self.gn)
-        return self.gn(pre)
+            return norm_fused.gn_bn_act(pre, self.gn, pre_bias=bias)
+        return self.gn(pre if bias is None else pre + bias.view(1, -1, 1, 1))
 
     def forward_pre_gn(self, input):
         """Everything of forward() before the final GroupNorm (run_fused joins that GroupNorm with the
-        BatchNorm2d / ReLU that follow the block in its nn.Sequential)."""
+        BatchNorm2d / ReLU that follow the block in its nn.Sequential).  Returns (conv output WITHOUT its
+        bias, bias or None): the fused normalisation folds the bias into its statistics."""
         raw = self._offset_conv(input)
         if norm_fused.supported(raw, self.gn_offset):
             offset = norm_fused.gn_bn_act(raw, self.gn_offset, None, "tanh")   # GroupNorm -> tanh in 2 passes
@@ -175,11 +176,8 @@ class MMConv(nn.Module):
             conv = self.dsc_conv_x
             samples = morph_sample(input, y_rows, tokens_last=True)
             output = dsc_gemm(conv.weight.view(conv.out_channels, -1), samples, B).view(B, conv.out_channels, H, W)
-            if conv.bias is not None:
-                output = output + conv.bias.view(1, -1, 1, 1)
-        else:
-            output = self.dsc_conv_y(morph_sample(input, y_rows))
-        return output
+            return output, conv.bias
+        return self.dsc_conv_y(morph_sample(input, y_rows)), None
 
 
 def run_fused(seq, x):
@@ -191,14 +189,14 @@ def run_fused(seq, x):
     while i < len(mods):
         m = mods[i]
         if isinstance(m, MMConv) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
-            pre = m.forward_pre_gn(x)
+            pre, bias = m.forward_pre_gn(x)
             bn = mods[i + 1]
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
             if norm_fused.supported(pre, m.gn, bn):
-                x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if relu else None)
+                x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if relu else None, pre_bias=bias)
                 i += 3 if relu else 2
                 continue
-            x = m.gn(pre)
+            x = m.gn(pre if bias is None else pre + bias.view(1, -1, 1, 1))
             i += 1
             continue
         x = m(x)

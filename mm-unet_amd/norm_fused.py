@@ -29,8 +29,8 @@ ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
 
 class GnBnActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gn_w, gn_b, bn_w, bn_b, run_mean, run_var, groups, gn_eps, has_bn, training, bn_eps, momentum,
-                act):
+    def forward(ctx, x, gn_w, gn_b, bn_w, bn_b, pre_bias, run_mean, run_var, groups, gn_eps, has_bn, training, bn_eps,
+                momentum, act):
         _lib.require_gpu(x)
         x = x.contiguous()
         B, C, H, W = x.shape
@@ -48,18 +48,19 @@ class GnBnActFn(torch.autograd.Function):
         p.gn_eps, p.bn_eps, p.momentum = gn_eps, bn_eps, momentum
         p.input, p.out = x.data_ptr(), out.data_ptr()
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
+        p.pre_bias = _lib.ptr(pre_bias)
         p.running_mean, p.running_var = _lib.ptr(run_mean), _lib.ptr(run_var)
         p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
         p.bn_mean, p.bn_rstd, p.scale, p.shift = bn_mean.data_ptr(), bn_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mmu_norm_fused_fwd(p, _lib.stream_of(x)))
-        ctx.save_for_backward(x, gn_w, gn_b, bn_w, bn_b, stats)
+        ctx.save_for_backward(x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats)
         ctx.cfg = (groups, gn_eps, has_bn, training, bn_eps, momentum, act)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, gn_w, gn_b, bn_w, bn_b, stats = ctx.saved_tensors
+        x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats = ctx.saved_tensors
         groups, gn_eps, has_bn, training, bn_eps, momentum, act = ctx.cfg
         B, C, H, W = x.shape
         dev, f32 = x.device, torch.float32
@@ -67,7 +68,7 @@ class GnBnActFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         L = _lib.lib()
         ws = torch.empty(L.mmu_norm_fused_workspace_floats(B, C, groups), device=dev, dtype=f32)
-        grads = torch.empty(4 * C, device=dev, dtype=f32)
+        grads = torch.empty(5 * C, device=dev, dtype=f32)
         s1, s2, scale, shift = (stats[i * B * C:(i + 1) * B * C] for i in range(4))
         mu = stats[4 * B * C:4 * B * C + B * groups]
         rstd = stats[4 * B * C + B * groups:4 * B * C + 2 * B * groups]
@@ -79,9 +80,12 @@ class GnBnActFn(torch.autograd.Function):
         p.gn_eps, p.bn_eps, p.momentum = gn_eps, bn_eps, momentum
         p.input, p.dout, p.dinput = x.data_ptr(), g.data_ptr(), dx.data_ptr()
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
+        p.pre_bias = _lib.ptr(pre_bias)
         p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
         p.bn_mean, p.bn_rstd, p.scale, p.shift = bn_mean.data_ptr(), bn_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
-        dgw, dgb, dbw, dbb = (grads[i * C:(i + 1) * C] for i in range(4))
+        dgw, dgb, dbw, dbb, dpb = (grads[i * C:(i + 1) * C] for i in range(5))
+        if pre_bias is not None:
+            p.dpre_bias = dpb.data_ptr()
         p.dgn_weight, p.dgn_bias = dgw.data_ptr(), dgb.data_ptr()
         if has_bn:
             p.dbn_weight, p.dbn_bias = dbw.data_ptr(), dbb.data_ptr()
@@ -90,7 +94,7 @@ class GnBnActFn(torch.autograd.Function):
             _lib.check(L.mmu_norm_fused_bwd(p, _lib.stream_of(x)))
         return (dx, dgw if gn_w is not None else None, dgb if gn_b is not None else None,
                 dbw if (has_bn and bn_w is not None) else None, dbb if (has_bn and bn_b is not None) else None,
-                None, None, None, None, None, None, None, None, None)
+                dpb if pre_bias is not None else None, None, None, None, None, None, None, None, None, None)
 
 
 def supported(x, gn, bn=None):
@@ -102,13 +106,15 @@ def supported(x, gn, bn=None):
     return ok
 
 
-def gn_bn_act(x, gn, bn=None, act=None):
-    """``act(bn(gn(x)))`` with ``gn`` an ``nn.GroupNorm``, ``bn`` an optional ``nn.BatchNorm2d`` (its running
-    statistics are updated in training mode exactly as the module would), ``act`` in {None, "relu", "tanh"}."""
+def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None):
+    """``act(bn(gn(x + pre_bias[None, :, None, None])))`` with ``gn`` an ``nn.GroupNorm``, ``bn`` an optional
+    ``nn.BatchNorm2d`` (its running statistics are updated in training mode exactly as the module would),
+    ``act`` in {None, "relu", "tanh"}; ``pre_bias`` (the bias of the convolution that produced ``x``) is folded
+    into the statistics instead of being added to the activation."""
     has_bn = bn is not None
     training = bool(has_bn and (bn.training or not bn.track_running_stats))
     if has_bn and bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return GnBnActFn.apply(x, gn.weight, gn.bias, bn.weight if has_bn else None, bn.bias if has_bn else None,
-                           bn.running_mean if has_bn else None, bn.running_var if has_bn else None, gn.num_groups,
+                           pre_bias, bn.running_mean if has_bn else None, bn.running_var if has_bn else None, gn.num_groups,
                            gn.eps, has_bn, training, bn.eps if has_bn else 0.0, bn.momentum if has_bn else 0.0, ACT[act])

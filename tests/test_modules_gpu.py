@@ -337,6 +337,9 @@ def test_tri_order_split_combine(case):
 
 
 @pytest.mark.parametrize("cfg", [dict(shape=(2, 8, 12, 10), groups=2, bn=True, act="relu", train=True),
+                                 dict(shape=(2, 8, 12, 10), groups=2, bn=True, act="relu", train=True, pre_bias=True),
+                                 dict(shape=(2, 6, 7, 5), groups=3, bn=False, act=None, train=True, pre_bias=True),
+                                 dict(shape=(2, 8, 6, 6), groups=4, bn=True, act=None, train=False, pre_bias=True),
                                  dict(shape=(3, 6, 16, 16), groups=3, bn=False, act="tanh", train=True),
                                  dict(shape=(2, 16, 9, 7), groups=4, bn=True, act=None, train=True),
                                  dict(shape=(2, 8, 8, 8), groups=2, bn=True, act="relu", train=False),
@@ -368,14 +371,18 @@ def test_gn_bn_act_vs_modules(cfg):
             m.train(cfg["train"])
     act = {None: lambda t: t, "relu": torch.relu, "tanh": torch.tanh}[cfg["act"]]
     xr = x.clone().requires_grad_()
-    y = gn(xr)
+    pb = (torch.randn(C, generator=gen) * 0.8).requires_grad_() if cfg.get("pre_bias") else None
+    y = gn(xr if pb is None else xr + pb.view(1, -1, 1, 1))
     if bn is not None:
         y = bn(y)
     ref = act(y)
     ref.backward(g)
     xg = x.to(DEV).requires_grad_()
-    out = gn_bn_act(xg, gn_d, bn_d, cfg["act"])
+    pbg = pb.detach().to(DEV).requires_grad_() if pb is not None else None
+    out = gn_bn_act(xg, gn_d, bn_d, cfg["act"], pre_bias=pbg)
     out.backward(g.to(DEV))
+    if pb is not None:
+        close(pbg.grad, pb.grad, 1e-3, 1e-3, "d pre_bias")
     close(out, ref, 1e-4, 1e-4, "out")
     close(xg.grad, xr.grad, 1e-3, 1e-4, "d input")
     close(gn_d.weight.grad, gn.weight.grad, 1e-3, 1e-3, "d gn weight")
