@@ -257,6 +257,7 @@ int mmu_tri_combine(const mmu_tri_params *p, void *stream);
 #define MMU_ACT_TANH 2
 typedef struct {
     int32_t batch, channels, groups, hw, has_bn, training, act;
+    int32_t has_gn;           /* 0: BatchNorm2d [-> act] alone (then groups == channels, has_bn == 1) */
     float gn_eps, bn_eps, momentum;
     const float *input;       /* [batch, channels, hw] */
     const float *gn_weight;   /* [channels] or NULL */

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict
 }
 
 struct FinArgs {
-    int B, C, G, HW, has_bn, training;
+    int B, C, G, HW, has_bn, training, has_gn;
     float eps_g, eps_b, momentum;
     float *s1, *s2;                // [B*C] moments of x (+ pre_bias: rewritten in place by the forward finalize)
     const float *pre_bias;         // [C] or NULL: the normalisation sees x + pre_bias[c]
@@ -136,6 +136,11 @@ __global__ __launch_bounds__(256) void nf_finalize_fwd_kernel(FinArgs p) {
         __syncthreads();
     }
     for (int bg = threadIdx.x; bg < p.B * p.G; bg += blockDim.x) {
+        if (!p.has_gn) {  // BatchNorm alone: the "group" stage is the identity
+            p.mu[bg] = 0.f;
+            p.rstd[bg] = 1.f;
+            continue;
+        }
         const int b = bg / p.G, g = bg - b * p.G;
         double a1 = 0, a2 = 0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
@@ -268,8 +273,8 @@ __global__ __launch_bounds__(256) void nf_finalize_bwd_kernel(FinArgs p) {
             a1 += gw * u1[b * p.C + c];
             a2 += gw * r * (u2[b * p.C + c] - mu * u1[b * p.C + c]);
         }
-        M1[bg] = (float)(a1 / n);
-        M2[bg] = (float)(a2 / n);
+        M1[bg] = p.has_gn ? (float)(a1 / n) : 0.f;
+        M2[bg] = p.has_gn ? (float)(a2 / n) : 0.f;
     }
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
         const int g = c / cpg;
@@ -357,6 +362,9 @@ int fill(const mmu_norm_params *p, FinArgs &a, const char *name) {
     MMU_CHECK((long)p->batch * p->channels < 65536, "%s: batch * channels must be < 65536", name);
     a = FinArgs{};
     a.B = p->batch; a.C = p->channels; a.G = p->groups; a.HW = p->hw; a.has_bn = p->has_bn; a.training = p->training;
+    a.has_gn = p->has_gn;
+    if (!p->has_gn && (!p->has_bn || p->groups != p->channels))
+        return mmu_fail("%s: has_gn = 0 needs has_bn = 1 and groups == channels", name);
     a.eps_g = p->gn_eps; a.eps_b = p->bn_eps; a.momentum = p->momentum;
     a.pre_bias = p->pre_bias;
     a.s1 = p->s1; a.s2 = p->s2; a.gn_w = p->gn_weight; a.gn_b = p->gn_bias; a.bn_w = p->bn_weight; a.bn_b = p->bn_bias;

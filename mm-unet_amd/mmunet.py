@@ -199,6 +199,11 @@ def run_fused(seq, x):
             x = m.gn(pre if bias is None else pre + bias.view(1, -1, 1, 1))
             i += 1
             continue
+        if isinstance(m, nn.BatchNorm2d) and norm_fused.bn_act_supported(x, m):   # Conv2d -> BatchNorm2d [-> ReLU]
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = norm_fused.bn_act(x, m, "relu" if relu else None)
+            i += 2 if relu else 1
+            continue
         x = m(x)
         i += 1
     return x
@@ -330,7 +335,7 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         x1 = run_fused(self.block1, x)
         if self.downsample:
-            return self.relu(self.block2(x) + x1)
+            return self.relu(run_fused(self.block2, x) + x1)
         return self.relu(x1 + x)
 
 
@@ -375,7 +380,7 @@ class MM_Net(nn.Module):
     def forward(self, x):
         size = x.size()[2:]
         up = lambda t: bilinear_resize(t, size=size)  # noqa: E731
-        e1 = self.encoder1(x)
+        e1 = run_fused(self.encoder1, x)
         e2 = self.encoder2(self.maxpool(e1))
         e3 = self.encoder3(e2)
         e4 = self.encoder4(e3)
@@ -383,7 +388,7 @@ class MM_Net(nn.Module):
         e3, e4, e5 = run_fused(self.down3, e3), run_fused(self.down4, e4), run_fused(self.down5, e5)
         d5 = self.decoder5(e5)
         out5 = self.side5(d5)
-        c1 = self.cbam(e1)          # contour branch on the stride-2 stem features
+        c1 = run_fused(self.cbam, e1)   # contour branch on the stride-2 stem features
         p_c = self.line_predict(c1)
         r4 = self.rcg4(out5, c1, e4)
         d4 = self.decoder4(torch.cat((d5, r4), dim=1))

@@ -44,8 +44,8 @@ class GnBnActFn(torch.autograd.Function):
         bn_rstd = stats[4 * B * C + 2 * B * groups + C:]
         p = _lib.NormParams()
         p.batch, p.channels, p.groups, p.hw = B, C, groups, H * W
-        p.has_bn, p.training, p.act = int(has_bn), int(training), act
-        p.gn_eps, p.bn_eps, p.momentum = gn_eps, bn_eps, momentum
+        p.has_bn, p.training, p.act, p.has_gn = int(has_bn), int(training), act, int(gn_eps >= 0)
+        p.gn_eps, p.bn_eps, p.momentum = max(gn_eps, 0.0), bn_eps, momentum
         p.input, p.out = x.data_ptr(), out.data_ptr()
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
         p.pre_bias = _lib.ptr(pre_bias)
@@ -76,17 +76,19 @@ class GnBnActFn(torch.autograd.Function):
         bn_rstd = stats[4 * B * C + 2 * B * groups + C:]
         p = _lib.NormParams()
         p.batch, p.channels, p.groups, p.hw = B, C, groups, H * W
-        p.has_bn, p.training, p.act = int(has_bn), int(training), act
-        p.gn_eps, p.bn_eps, p.momentum = gn_eps, bn_eps, momentum
+        p.has_bn, p.training, p.act, p.has_gn = int(has_bn), int(training), act, int(gn_eps >= 0)
+        p.gn_eps, p.bn_eps, p.momentum = max(gn_eps, 0.0), bn_eps, momentum
         p.input, p.dout, p.dinput = x.data_ptr(), g.data_ptr(), dx.data_ptr()
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
         p.pre_bias = _lib.ptr(pre_bias)
         p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
         p.bn_mean, p.bn_rstd, p.scale, p.shift = bn_mean.data_ptr(), bn_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
         dgw, dgb, dbw, dbb, dpb = (grads[i * C:(i + 1) * C] for i in range(5))
+        if gn_eps < 0:   # BatchNorm alone: no GroupNorm parameters
+            dgw = dgb = None
         if pre_bias is not None:
             p.dpre_bias = dpb.data_ptr()
-        p.dgn_weight, p.dgn_bias = dgw.data_ptr(), dgb.data_ptr()
+        p.dgn_weight, p.dgn_bias = _lib.ptr(dgw), _lib.ptr(dgb)
         if has_bn:
             p.dbn_weight, p.dbn_bias = dbw.data_ptr(), dbb.data_ptr()
         p.workspace = ws.data_ptr()
@@ -104,6 +106,23 @@ def supported(x, gn, bn=None):
         ok = ok and isinstance(bn, nn.BatchNorm2d) and (bn.track_running_stats or bn.training) and \
             bn.momentum is not None
     return ok
+
+
+def bn_act_supported(x, bn):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled() and \
+        x.shape[0] * x.shape[1] < 65536 and isinstance(bn, nn.BatchNorm2d) and bn.affine and \
+        (bn.track_running_stats or bn.training) and bn.momentum is not None
+
+
+def bn_act(x, bn, act=None):
+    """``act(bn(x))`` for an ``nn.BatchNorm2d`` (training or eval statistics): the same two-pass kernels with
+    the GroupNorm stage switched off -- BatchNorm and ReLU read and write the activation once each way
+    together instead of once each."""
+    training = bool(bn.training or not bn.track_running_stats)
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return GnBnActFn.apply(x, None, None, bn.weight, bn.bias, None, bn.running_mean, bn.running_var, x.shape[1],
+                           -1.0, True, training, bn.eps, bn.momentum, ACT[act])
 
 
 def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None):

@@ -395,6 +395,38 @@ def test_gn_bn_act_vs_modules(cfg):
         assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked)
 
 
+@pytest.mark.parametrize("cfg", [((2, 8, 12, 10), "relu", True), ((3, 5, 7, 9), None, True), ((2, 16, 8, 8), "relu", False)])
+def test_bn_act_vs_modules(cfg):
+    """bn_act == act(BatchNorm2d(x)) (the GroupNorm stage of the fused normalisation switched off)."""
+    import copy
+    from mm_unet_amd.norm_fused import bn_act
+    (B, C, H, W), actn, train = cfg
+    gen = torch.Generator().manual_seed(43)
+    x = torch.randn(B, C, H, W, generator=gen) * 1.3 - 0.2
+    g = torch.randn(B, C, H, W, generator=gen)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=gen) * 0.5 + 1)
+        bn.bias.copy_(torch.randn(C, generator=gen) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=gen) * 0.2)
+        bn.running_var.copy_(torch.rand(C, generator=gen) + 0.5)
+    bn_d = copy.deepcopy(bn).to(DEV)
+    bn.train(train), bn_d.train(train)
+    act = {None: lambda t: t, "relu": torch.relu}[actn]
+    xr = x.clone().requires_grad_()
+    ref = act(bn(xr))
+    ref.backward(g)
+    xg = x.to(DEV).requires_grad_()
+    out = bn_act(xg, bn_d, actn)
+    out.backward(g.to(DEV))
+    close(out, ref, 1e-4, 1e-4, "out")
+    close(xg.grad, xr.grad, 1e-3, 1e-4, "d input")
+    close(bn_d.weight.grad, bn.weight.grad, 1e-3, 1e-3, "d weight")
+    close(bn_d.bias.grad, bn.bias.grad, 1e-3, 1e-3, "d bias")
+    close(bn_d.running_mean, bn.running_mean, 1e-5, 1e-5, "running_mean")
+    close(bn_d.running_var, bn.running_var, 1e-4, 1e-5, "running_var")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
