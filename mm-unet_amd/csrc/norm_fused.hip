@@ -124,7 +124,7 @@ struct FinArgs {
 };
 
 // one workgroup; all per-(b,c) algebra in double
-__global__ __launch_bounds__(256) void nf_finalize_fwd_kernel(FinArgs p) {
+__global__ __launch_bounds__(1024) void nf_finalize_fwd_kernel(FinArgs p) {
     const int cpg = p.C / p.G;
     const double n = (double)cpg * p.HW, N = (double)p.B * p.HW;
     if (p.pre_bias) {  // moments of x + bias from the moments of x
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void nf_finalize_fwd_kernel(FinArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void nf_finalize_bwd_kernel(FinArgs p) {
+__global__ __launch_bounds__(1024) void nf_finalize_bwd_kernel(FinArgs p) {
     const int cpg = p.C / p.G;
     const double n = (double)cpg * p.HW, N = (double)p.B * p.HW, HW = p.HW;
     // workspace: mexact[C] (double) | u1[B*C] u2[B*C] M1[B*G] M2[B*G] kk[C] ee[C] ff[C]
@@ -386,7 +386,7 @@ extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int BC = a.B * a.C;
     nf_moments_kernel<false><<<BC, 256, 0, st>>>(p->input, nullptr, nullptr, nullptr, p->s1, p->s2, a.HW, 0);
-    nf_finalize_fwd_kernel<<<1, 256, 0, st>>>(a);
+    nf_finalize_fwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
     nf_apply_kernel<false><<<grid, 256, 0, st>>>(p->input, nullptr, a.A, a.D, nullptr, nullptr, nullptr, p->out, a.HW,
                                                   p->act);
@@ -411,7 +411,7 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     a.dgn_w = p->dgn_weight; a.dgn_b = p->dgn_bias; a.dbn_w = p->dbn_weight; a.dbn_b = p->dbn_bias;
     a.dpre_bias = p->pre_bias ? p->dpre_bias : nullptr;
     nf_moments_kernel<true><<<BC, 256, 0, st>>>(p->input, p->dout, a.A, a.D, t1, t2, a.HW, p->act);
-    nf_finalize_bwd_kernel<<<1, 256, 0, st>>>(a);
+    nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
     nf_apply_kernel<true><<<grid, 256, 0, st>>>(p->input, p->dout, a.A, a.D, a.c0, a.c1, a.c2, p->dinput, a.HW, p->act);
     MMU_HIP_LAUNCH_CHECK("norm_fused_bwd");
