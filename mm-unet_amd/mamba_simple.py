@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from .causal_conv1d_interface import causal_conv1d_fn
 from .selective_scan_interface import _dbl_view, mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn
 from . import tri_order
-from .tall_gemm import proj_tokens
+from .tall_gemm import proj_bcl, proj_tokens
 
 
 class Mamba(nn.Module):
@@ -118,6 +118,46 @@ class Mamba(nn.Module):
             o = o + self.out_proj.bias.view(-1, 1)
         return o.view(-1, batch, seqlen).permute(1, 2, 0)
 
+    def _v3(self, xz, batch, seqlen):
+        """The three scans of the tri-directional block and their sum (mamba_simple.py:212-270), before out_proj:
+        xz (B, 2*d_inner, L) -> (total (B, d_inner, L), o_1, o_2, o_3)."""
+        o_1 = o_2 = o_3 = None
+        if seqlen % self.nslices != 0:
+            raise RuntimeError(f"Mamba v3: seqlen {seqlen} must be divisible by nslices {self.nslices}")
+        ns = self.nslices
+        fused = tri_order.supported(xz)
+        if fused:   # flip + slice-interleave in one pass; the three input gradients meet in one kernel
+            xz_a, xz_f, xz_s = tri_order.tri_split(xz, ns)
+        else:
+            xz_a, xz_f = xz, xz.flip([-1])
+            # token i of slice s -> position i*nslices + s   (mamba_simple.py:245-247)
+            xz_s = xz.reshape(batch, 2 * self.d_inner, ns, seqlen // ns).transpose(-1, -2) \
+                .reshape(batch, 2 * self.d_inner, seqlen)
+        out = self._branch(xz_a, "")
+        out_b = self._branch(xz_f, "_b")
+        out_sp = self._branch(xz_s, "_s")          # still in slice-interleaved order
+        unslice = lambda t: t.reshape(batch, self.d_inner, seqlen // ns, ns).permute(0, 1, 3, 2).flatten(-2)  # noqa: E731
+        if self.return_branch_outputs:             # (out, o_1, o_2, o_3) of mamba_simple.py:267-270,362
+            o_1, o_2, o_3 = out, out_b, unslice(out_sp)
+        if fused and tri_order.supported(out, out_b, out_sp):
+            total = tri_order.tri_combine(out, out_b, out_sp, ns)
+        else:
+            total = out + out_b.flip([-1]) + (o_3 if o_3 is not None else unslice(out_sp))
+        return total, o_1, o_2, o_3
+
+    def forward_bcl(self, x):
+        """Channels-first variant for callers that hold feature maps: x (B, d_model, L) contiguous ->
+        (out (B, d_model, L) contiguous, o_1, o_2, o_3).  Same computation as ``forward(x.transpose(1, 2))``
+        followed by ``.transpose(1, 2)``, without the transposing copies (see tall_gemm.proj_bcl)."""
+        ok = (self.use_fast_path and self.bimamba_type == "v3" and self.in_proj.bias is None and x.is_cuda
+              and self.out_proj.bias is None and x.dtype == torch.float32 and not torch.is_autocast_enabled())
+        if not ok:
+            res = self.forward(x.transpose(1, 2))
+            return (res[0].transpose(1, 2),) + tuple(res[1:])
+        xz = proj_bcl(self.in_proj.weight, x.contiguous(), True)
+        total, o_1, o_2, o_3 = self._v3(xz, x.shape[0], x.shape[2])
+        return proj_bcl(self.out_proj.weight, total, False), o_1, o_2, o_3
+
     def forward(self, hidden_states, inference_params=None):
         """hidden_states: (B, L, D) -> (out (B, L, D), o_1, o_2, o_3)."""
         if inference_params is not None:
@@ -132,27 +172,7 @@ class Mamba(nn.Module):
         o_1 = o_2 = o_3 = None
         if self.use_fast_path:
             if self.bimamba_type == "v3":
-                if seqlen % self.nslices != 0:
-                    raise RuntimeError(f"Mamba v3: seqlen {seqlen} must be divisible by nslices {self.nslices}")
-                ns = self.nslices
-                fused = tri_order.supported(xz)
-                if fused:   # flip + slice-interleave in one pass; the three input gradients meet in one kernel
-                    xz_a, xz_f, xz_s = tri_order.tri_split(xz, ns)
-                else:
-                    xz_a, xz_f = xz, xz.flip([-1])
-                    # token i of slice s -> position i*nslices + s   (mamba_simple.py:245-247)
-                    xz_s = xz.reshape(batch, 2 * self.d_inner, ns, seqlen // ns).transpose(-1, -2) \
-                        .reshape(batch, 2 * self.d_inner, seqlen)
-                out = self._branch(xz_a, "")
-                out_b = self._branch(xz_f, "_b")
-                out_sp = self._branch(xz_s, "_s")          # still in slice-interleaved order
-                unslice = lambda t: t.reshape(batch, self.d_inner, seqlen // ns, ns).permute(0, 1, 3, 2).flatten(-2)  # noqa: E731
-                if self.return_branch_outputs:             # (out, o_1, o_2, o_3) of mamba_simple.py:267-270,362
-                    o_1, o_2, o_3 = out, out_b, unslice(out_sp)
-                if fused and tri_order.supported(out, out_b, out_sp):
-                    total = tri_order.tri_combine(out, out_b, out_sp, ns)
-                else:
-                    total = out + out_b.flip([-1]) + (o_3 if o_3 is not None else unslice(out_sp))
+                total, o_1, o_2, o_3 = self._v3(xz, batch, seqlen)
                 out = self._out_proj(total)
             elif self.bimamba_type == "v2":
                 out = self._branch(xz, "")

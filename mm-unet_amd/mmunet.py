@@ -293,8 +293,10 @@ class RCG(nn.Module):
         # tri-directional Mamba at 2x resolution (MMUNet.py:398-412)
         x0 = self.upsample(x2)
         B, C, H, W = x0.shape
-        out, _, _, _ = self.mamba(x0.reshape(B, C, H * W).transpose(-1, -2))
-        x0 = self.downsample(out.transpose(-1, -2).reshape(B, C, H, W))
+        # (channels-first entry: same block as self.mamba(x0.flatten(2).transpose(1, 2)), without the
+        # (B, L, C) round trip -- 134 MB transposing copies each way at 256 x 256)
+        out, _, _, _ = self.mamba.forward_bcl(x0.reshape(B, C, H * W))
+        x0 = self.downsample(out.reshape(B, C, H, W))
         return x0 * self.mlp(x2) * x2 + f
 
 

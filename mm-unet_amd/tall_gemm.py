@@ -93,3 +93,51 @@ class _DscGemmFn(torch.autograd.Function):
 def dsc_gemm(W2, samples, batch):
     """(Cout, Cin*K) x (Cin*K, B*T) tokens-last samples -> (B, Cout, T)."""
     return _DscGemmFn.apply(W2, samples, batch)
+
+
+class _ProjBclFn(torch.autograd.Function):
+    """``W (O, I)`` applied per batch item between the two layouts that meet at the Mamba block of RCG
+    (MMUNet.py:398-412): feature maps are ``[B][C][L]`` (batch-major), the fused Mamba path works on
+    ``[C][B][L]`` (tokens-last).  ``to_cb=True``:  X (B, I, L) contiguous -> (B, O, L) tensor laid out
+    [O][B][L];  ``to_cb=False``: X (B, I, L) laid out [I][B][L] -> (B, O, L) contiguous.  Each batch item is
+    one GEMM whose strided operand / result is addressed in place (leading dimension B*L), so neither side is
+    ever transposed or copied (the reference's ``(B, L, C)`` interface costs a 134 MB transposing copy each
+    way at 256 x 256, plus one more for the weight gradient).  Weight gradient: split-K per batch item."""
+
+    @staticmethod
+    def forward(ctx, W, X, to_cb):
+        B, I, L = X.shape
+        O = W.shape[0]
+        if to_cb:
+            out = torch.empty((O, B, L), device=X.device, dtype=X.dtype).permute(1, 0, 2)   # [O][B][L]
+        else:
+            out = torch.empty((B, O, L), device=X.device, dtype=X.dtype)
+        for b in range(B):
+            torch.mm(W, X[b], out=out[b])
+        ctx.save_for_backward(W, X)
+        ctx.to_cb = to_cb
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        W, X = ctx.saved_tensors
+        B, I, L = X.shape
+        dW = dX = None
+        if ctx.needs_input_grad[1]:
+            if ctx.to_cb:
+                dX = torch.empty((B, I, L), device=X.device, dtype=X.dtype)
+            else:
+                dX = torch.empty((I, B, L), device=X.device, dtype=X.dtype).permute(1, 0, 2)
+            Wt = W.t()
+            for b in range(B):
+                torch.mm(Wt, G[b], out=dX[b])
+        if ctx.needs_input_grad[0]:
+            dW = nt_splitk(G[0], X[0])
+            for b in range(1, B):
+                dW = dW + nt_splitk(G[b], X[b])
+            dW = dW.to(W.dtype)
+        return dW, dX, None
+
+
+def proj_bcl(W, X, to_cb):
+    return _ProjBclFn.apply(W, X, to_cb)

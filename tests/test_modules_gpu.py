@@ -427,6 +427,31 @@ def test_bn_act_vs_modules(cfg):
     close(bn_d.running_var, bn.running_var, 1e-4, 1e-5, "running_var")
 
 
+def test_mamba_v3_forward_bcl_matches_forward():
+    """Mamba.forward_bcl(x) == forward(x.transpose(1, 2)) transposed back: outputs and every gradient."""
+    from mm_unet_amd.mamba_simple import Mamba
+    torch.manual_seed(5)
+    m = Mamba(d_model=16, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=8).to(DEV)
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 16, 512, generator=gen).to(DEV)
+    g = torch.randn(2, 16, 512, generator=gen).to(DEV)
+    xa = x.clone().requires_grad_()
+    ra = m(xa.transpose(1, 2))
+    ra[0].transpose(1, 2).backward(g)
+    ga = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    xb = x.clone().requires_grad_()
+    rb = m.forward_bcl(xb)
+    rb[0].backward(g)
+    close(rb[0], ra[0].transpose(1, 2), 1e-4, 1e-4, "out")
+    for i in (1, 2, 3):
+        close(rb[i], ra[i], 1e-4, 1e-4, f"o_{i}")
+    close(xb.grad, xa.grad, 1e-3, 1e-4, "d x")
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            close(p.grad, ga[k], 2e-3, 1e-3, k)
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
