@@ -68,6 +68,7 @@ class _DscGemmFn(torch.autograd.Function):
     gradient is brought to tokens-last once; dX = W2^T @ G lands in the samples' layout, dW uses split-K."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, W2, samples, batch):
         O, I = W2.shape
         T = samples.shape[1] // batch
@@ -77,8 +78,10 @@ class _DscGemmFn(torch.autograd.Function):
         return torch.bmm(W2.unsqueeze(0).expand(batch, O, I), Xb)         # (B, O, T) contiguous
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, G):
         W2, samples = ctx.saved_tensors
+        G = G.float()
         B = ctx.batch
         O = W2.shape[0]
         G2 = G.permute(1, 0, 2).reshape(O, -1)                             # (O, B*T): the one small copy
@@ -105,6 +108,7 @@ class _ProjBclFn(torch.autograd.Function):
     way at 256 x 256, plus one more for the weight gradient).  Weight gradient: split-K per batch item."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, W, X, to_cb):
         B, I, L = X.shape
         O = W.shape[0]
@@ -119,8 +123,10 @@ class _ProjBclFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, G):
         W, X = ctx.saved_tensors
+        G = G.float()
         B, I, L = X.shape
         dW = dX = None
         if ctx.needs_input_grad[1]:

@@ -170,6 +170,22 @@ def test_mmnet_bf16_autocast_smoke():
     assert float((lb.float().cpu() - ref).abs().max()) < 0.3 * max(1.0, float(ref.abs().max()))
 
 
+def test_mmnet_bf16_autocast_train_step_large_maps():
+    """A bf16-autocast training step at a size where the split-K / strided-GEMM paths are taken
+    (B*H*W >= 8192 pixels in the first MMConv stage): runs, finite loss and gradients."""
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    m = _mmnet().train()
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 256, 256, generator=gen).to(DEV)
+    t = (torch.rand(2, 1, 256, 256, generator=gen) > 0.88).float().to(DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(x)
+    loss = DICE_BCE_Loss()(out.float(), t)
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_dropin_module_names():
     import sys
     import mm_unet_amd.dropin as dropin
