@@ -100,7 +100,8 @@ class GnBnActFn(torch.autograd.Function):
 
 
 def supported(x, gn, bn=None):
-    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled() and \
+    # (fp32 activations also under autocast: group_norm / batch_norm are on autocast's fp32 list anyway)
+    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and \
         x.shape[0] * x.shape[1] < 65536 and isinstance(gn, nn.GroupNorm)
     if bn is not None:
         ok = ok and isinstance(bn, nn.BatchNorm2d) and (bn.track_running_stats or bn.training) and \
@@ -109,7 +110,7 @@ def supported(x, gn, bn=None):
 
 
 def bn_act_supported(x, bn):
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled() and \
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and \
         x.shape[0] * x.shape[1] < 65536 and isinstance(bn, nn.BatchNorm2d) and bn.affine and \
         (bn.track_running_stats or bn.training) and bn.momentum is not None
 
