@@ -1,10 +1,29 @@
 """Plain U-Net of the reference's top-level ``model.py`` (:5-85): ``Unet(in_channels, classes)`` with
 ``InConv`` / ``Down`` / ``Up`` / ``OutConv``.  Same sub-module names and creation order, so
-state_dicts and seeds are interchangeable.  Pure ATen ops (MIOpen on the GPU); this is the model
-BASELINE config 1 runs on CPU as a plumbing check."""
+state_dicts and seeds are interchangeable.  ATen ops (MIOpen convolutions on the GPU); on the GPU every
+BatchNorm2d -> ReLU pair runs as one fused normalisation (norm_fused.bn_act: two passes over the activation
+each way instead of five).  This is also the model BASELINE config 1 runs on CPU as a plumbing check (there
+the plain modules run)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import norm_fused
+
+
+def _conv_bn_relu(seq, x):
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.BatchNorm2d) and norm_fused.bn_act_supported(x, m):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = norm_fused.bn_act(x, m, "relu" if relu else None)
+            i += 2 if relu else 1
+            continue
+        x = m(x)
+        i += 1
+    return x
 
 
 class InConv(nn.Module):
@@ -16,7 +35,7 @@ class InConv(nn.Module):
                                   nn.ReLU(inplace=True))
 
     def forward(self, x):
-        return self.conv(x)
+        return _conv_bn_relu(self.conv, x)
 
 
 class Down(nn.Module):
