@@ -1402,8 +1402,8 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
                     accC[pi][i] = hsel ? fma_bcast<1>(dy2[k], hh[i], accC[pi][i]) : fma_bcast<0>(dy2[k], hh[i], accC[pi][i]);
                 }
             }
-            dAq[2 * pi] = wave_sum(dAp.x);
-            dAq[2 * pi + 1] = wave_sum(dAp.y);
+            dAq[2 * pi] = dAp.x;      // per-lane partials; reduced over the wave below, all four at once
+            dAq[2 * pi + 1] = dAp.y;
             __builtin_amdgcn_sched_barrier(0);  // one pair at a time: interleaving two doubles the live registers
         }
         put_slots(par ^ 1);  // (the prefetch group has landed long ago)
@@ -1424,13 +1424,10 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
         // partial sums of dA (this wave's 4 states), dD, dbias: row of chunk c0; zeros for chunk c0 + 1
         const unsigned prow = dcur * (unsigned)(N + 2) * 4u, prow1 = prow + (unsigned)p.dim * (N + 2) * 4u;
         {
-            float v = dAq[0];
-            v = lane == 1 ? dAq[1] : v;
-            v = lane == 2 ? dAq[2] : v;
-            v = lane == 3 ? dAq[3] : v;
-            if (lane < 4) {
-                buf_store1(r_part, (n0 + lane) * 4u, prow, v);
-                buf_store1(r_part, (n0 + lane) * 4u, prow1, 0.f);
+            const float v = wave_sum4(dAq[0], dAq[1], dAq[2], dAq[3]);   // lanes 12..15: totals of states n0..n0+3
+            if (lane >= 12 && lane < 16) {
+                buf_store1(r_part, (n0 + lane - 12) * 4u, prow, v);
+                buf_store1(r_part, (n0 + lane - 12) * 4u, prow1, 0.f);
             }
         }
         float ov[4];
