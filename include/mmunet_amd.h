@@ -258,6 +258,7 @@ int mmu_tri_combine(const mmu_tri_params *p, void *stream);
 typedef struct {
     int32_t batch, channels, groups, hw, has_bn, training, act;
     int32_t has_gn;           /* 0: BatchNorm2d [-> act] alone (then groups == channels, has_bn == 1) */
+    int32_t dinput_channel_major;  /* bwd: write dinput as [channels][batch][hw] (for a tokens-last consumer) */
     float gn_eps, bn_eps, momentum;
     const float *input;       /* [batch, channels, hw] */
     const float *gn_weight;   /* [channels] or NULL */

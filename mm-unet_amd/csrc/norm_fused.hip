@@ -324,11 +324,17 @@ __global__ __launch_bounds__(256) void nf_apply_kernel(const float *__restrict__
                                                        const float *__restrict__ A, const float *__restrict__ D,
                                                        const float *__restrict__ c0, const float *__restrict__ c1,
                                                        const float *__restrict__ c2, float *__restrict__ out, int HW,
-                                                       int act) {
+                                                       int act, int out_cb_batch) {
     const int bc = blockIdx.y;
     const float Av = A[bc], Dv = D[bc];
     const float k0 = BWD ? c0[bc] : 0.f, k1 = BWD ? c1[bc] : 0.f, k2 = BWD ? c2[bc] : 0.f;
     const long base = (long)bc * HW;
+    // out_cb_batch = B > 0: the result is written channel-major, [C][B][HW] (dinput for a tokens-last consumer)
+    long obase = base;
+    if (out_cb_batch > 0) {
+        const int C = gridDim.y / out_cb_batch, b = bc / C, c = bc - b * C;
+        obase = ((long)c * out_cb_batch + b) * HW;
+    }
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= HW) return;
     if ((HW & 3) == 0) {
@@ -344,11 +350,11 @@ __global__ __launch_bounds__(256) void nf_apply_kernel(const float *__restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xv[j], Dv), act);
         }
-        *reinterpret_cast<float4 *>(out + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(out + obase + i) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
         for (int j = 0; j < 4 && i + j < HW; ++j) {
             const float xv = x[base + i + j];
-            out[base + i + j] = BWD ? fmaf(k0 * dout[base + i + j], act_grad(fmaf(Av, xv, Dv), act), fmaf(k1, xv, k2))
+            out[obase + i + j] = BWD ? fmaf(k0 * dout[base + i + j], act_grad(fmaf(Av, xv, Dv), act), fmaf(k1, xv, k2))
                                     : act_fwd(fmaf(Av, xv, Dv), act);
         }
     }
@@ -389,7 +395,7 @@ extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
     nf_finalize_fwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
     nf_apply_kernel<false><<<grid, 256, 0, st>>>(p->input, nullptr, a.A, a.D, nullptr, nullptr, nullptr, p->out, a.HW,
-                                                  p->act);
+                                                  p->act, 0);
     MMU_HIP_LAUNCH_CHECK("norm_fused_fwd");
     return 0;
 }
@@ -413,7 +419,8 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     nf_moments_kernel<true><<<BC, 256, 0, st>>>(p->input, p->dout, a.A, a.D, t1, t2, a.HW, p->act);
     nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
-    nf_apply_kernel<true><<<grid, 256, 0, st>>>(p->input, p->dout, a.A, a.D, a.c0, a.c1, a.c2, p->dinput, a.HW, p->act);
+    nf_apply_kernel<true><<<grid, 256, 0, st>>>(p->input, p->dout, a.A, a.D, a.c0, a.c1, a.c2, p->dinput, a.HW, p->act,
+                                                 p->dinput_channel_major ? a.B : 0);
     MMU_HIP_LAUNCH_CHECK("norm_fused_bwd");
     return 0;
 }

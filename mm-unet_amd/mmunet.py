@@ -147,7 +147,7 @@ class MMConv(nn.Module):
         """GroupNorm(K x 1 DSC conv(deformable samples)) -- MMUNet.py:244-265."""
         pre, bias = self.forward_pre_gn(input)
         if norm_fused.supported(pre, self.gn):
-            return norm_fused.gn_bn_act(pre, self.gn, pre_bias=bias)
+            return norm_fused.gn_bn_act(pre, self.gn, pre_bias=bias, grad_channel_major=self.morph == 0)
         return self.gn(pre if bias is None else pre + bias.view(1, -1, 1, 1))
 
     def forward_pre_gn(self, input):
@@ -193,7 +193,8 @@ def run_fused(seq, x):
             bn = mods[i + 1]
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
             if norm_fused.supported(pre, m.gn, bn):
-                x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if relu else None, pre_bias=bias)
+                x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if relu else None, pre_bias=bias,
+                                         grad_channel_major=m.morph == 0)
                 i += 3 if relu else 2
                 continue
             x = m.gn(pre if bias is None else pre + bias.view(1, -1, 1, 1))

@@ -30,7 +30,7 @@ ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
 class GnBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gn_w, gn_b, bn_w, bn_b, pre_bias, run_mean, run_var, groups, gn_eps, has_bn, training, bn_eps,
-                momentum, act):
+                momentum, act, grad_cb=False):
         _lib.require_gpu(x)
         x = x.contiguous()
         B, C, H, W = x.shape
@@ -56,6 +56,7 @@ class GnBnActFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_norm_fused_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats)
         ctx.cfg = (groups, gn_eps, has_bn, training, bn_eps, momentum, act)
+        ctx.grad_cb = bool(grad_cb)
         return out
 
     @staticmethod
@@ -65,7 +66,10 @@ class GnBnActFn(torch.autograd.Function):
         B, C, H, W = x.shape
         dev, f32 = x.device, torch.float32
         g = dout.contiguous()
-        dx = torch.empty_like(x)
+        if ctx.grad_cb:   # the producer of x is a tokens-last GEMM: hand it its gradient as [C][B][HW] (no copy there)
+            dx = torch.empty((C, B, H, W), device=dev, dtype=f32).permute(1, 0, 2, 3)
+        else:
+            dx = torch.empty_like(x)
         L = _lib.lib()
         ws = torch.empty(L.mmu_norm_fused_workspace_floats(B, C, groups), device=dev, dtype=f32)
         grads = torch.empty(5 * C, device=dev, dtype=f32)
@@ -79,6 +83,7 @@ class GnBnActFn(torch.autograd.Function):
         p.has_bn, p.training, p.act, p.has_gn = int(has_bn), int(training), act, int(gn_eps >= 0)
         p.gn_eps, p.bn_eps, p.momentum = max(gn_eps, 0.0), bn_eps, momentum
         p.input, p.dout, p.dinput = x.data_ptr(), g.data_ptr(), dx.data_ptr()
+        p.dinput_channel_major = int(ctx.grad_cb)
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
         p.pre_bias = _lib.ptr(pre_bias)
         p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
@@ -96,7 +101,7 @@ class GnBnActFn(torch.autograd.Function):
             _lib.check(L.mmu_norm_fused_bwd(p, _lib.stream_of(x)))
         return (dx, dgw if gn_w is not None else None, dgb if gn_b is not None else None,
                 dbw if (has_bn and bn_w is not None) else None, dbb if (has_bn and bn_b is not None) else None,
-                dpb if pre_bias is not None else None, None, None, None, None, None, None, None, None, None)
+                dpb if pre_bias is not None else None, None, None, None, None, None, None, None, None, None, None)
 
 
 def supported(x, gn, bn=None):
@@ -126,15 +131,17 @@ def bn_act(x, bn, act=None):
                            -1.0, True, training, bn.eps, bn.momentum, ACT[act])
 
 
-def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None):
+def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False):
     """``act(bn(gn(x + pre_bias[None, :, None, None])))`` with ``gn`` an ``nn.GroupNorm``, ``bn`` an optional
     ``nn.BatchNorm2d`` (its running statistics are updated in training mode exactly as the module would),
     ``act`` in {None, "relu", "tanh"}; ``pre_bias`` (the bias of the convolution that produced ``x``) is folded
-    into the statistics instead of being added to the activation."""
+    into the statistics instead of being added to the activation.  ``grad_channel_major``: return d x laid out
+    [C][B][HW] (what a tokens-last GEMM producer of ``x`` wants; saves it a transposing copy)."""
     has_bn = bn is not None
     training = bool(has_bn and (bn.training or not bn.track_running_stats))
     if has_bn and bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return GnBnActFn.apply(x, gn.weight, gn.bias, bn.weight if has_bn else None, bn.bias if has_bn else None,
                            pre_bias, bn.running_mean if has_bn else None, bn.running_var if has_bn else None, gn.num_groups,
-                           gn.eps, has_bn, training, bn.eps if has_bn else 0.0, bn.momentum if has_bn else 0.0, ACT[act])
+                           gn.eps, has_bn, training, bn.eps if has_bn else 0.0, bn.momentum if has_bn else 0.0, ACT[act],
+                           grad_channel_major)
