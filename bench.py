@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--infer", action="store_true",
+                    help="forward-only (BASELINE config 2) instead of the training step; prints its own metric name")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (the command profiles/r01_roofline_leg_kernel_stats.csv is taken from)")
     ap.add_argument("--cpu-size", type=int, default=512, help="image side of the cpu_baseline sample")
@@ -129,6 +131,30 @@ def main():
         print(json.dumps({"roofline": scan_roofline(dev)}), flush=True)
         return
 
+    if args.infer:
+        from mm_unet_amd.mmunet import MM_Net
+        from mm_unet_amd.train_step import InferStep
+        torch.manual_seed(50)
+        step = InferStep(MM_Net(num_classes=1).to(dev), amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
+                         use_graph=not args.no_graph)
+        gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+        images = torch.randn(args.batch, 3, args.size, args.size, device=dev, generator=gen)
+        for _ in range(args.warmup + 2):
+            step(images)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(images)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(out).all()
+        print(json.dumps({"metric": "images/sec forward (inference), MM-UNet 3x512x512 bs=8 per GPU",
+                          "value": round(args.batch * args.steps / dt, 3), "unit": "images/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                          "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": f"MM_Net eval forward, 3x{args.size}x{args.size}, bs={args.batch}",
+                                     "launch": "eager" if args.no_graph else "hip-graph replay"}}), flush=True)
+        return
     from mm_unet_amd.dp import broadcast_module_state
     from mm_unet_amd.loss import DICE_BCE_Loss
     from mm_unet_amd.mmunet import MM_Net

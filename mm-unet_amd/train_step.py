@@ -93,3 +93,38 @@ class TrainStep:
             self.reducer.finish()
             self.optimizer.step()
         return self._loss
+
+
+class InferStep:
+    """Forward-only counterpart of TrainStep for serving (BASELINE config 2: inference, bs 8, 3x512x512):
+    ``model.eval()`` forward under ``no_grad``, captured into a HIP graph after one eager warm-up call
+    (MIOpen kernel selection) and replayed from then on -- an eager MM_Net forward is ~2,000 launches and
+    host-bound (150 ms for bs 8; the GPU needs a fraction of that).  Shapes are fixed at capture time."""
+
+    def __init__(self, model, amp_dtype=None, use_graph=True):
+        self.model, self.amp_dtype, self.use_graph = model.eval(), amp_dtype, use_graph
+        self._graph = None
+        self._warm = False
+
+    def _forward(self, images):
+        with torch.no_grad():
+            if self.amp_dtype is not None:
+                with torch.autocast(images.device.type, dtype=self.amp_dtype):
+                    return self.model(images)
+            return self.model(images)
+
+    def __call__(self, images):
+        if not self.use_graph:
+            return self._forward(images)
+        if self._graph is None:
+            if not self._warm:
+                self._warm = True
+                return self._forward(images)
+            self._x = images.clone()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._out = self._forward(self._x)
+            torch.cuda.synchronize(images.device)
+        self._x.copy_(images)
+        self._graph.replay()
+        return self._out

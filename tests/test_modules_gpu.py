@@ -186,6 +186,21 @@ def test_mmnet_bf16_autocast_train_step_large_maps():
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
 
 
+def test_infer_step_graph_matches_eager():
+    """InferStep (forward-only HIP graph) returns what the eager eval forward returns, for changing inputs."""
+    from mm_unet_amd.train_step import InferStep
+    m = _mmnet().eval()
+    step = InferStep(m)
+    gen = torch.Generator().manual_seed(8)
+    for i in range(4):
+        x = torch.randn(2, 3, 64, 64, generator=gen).to(DEV)
+        out = step(x).clone()
+        with torch.no_grad():
+            ref = m(x)
+        close(out, ref, 1e-4, 1e-4, f"call {i}")
+    assert step._graph is not None
+
+
 def test_dropin_module_names():
     import sys
     import mm_unet_amd.dropin as dropin
