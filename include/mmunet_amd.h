@@ -266,12 +266,15 @@ typedef struct {
     const float *bn_weight;   /* [channels] or NULL */
     const float *bn_bias;     /* [channels] or NULL */
     const float *pre_bias;    /* [channels] or NULL: normalise input + pre_bias[c] (the bias of the conv before) */
+    const float *residual;    /* fwd, or NULL: out = relu(norm(input) + residual)  (ResidualBlock, MMUNet.py:455-467) */
     float *running_mean;      /* [channels]: updated in training mode (may be NULL), used in eval mode */
     float *running_var;
     float *out;               /* fwd */
     float *s1, *s2, *mu, *rstd, *bn_mean, *bn_rstd, *scale, *shift;   /* saved statistics */
     const float *dout;        /* bwd */
+    const float *act_out;     /* bwd, residual mode: the forward output (its sign is the ReLU mask) */
     float *dinput;            /* bwd */
+    float *dresidual;         /* bwd, residual mode: gradient of the residual input */
     float *dgn_weight, *dgn_bias, *dbn_weight, *dbn_bias, *dpre_bias; /* bwd, each optional */
     float *workspace;         /* bwd */
 } mmu_norm_params;

@@ -88,9 +88,10 @@ class NormParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "channels", "groups", "hw", "has_bn", "training", "act", "has_gn",
                                        "dinput_channel_major")]
                 + [(n, ctypes.c_float) for n in ("gn_eps", "bn_eps", "momentum")]
-                + [(n, _vp) for n in ("input", "gn_weight", "gn_bias", "bn_weight", "bn_bias", "pre_bias", "running_mean",
+                + [(n, _vp) for n in ("input", "gn_weight", "gn_bias", "bn_weight", "bn_bias", "pre_bias", "residual",
+                                      "running_mean",
                                       "running_var", "out", "s1", "s2", "mu", "rstd", "bn_mean", "bn_rstd", "scale",
-                                      "shift", "dout", "dinput", "dgn_weight", "dgn_bias", "dbn_weight", "dbn_bias",
+                                      "shift", "dout", "act_out", "dinput", "dresidual", "dgn_weight", "dgn_bias", "dbn_weight", "dbn_bias",
                                       "dpre_bias", "workspace")])
 
 

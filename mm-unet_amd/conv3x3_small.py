@@ -22,7 +22,13 @@ class Conv3x3SmallFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         _lib.require_gpu(x, weight)
+        if not supported(x, weight) or weight.shape[1] != x.shape[1] or \
+                (bias is not None and (bias.dtype != torch.float32 or bias.numel() != weight.shape[0])):
+            raise RuntimeError("conv3x3_small: float32 NCHW input, [CO, Cin, 3, 3] float32 weight with CO in "
+                               f"{SUPPORTED_CO} and a float32 bias of CO elements required")
         x = x.contiguous()
+        weight = weight.contiguous()
+        bias = bias.contiguous() if bias is not None else None
         B, Cin, H, W = x.shape
         CO = weight.shape[0]
         wt = weight.permute(1, 2, 3, 0).contiguous()          # [Cin][3][3][CO]
@@ -45,7 +51,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
         x, wt = ctx.saved_tensors
         B, Cin, H, W = x.shape
         CO = ctx.wshape[0]
-        g = dout.contiguous()
+        g = dout.float().contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = dw = db = None
         if need_x:

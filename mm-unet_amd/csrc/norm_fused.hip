@@ -51,11 +51,12 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 // moments per (b, c): grid (B*C), block 256.  BWD: t1 = sum g2, t2 = sum g2 x with g2 = dout * act'(A x + D)
+// act_out (BWD, residual mode): the forward output relu(A x + D + residual); its sign is the ReLU mask
 template <bool BWD>
 __global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict__ x, const float *__restrict__ dout,
                                                          const float *__restrict__ A, const float *__restrict__ D,
                                                          float *__restrict__ m1, float *__restrict__ m2, int HW,
-                                                         int act) {
+                                                         int act, const float *__restrict__ act_out) {
     __shared__ float red[8];
     const long base = (long)blockIdx.x * HW;
     const float Av = BWD ? A[blockIdx.x] : 0.f, Dv = BWD ? D[blockIdx.x] : 0.f;
@@ -63,15 +64,21 @@ __global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict
     if ((HW & 3) == 0) {
         const float4 *xp = reinterpret_cast<const float4 *>(x + base);
         const float4 *gp = BWD ? reinterpret_cast<const float4 *>(dout + base) : nullptr;
+        const float4 *op = (BWD && act_out) ? reinterpret_cast<const float4 *>(act_out + base) : nullptr;
         for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
             const float4 v = xp[i];
             const float xv[4] = {v.x, v.y, v.z, v.w};
             if (BWD) {
                 const float4 g = gp[i];
                 const float gv[4] = {g.x, g.y, g.z, g.w};
+                float ov[4] = {0.f, 0.f, 0.f, 0.f};
+                if (op) {
+                    const float4 o = op[i];
+                    ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float g2 = gv[j] * act_grad(fmaf(Av, xv[j], Dv), act);
+                    const float g2 = gv[j] * (op ? (ov[j] > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv[j], Dv), act));
                     s1 += g2;
                     s2 = fmaf(g2, xv[j], s2);
                 }
@@ -87,7 +94,8 @@ __global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             const float xv = x[base + i];
             if (BWD) {
-                const float g2 = dout[base + i] * act_grad(fmaf(Av, xv, Dv), act);
+                const float g2 = dout[base + i] * (act_out ? (act_out[base + i] > 0.f ? 1.f : 0.f)
+                                                           : act_grad(fmaf(Av, xv, Dv), act));
                 s1 += g2;
                 s2 = fmaf(g2, xv, s2);
             } else {
@@ -324,7 +332,9 @@ __global__ __launch_bounds__(256) void nf_apply_kernel(const float *__restrict__
                                                        const float *__restrict__ A, const float *__restrict__ D,
                                                        const float *__restrict__ c0, const float *__restrict__ c1,
                                                        const float *__restrict__ c2, float *__restrict__ out, int HW,
-                                                       int act, int out_cb_batch) {
+                                                       int act, int out_cb_batch, const float *__restrict__ res,
+                                                       float *__restrict__ dres) {
+    // res: FWD = residual added before the activation; BWD = the forward output (ReLU mask).  dres: BWD only.
     const int bc = blockIdx.y;
     const float Av = A[bc], Dv = D[bc];
     const float k0 = BWD ? c0[bc] : 0.f, k1 = BWD ? c1[bc] : 0.f, k2 = BWD ? c2[bc] : 0.f;
@@ -340,22 +350,37 @@ __global__ __launch_bounds__(256) void nf_apply_kernel(const float *__restrict__
     if ((HW & 3) == 0) {
         const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
         const float xv[4] = {v.x, v.y, v.z, v.w};
-        float o[4];
+        float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (res) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(res + base + i);
+            rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+        }
         if (BWD) {
             const float4 g = *reinterpret_cast<const float4 *>(dout + base + i);
             const float gv[4] = {g.x, g.y, g.z, g.w};
+            float g2[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = fmaf(k0 * gv[j], act_grad(fmaf(Av, xv[j], Dv), act), fmaf(k1, xv[j], k2));
+            for (int j = 0; j < 4; ++j) {
+                g2[j] = gv[j] * (res ? (rv[j] > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv[j], Dv), act));
+                o[j] = fmaf(k0, g2[j], fmaf(k1, xv[j], k2));
+            }
+            if (dres) *reinterpret_cast<float4 *>(dres + base + i) = make_float4(g2[0], g2[1], g2[2], g2[3]);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xv[j], Dv), act);
+            for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xv[j], Dv) + rv[j], act);
         }
         *reinterpret_cast<float4 *>(out + obase + i) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
         for (int j = 0; j < 4 && i + j < HW; ++j) {
             const float xv = x[base + i + j];
-            out[obase + i + j] = BWD ? fmaf(k0 * dout[base + i + j], act_grad(fmaf(Av, xv, Dv), act), fmaf(k1, xv, k2))
-                                    : act_fwd(fmaf(Av, xv, Dv), act);
+            const float rr = res ? res[base + i + j] : 0.f;
+            if (BWD) {
+                const float g2 = dout[base + i + j] * (res ? (rr > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv, Dv), act));
+                out[obase + i + j] = fmaf(k0, g2, fmaf(k1, xv, k2));
+                if (dres) dres[base + i + j] = g2;
+            } else {
+                out[obase + i + j] = act_fwd(fmaf(Av, xv, Dv) + rr, act);
+            }
         }
     }
 }
@@ -391,11 +416,12 @@ extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
               "norm_fused_fwd: eval-mode BatchNorm needs running statistics");
     hipStream_t st = (hipStream_t)stream;
     const int BC = a.B * a.C;
-    nf_moments_kernel<false><<<BC, 256, 0, st>>>(p->input, nullptr, nullptr, nullptr, p->s1, p->s2, a.HW, 0);
+    MMU_CHECK(!p->residual || p->act == ACT_RELU, "norm_fused_fwd: a residual input needs act = ReLU");
+    nf_moments_kernel<false><<<BC, 256, 0, st>>>(p->input, nullptr, nullptr, nullptr, p->s1, p->s2, a.HW, 0, nullptr);
     nf_finalize_fwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
     nf_apply_kernel<false><<<grid, 256, 0, st>>>(p->input, nullptr, a.A, a.D, nullptr, nullptr, nullptr, p->out, a.HW,
-                                                  p->act, 0);
+                                                  p->act, 0, p->residual, nullptr);
     MMU_HIP_LAUNCH_CHECK("norm_fused_fwd");
     return 0;
 }
@@ -416,11 +442,13 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     if ((uintptr_t)a.scratch & 7) a.scratch += 1;  // the first entry of the scratch area is a double array
     a.dgn_w = p->dgn_weight; a.dgn_b = p->dgn_bias; a.dbn_w = p->dbn_weight; a.dbn_b = p->dbn_bias;
     a.dpre_bias = p->pre_bias ? p->dpre_bias : nullptr;
-    nf_moments_kernel<true><<<BC, 256, 0, st>>>(p->input, p->dout, a.A, a.D, t1, t2, a.HW, p->act);
+    MMU_CHECK((p->act_out == nullptr) == (p->dresidual == nullptr) && (!p->act_out || p->act == ACT_RELU),
+              "norm_fused_bwd: act_out and dresidual go together (residual mode, ReLU only)");
+    nf_moments_kernel<true><<<BC, 256, 0, st>>>(p->input, p->dout, a.A, a.D, t1, t2, a.HW, p->act, p->act_out);
     nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
     nf_apply_kernel<true><<<grid, 256, 0, st>>>(p->input, p->dout, a.A, a.D, a.c0, a.c1, a.c2, p->dinput, a.HW, p->act,
-                                                 p->dinput_channel_major ? a.B : 0);
+                                                 p->dinput_channel_major ? a.B : 0, p->act_out, p->dresidual);
     MMU_HIP_LAUNCH_CHECK("norm_fused_bwd");
     return 0;
 }

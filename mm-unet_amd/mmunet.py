@@ -180,8 +180,9 @@ class MMConv(nn.Module):
         return self.dsc_conv_y(morph_sample(input, y_rows)), None
 
 
-def run_fused(seq, x):
-    """``seq(x)`` for an nn.Sequential, with every ``MMConv -> BatchNorm2d [-> ReLU]`` run as the MMConv up
+def run_fused(seq, x, residual=None):
+    """``seq(x)`` (``relu(seq(x) + residual)`` when a residual is given: the tail of a ResidualBlock) for an
+    nn.Sequential, with every ``MMConv -> BatchNorm2d [-> ReLU]`` run as the MMConv up
     to its final GroupNorm followed by ONE fused GroupNorm + BatchNorm + ReLU (norm_fused): 2 passes over the
     activation instead of 8 forward, 2 instead of 13 backward.  Module structure / state_dict are untouched."""
     mods = list(seq)
@@ -193,8 +194,11 @@ def run_fused(seq, x):
             bn = mods[i + 1]
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
             if norm_fused.supported(pre, m.gn, bn):
-                x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if relu else None, pre_bias=bias,
-                                         grad_channel_major=m.morph == 0)
+                last = residual is not None and not relu and i + 2 == len(mods)   # ... -> BN, then + residual, ReLU
+                x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if (relu or last) else None, pre_bias=bias,
+                                         grad_channel_major=m.morph == 0, residual=residual if last else None)
+                if last:
+                    return x
                 i += 3 if relu else 2
                 continue
             x = m.gn(pre if bias is None else pre + bias.view(1, -1, 1, 1))
@@ -207,7 +211,7 @@ def run_fused(seq, x):
             continue
         x = m(x)
         i += 1
-    return x
+    return x if residual is None else torch.relu(x + residual)
 
 
 class HPPF(nn.Module):
@@ -336,10 +340,8 @@ class ResidualBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        x1 = run_fused(self.block1, x)
-        if self.downsample:
-            return self.relu(run_fused(self.block2, x) + x1)
-        return self.relu(x1 + x)
+        # relu(block1(x) + shortcut): the add and the ReLU ride along in block1's last fused normalisation
+        return run_fused(self.block1, x, residual=run_fused(self.block2, x) if self.downsample else x)
 
 
 class MM_Net(nn.Module):

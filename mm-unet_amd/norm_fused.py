@@ -30,7 +30,7 @@ ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
 class GnBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gn_w, gn_b, bn_w, bn_b, pre_bias, run_mean, run_var, groups, gn_eps, has_bn, training, bn_eps,
-                momentum, act, grad_cb=False):
+                momentum, act, grad_cb=False, residual=None):
         _lib.require_gpu(x)
         x = x.contiguous()
         B, C, H, W = x.shape
@@ -49,19 +49,34 @@ class GnBnActFn(torch.autograd.Function):
         p.input, p.out = x.data_ptr(), out.data_ptr()
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
         p.pre_bias = _lib.ptr(pre_bias)
+        ctx.res_dtype = None
+        if residual is not None:
+            if residual.shape != x.shape or residual.device != x.device:
+                raise RuntimeError("gn_bn_act: residual must have the shape / device of the input")
+            ctx.res_dtype = residual.dtype
+            residual = residual.float().contiguous()     # (bf16 under autocast: the sum is fp32 there as well)
+            p.residual = residual.data_ptr()
+        for name, t in (("gn weight", gn_w), ("gn bias", gn_b), ("bn weight", bn_w), ("bn bias", bn_b),
+                        ("pre_bias", pre_bias), ("running_mean", run_mean), ("running_var", run_var)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C
+                                  or t.device != dev):
+                raise RuntimeError(f"gn_bn_act: {name} must be a contiguous float32 vector of {C} elements on {dev}")
+        if x.dtype != torch.float32 or C % groups != 0:
+            raise RuntimeError("gn_bn_act: float32 input with channels divisible by groups required")
         p.running_mean, p.running_var = _lib.ptr(run_mean), _lib.ptr(run_var)
         p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
         p.bn_mean, p.bn_rstd, p.scale, p.shift = bn_mean.data_ptr(), bn_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mmu_norm_fused_fwd(p, _lib.stream_of(x)))
-        ctx.save_for_backward(x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats, out if ctx.has_res else None)
         ctx.cfg = (groups, gn_eps, has_bn, training, bn_eps, momentum, act)
         ctx.grad_cb = bool(grad_cb)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats = ctx.saved_tensors
+        x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats, out_saved = ctx.saved_tensors
         groups, gn_eps, has_bn, training, bn_eps, momentum, act = ctx.cfg
         B, C, H, W = x.shape
         dev, f32 = x.device, torch.float32
@@ -84,6 +99,10 @@ class GnBnActFn(torch.autograd.Function):
         p.gn_eps, p.bn_eps, p.momentum = max(gn_eps, 0.0), bn_eps, momentum
         p.input, p.dout, p.dinput = x.data_ptr(), g.data_ptr(), dx.data_ptr()
         p.dinput_channel_major = int(ctx.grad_cb)
+        dres = None
+        if ctx.has_res:
+            dres = torch.empty_like(x)
+            p.act_out, p.dresidual = out_saved.data_ptr(), dres.data_ptr()
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
         p.pre_bias = _lib.ptr(pre_bias)
         p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
@@ -101,7 +120,8 @@ class GnBnActFn(torch.autograd.Function):
             _lib.check(L.mmu_norm_fused_bwd(p, _lib.stream_of(x)))
         return (dx, dgw if gn_w is not None else None, dgb if gn_b is not None else None,
                 dbw if (has_bn and bn_w is not None) else None, dbb if (has_bn and bn_b is not None) else None,
-                dpb if pre_bias is not None else None, None, None, None, None, None, None, None, None, None, None)
+                dpb if pre_bias is not None else None, None, None, None, None, None, None, None, None, None, None,
+                dres if dres is None else dres.to(ctx.res_dtype))
 
 
 def supported(x, gn, bn=None):
@@ -120,7 +140,7 @@ def bn_act_supported(x, bn):
         (bn.track_running_stats or bn.training) and bn.momentum is not None
 
 
-def bn_act(x, bn, act=None):
+def bn_act(x, bn, act=None, residual=None):
     """``act(bn(x))`` for an ``nn.BatchNorm2d`` (training or eval statistics): the same two-pass kernels with
     the GroupNorm stage switched off -- BatchNorm and ReLU read and write the activation once each way
     together instead of once each."""
@@ -128,15 +148,19 @@ def bn_act(x, bn, act=None):
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return GnBnActFn.apply(x, None, None, bn.weight, bn.bias, None, bn.running_mean, bn.running_var, x.shape[1],
-                           -1.0, True, training, bn.eps, bn.momentum, ACT[act])
+                           -1.0, True, training, bn.eps, bn.momentum, ACT[act], False, residual)
 
 
-def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False):
+def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False, residual=None):
     """``act(bn(gn(x + pre_bias[None, :, None, None])))`` with ``gn`` an ``nn.GroupNorm``, ``bn`` an optional
     ``nn.BatchNorm2d`` (its running statistics are updated in training mode exactly as the module would),
     ``act`` in {None, "relu", "tanh"}; ``pre_bias`` (the bias of the convolution that produced ``x``) is folded
     into the statistics instead of being added to the activation.  ``grad_channel_major``: return d x laid out
-    [C][B][HW] (what a tokens-last GEMM producer of ``x`` wants; saves it a transposing copy)."""
+    [C][B][HW] (what a tokens-last GEMM producer of ``x`` wants; saves it a transposing copy).  ``residual``
+    (needs ``act="relu"``): ``relu(bn(gn(x)) + residual)`` -- the tail of a ResidualBlock (MMUNet.py:455-467) in
+    the same two passes; its gradient ``dout * (out > 0)`` is written by the backward apply pass."""
+    if residual is not None and act != "relu":
+        raise ValueError("gn_bn_act: a residual input needs act='relu'")
     has_bn = bn is not None
     training = bool(has_bn and (bn.training or not bn.track_running_stats))
     if has_bn and bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -144,4 +168,4 @@ def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False)
     return GnBnActFn.apply(x, gn.weight, gn.bias, bn.weight if has_bn else None, bn.bias if has_bn else None,
                            pre_bias, bn.running_mean if has_bn else None, bn.running_var if has_bn else None, gn.num_groups,
                            gn.eps, has_bn, training, bn.eps if has_bn else 0.0, bn.momentum if has_bn else 0.0, ACT[act],
-                           grad_channel_major)
+                           grad_channel_major, residual)

@@ -41,6 +41,8 @@ def _params(ref, ns):
 
 
 def _split(x, ns):
+    if _dense_rows(x) is None or x.shape[2] % ns != 0:
+        raise RuntimeError("tri_split: float32 (B, C, L) tensor with dense rows and L divisible by nslices required")
     xf, xs = _like(x), _like(x)
     p = _params(x, ns)
     p.a, p.flip, p.slice = x.data_ptr(), xf.data_ptr(), xs.data_ptr()
@@ -50,10 +52,12 @@ def _split(x, ns):
 
 
 def _combine(a, bf, cs, ns):
-    if not supported(a, bf, cs):   # gradients can arrive in another layout
-        tag = _dense_rows(a)
-        a = a if tag else a.contiguous()
+    if not supported(a, bf, cs):   # gradients can arrive in another layout (or dtype): bring them to a's
+        if _dense_rows(a) is None:
+            a = a.float().contiguous()
         bf, cs = (t if (_dense_rows(t) == _dense_rows(a)) else _relayout(t, a) for t in (bf, cs))
+    if not supported(a, bf, cs):
+        raise RuntimeError("tri_combine: float32 (B, C, L) tensors with dense rows required")
     out = _like(a)
     p = _params(a, ns)
     p.a, p.flip, p.slice, p.out = a.data_ptr(), bf.data_ptr(), cs.data_ptr(), out.data_ptr()
@@ -93,7 +97,7 @@ class TriCombineFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if _dense_rows(g) is None:
-            g = g.contiguous()
+            g = g.float().contiguous()
         gf, gs = _split(g, ctx.ns)
         return g, gf, gs, None
 

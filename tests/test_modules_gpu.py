@@ -371,6 +371,9 @@ def test_tri_order_split_combine(case):
                                  dict(shape=(2, 8, 12, 10), groups=2, bn=True, act="relu", train=True, pre_bias=True),
                                  dict(shape=(2, 6, 7, 5), groups=3, bn=False, act=None, train=True, pre_bias=True),
                                  dict(shape=(2, 8, 6, 6), groups=4, bn=True, act=None, train=False, pre_bias=True),
+                                 dict(shape=(2, 8, 12, 10), groups=2, bn=True, act="relu", train=True, residual=True),
+                                 dict(shape=(2, 6, 7, 9), groups=3, bn=True, act="relu", train=False, residual=True,
+                                      pre_bias=True),
                                  dict(shape=(3, 6, 16, 16), groups=3, bn=False, act="tanh", train=True),
                                  dict(shape=(2, 16, 9, 7), groups=4, bn=True, act=None, train=True),
                                  dict(shape=(2, 8, 8, 8), groups=2, bn=True, act="relu", train=False),
@@ -406,12 +409,16 @@ def test_gn_bn_act_vs_modules(cfg):
     y = gn(xr if pb is None else xr + pb.view(1, -1, 1, 1))
     if bn is not None:
         y = bn(y)
-    ref = act(y)
+    res = (torch.randn(B, C, H, W, generator=gen)).requires_grad_() if cfg.get("residual") else None
+    ref = act(y if res is None else y + res)
     ref.backward(g)
     xg = x.to(DEV).requires_grad_()
     pbg = pb.detach().to(DEV).requires_grad_() if pb is not None else None
-    out = gn_bn_act(xg, gn_d, bn_d, cfg["act"], pre_bias=pbg)
+    resg = res.detach().to(DEV).requires_grad_() if res is not None else None
+    out = gn_bn_act(xg, gn_d, bn_d, cfg["act"], pre_bias=pbg, residual=resg)
     out.backward(g.to(DEV))
+    if res is not None:
+        close(resg.grad, res.grad, 1e-5, 1e-5, "d residual")
     if pb is not None:
         close(pbg.grad, pb.grad, 1e-3, 1e-3, "d pre_bias")
     close(out, ref, 1e-4, 1e-4, "out")
