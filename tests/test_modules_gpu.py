@@ -201,6 +201,79 @@ def test_infer_step_graph_matches_eager():
     assert step._graph is not None
 
 
+def test_new_ops_at_model_shapes_vs_aten_on_gpu():
+    """The ops that stand in for ATen modules, at the largest shapes MM-UNet runs them at (bs 8, 512 x 512
+    input), against the ATen ops themselves on the same GPU: catches indexing mistakes that small CPU-checked
+    cases cannot (offsets past 2^31 bytes, multi-tile paths, channel slicing)."""
+    import torch.nn.functional as F
+    from mm_unet_amd import tri_order
+    from mm_unet_amd.conv3x3_small import conv3x3_small
+    from mm_unet_amd.norm_fused import bn_act, gn_bn_act
+    from mm_unet_amd.resize import bilinear_resize
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=gen)      # noqa: E731
+
+    # bilinear x2 on [8, 64, 128, 128] (DecoderBlock) and 64 -> 512 (side outputs)
+    for shape, size in (((8, 64, 128, 128), (256, 256)), ((8, 1, 64, 64), (512, 512)), ((8, 64, 256, 256), (128, 128))):
+        x, g = rnd(*shape).requires_grad_(), rnd(shape[0], shape[1], *size)
+        ref = F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+        gx_ref, = torch.autograd.grad(ref, x, g)
+        xo = x.detach().clone().requires_grad_()
+        out = bilinear_resize(xo, size=size)
+        gx, = torch.autograd.grad(out, xo, g)
+        # (source coordinates up to 255 have an fp32 ulp of 1.5e-5; ATen rounds r*o before subtracting the
+        # integer part, the kernel's fma does not -- differences of a few 1e-5 on O(1) values)
+        close(out, ref, 1e-4, 1e-4, f"resize {shape}->{size}")
+        close(gx, gx_ref, 1e-4, 5e-4, f"resize grad {shape}->{size}")
+
+    # offset conv at its largest maps
+    for B, Cin, H in ((8, 64, 256), (8, 128, 128), (8, 512, 16)):
+        x, w, b, g = rnd(B, Cin, H, H).requires_grad_(), (0.1 * rnd(6, Cin, 3, 3)).requires_grad_(), rnd(6).requires_grad_(), rnd(B, 6, H, H)
+        ref = F.conv2d(x, w, b, padding=1)
+        gr = torch.autograd.grad(ref, (x, w, b), g)
+        out = conv3x3_small(x, w, b)
+        go = torch.autograd.grad(out, (x, w, b), g)
+        close(out, ref, 1e-4, 1e-3, f"conv3x3 {Cin}@{H}")
+        for a_, r_, nm in zip(go, gr, ("dx", "dw", "db")):
+            close(a_, r_, 2e-3, 2e-3 * float(r_.abs().max()), f"conv3x3 {nm} {Cin}@{H}")
+
+    # GroupNorm -> BatchNorm -> ReLU on [8, 64, 128, 128] and BatchNorm -> ReLU on [8, 64, 256, 256]
+    import copy
+    x, g = (1.5 * rnd(8, 64, 128, 128) + 0.3).requires_grad_(), rnd(8, 64, 128, 128)
+    gn, bn = torch.nn.GroupNorm(16, 64).to(DEV), torch.nn.BatchNorm2d(64).to(DEV)
+    gn2, bn2 = copy.deepcopy(gn), copy.deepcopy(bn)
+    ref = torch.relu(bn(gn(x)))
+    gr, = torch.autograd.grad(ref, x, g)
+    xo = x.detach().clone().requires_grad_()
+    out = gn_bn_act(xo, gn2, bn2, "relu")
+    go, = torch.autograd.grad(out, xo, g)
+    close(out, ref, 1e-4, 1e-4, "gn_bn_relu")
+    close(go, gr, 1e-3, 1e-4, "gn_bn_relu grad")
+    close(bn2.running_var, bn.running_var, 1e-4, 1e-5, "running_var")
+    x, g = rnd(8, 64, 256, 256).requires_grad_(), rnd(8, 64, 256, 256)
+    bn, bn2 = torch.nn.BatchNorm2d(64).to(DEV), None
+    bn2 = copy.deepcopy(bn)
+    ref = torch.relu(bn(x))
+    gr, = torch.autograd.grad(ref, x, g)
+    xo = x.detach().clone().requires_grad_()
+    out = bn_act(xo, bn2, "relu")
+    go, = torch.autograd.grad(out, xo, g)
+    close(out, ref, 1e-4, 1e-4, "bn_relu")
+    close(go, gr, 1e-3, 1e-4, "bn_relu grad")
+
+    # tri-directional re-orderings at RCG's largest call: [8, 256, 65536] laid out [C][B][L], 64 slices
+    B, C, L, ns = 8, 256, 65536, 64
+    x = rnd(C, B, L).permute(1, 0, 2)
+    xa, xf, xs = tri_order.tri_split(x, ns)
+    assert torch.equal(xf, x.flip([-1]))
+    assert torch.equal(xs, x.reshape(B, C, ns, L // ns).transpose(-1, -2).reshape(B, C, L))
+    del xa, xf, xs
+    a, b_, c = x[:, :128], rnd(128, B, L).permute(1, 0, 2), rnd(128, B, L).permute(1, 0, 2)
+    a = a.contiguous().permute(1, 0, 2).contiguous().permute(1, 0, 2)      # dense [C][B][L] rows
+    ref = a + b_.flip([-1]) + c.reshape(B, 128, L // ns, ns).permute(0, 1, 3, 2).flatten(-2)
+    close(tri_order.tri_combine(a, b_, c, ns), ref, 1e-6, 1e-6, "tri_combine")
+
+
 def test_dropin_module_names():
     import sys
     import mm_unet_amd.dropin as dropin
