@@ -57,6 +57,29 @@ __device__ __forceinline__ void unzig(int l, int H, int W, int &h, int &w) {
     }
 }
 
+// Block-wide sums of NV per-thread values at once (256 threads), added to dst[0..NV) with one float atomic
+// each.  Four values share one wave reduction (wave_sum4), the four waves meet in LDS once: one barrier for
+// all NV values.  (One block_sum per value -- 36 of them for the in_proj weight gradient, two barriers each --
+// made these kernels 20 us for a single workgroup.)  scale: optional factor for the LAST value (NV - 1).
+template <int NV>
+__device__ __forceinline__ void block_sum_many_atomic(const float (&v)[NV], float *lds /* [4][NV4] */, float *dst,
+                                                      int ndst, float last_scale = 1.f) {
+    constexpr int NV4 = (NV + 3) & ~3;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV4; i += 4) {
+        const float r = wave_sum4(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
+                                  i + 3 < NV ? v[i + 3] : 0.f);
+        if (lane >= 12 && lane < 16) lds[w * NV4 + i + lane - 12] = r;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ndst; i += blockDim.x) {
+        float s = lds[i] + lds[NV4 + i] + lds[2 * NV4 + i] + lds[3 * NV4 + i];
+        if (i == NV - 1) s *= last_scale;
+        atomicAdd(dst + i, s);
+    }
+}
+
 // block-wide sum of v (256 threads); result valid in thread 0
 __device__ __forceinline__ float block_sum(float v, float *red) {
     v = wave_sum(v);
@@ -90,7 +113,7 @@ __global__ __launch_bounds__(256) void zigzag_inproj_fwd_kernel(CoordArgs p) {
 // ---- A backward: grid-stride over tokens so the 4K*K weight partials are reduced once per block ---
 template <int K>
 __global__ __launch_bounds__(256) void zigzag_inproj_bwd_kernel(CoordArgs p) {
-    __shared__ float red[4];
+    __shared__ float red[4 * ((4 * K * K + 3) & ~3)];
     const int L = p.H * p.W;
     const long total = (long)p.B * L;
     float dw[4 * K * K];
@@ -121,11 +144,7 @@ __global__ __launch_bounds__(256) void zigzag_inproj_bwd_kernel(CoordArgs p) {
             p.doff[(((long)b * 2 * K + K + k) * p.H + h) * p.W + w] = 0.f;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4 * K * K; ++i) {
-        const float s = block_sum(dw[i], red);
-        if (threadIdx.x == 0) atomicAdd(&p.dwin[i], s);
-    }
+    block_sum_many_atomic<4 * K * K>(dw, red, p.dwin, 4 * K * K);
 }
 
 __device__ __forceinline__ float coord_weight(float altho, float &dwgt_daltho) {
@@ -170,7 +189,8 @@ __global__ __launch_bounds__(256) void coords_outproj_fwd_kernel(CoordArgs p) {
 // ---- B backward ---------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void coords_outproj_bwd_kernel(CoordArgs p) {
-    __shared__ float red[4];
+    constexpr int NV = 2 * K * K + 1, NV4 = (NV + 3) & ~3;   // the out_proj weight gradient and d(altho)
+    __shared__ float red[4 * NV4];
     const int L = p.H * p.W;
     const long total = (long)p.B * L;
     float dwgt_da;
@@ -229,13 +249,13 @@ __global__ __launch_bounds__(256) void coords_outproj_bwd_kernel(CoordArgs p) {
             p.doff[(((long)b * 2 * K + K + k) * p.H + h) * p.W + w] = 0.f;
         }
     }
+    float vals[NV];
 #pragma unroll
-    for (int i = 0; i < 2 * K * K; ++i) {
-        const float s = block_sum(dwo[i], red);
-        if (threadIdx.x == 0) atomicAdd(&p.dwout[i], s);
-    }
-    const float s = block_sum(dwg, red);
-    if (threadIdx.x == 0) atomicAdd(p.daltho, s * dwgt_da);
+    for (int i = 0; i < 2 * K * K; ++i) vals[i] = dwo[i];
+    vals[NV - 1] = dwg;
+    block_sum_many_atomic<NV>(vals, red, p.dwout, 2 * K * K);
+    if (threadIdx.x == 0)
+        atomicAdd(p.daltho, (red[NV - 1] + red[NV4 + NV - 1] + red[2 * NV4 + NV - 1] + red[3 * NV4 + NV - 1]) * dwgt_da);
 }
 
 int check(const mmu_coords_params *p, const char *name) {
