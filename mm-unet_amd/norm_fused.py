@@ -80,7 +80,9 @@ class GnBnActFn(torch.autograd.Function):
         groups, gn_eps, has_bn, training, bn_eps, momentum, act = ctx.cfg
         B, C, H, W = x.shape
         dev, f32 = x.device, torch.float32
-        g = dout.contiguous()
+        g = dout.float().contiguous()
+        if g.shape != x.shape:
+            raise RuntimeError("gn_bn_act backward: gradient shape mismatch")
         if ctx.grad_cb:   # the producer of x is a tokens-last GEMM: hand it its gradient as [C][B][HW] (no copy there)
             dx = torch.empty((C, B, H, W), device=dev, dtype=f32).permute(1, 0, 2, 3)
         else:
