@@ -283,6 +283,26 @@ size_t mmu_norm_fused_workspace_floats(int batch, int channels, int groups);
 int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream);
 int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream);
 
+/* ---- conv1d + SiLU + x_proj + dt_proj of a small Mamba block in one kernel (a5/a6 glue, MMConv's blocks) ---- */
+/* mamba_ssm/ops/selective_scan_interface.py:173-210 for inner width dim in {2, 6}, conv width 4, dt_rank 1,
+ * float32:  conv_out = silu(causal_conv1d(x)),  x_dbl[j] = sum_d x_proj_weight[j][d] conv_out[d]  (rows = dt_rank
+ * + 2*dstate; row 0 = dt),  delta[d] = dt_proj_weight[d] * x_dbl[0].  x / conv_out / delta: [batch, dim, L] with
+ * unit L stride and the strides given (multiples of 4, 16-byte aligned bases); x_dbl: [rows, batch*L]
+ * contiguous, or NULL to skip it (backward recomputation). */
+typedef struct {
+    int32_t batch, dim, seqlen, rows;
+    const float *x;               int64_t x_bs, x_ds;
+    const float *conv_weight;     /* [dim, 4] */
+    const float *conv_bias;       /* [dim] or NULL */
+    const float *x_proj_weight;   /* [rows, dim] */
+    const float *dt_proj_weight;  /* [dim] (dt_rank 1) */
+    float *conv_out;              int64_t conv_bs, conv_ds;
+    float *x_dbl;                 /* [rows, batch*seqlen] or NULL */
+    float *delta;                 int64_t delta_bs, delta_ds;
+} mmu_mamba_pre_params;
+
+int mmu_mamba_pre_small(const mmu_mamba_pre_params *p, void *stream);
+
 /* ---- MMConv glue around its K-channel Mamba, fused ----------------- */
 /* Replaces ~30 tiny PyTorch kernels per MMConv block and direction (src/UM_Net/MMUNet.py:122-193 +
  * requirements/mamba_simple.py:201-205,365): zig-zag token flatten + in_proj (A), and out_proj + inverse

@@ -95,6 +95,13 @@ class NormParams(ctypes.Structure):
                                       "dpre_bias", "workspace")])
 
 
+class MambaPreParams(ctypes.Structure):
+    _fields_ = [("batch", _i32), ("dim", _i32), ("seqlen", _i32), ("rows", _i32),
+                ("x", _vp), ("x_bs", _i64), ("x_ds", _i64), ("conv_weight", _vp), ("conv_bias", _vp),
+                ("x_proj_weight", _vp), ("dt_proj_weight", _vp), ("conv_out", _vp), ("conv_bs", _i64), ("conv_ds", _i64),
+                ("x_dbl", _vp), ("delta", _vp), ("delta_bs", _i64), ("delta_ds", _i64)]
+
+
 class CoordsParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
@@ -109,7 +116,7 @@ EXPORTS = (
     "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
-    "mmu_tri_split", "mmu_tri_combine", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
+    "mmu_tri_split", "mmu_tri_combine", "mmu_mamba_pre_small", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_debug_wave_scan",
 )
 
@@ -144,7 +151,8 @@ def lib():
                      ("mmu_bilinear_resize_fwd", ResizeParams), ("mmu_bilinear_resize_bwd", ResizeParams),
                      ("mmu_conv3x3_small_fwd", Conv3x3sParams), ("mmu_conv3x3_small_bwd", Conv3x3sParams),
                      ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
-                     ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams)):
+                     ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
+                     ("mmu_mamba_pre_small", MambaPreParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]

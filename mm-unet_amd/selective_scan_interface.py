@@ -28,7 +28,7 @@ No CPU path: tensors must live on the GPU, the HIP library must be present.
 import torch
 import torch.nn.functional as F
 
-from . import causal_conv1d_hip, selective_scan_hip
+from . import _lib, causal_conv1d_hip, selective_scan_hip
 from .tall_gemm import nt_splitk
 
 try:  # torch >= 2.4
@@ -112,6 +112,11 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 # ---------------------------------------------------------------------------------------------
 # fused inner function
 # ---------------------------------------------------------------------------------------------
+# conv1d + x_proj + dt_proj of the small (inner width 2 / 6, dt_rank 1) blocks as one kernel; False keeps the
+# three-launch path (tests compare the two)
+PRE_SMALL_FUSED = True
+
+
 def _dbl_view(t):
     """(B, D, L) -> (D, B*L) matrix (a view when t is laid out [D][B][L], as inside mamba_inner)."""
     b, d, l = t.shape
@@ -123,6 +128,40 @@ def _rows_as_bnl(rows, batch, L):
     kernels take B/C with any batch/state stride, so no transpose copy is needed."""
     n = rows.shape[0]
     return rows.view(n, batch, L).permute(1, 0, 2).unsqueeze(1)
+
+
+def _pre_small_ok(x, conv1d_weight, x_proj_weight, delta_proj_weight, B, C, B_proj_bias, C_proj_bias):
+    """The one-kernel conv1d + x_proj + dt_proj (csrc/mamba_pre.hip) covers MMConv's Mamba blocks: inner width
+    2 or 6, conv width 4, dt_rank 1, float32 everywhere, input-dependent B and C without projection biases."""
+    return (x.dtype == torch.float32 and x_proj_weight.dtype == torch.float32
+            and delta_proj_weight.dtype == torch.float32 and x.shape[1] in (2, 6) and conv1d_weight.shape[-1] == 4
+            and delta_proj_weight.shape[1] == 1 and B is None and C is None and B_proj_bias is None
+            and C_proj_bias is None and x.shape[2] % 4 == 0 and x.stride(2) == 1
+            and x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0 and x.data_ptr() % 16 == 0
+            and conv1d_weight.dtype == torch.float32)
+
+
+def _pre_small(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, want_x_dbl):
+    """Returns (conv1d_out, x_dblT or None, delta), conv1d_out/delta laid out [D][B][L]."""
+    batch, dim, L = x.shape
+    rows = x_proj_weight.shape[0]
+    conv = torch.empty((dim, batch, L), dtype=torch.float32, device=x.device).permute(1, 0, 2)
+    delta = torch.empty((dim, batch, L), dtype=torch.float32, device=x.device).permute(1, 0, 2)
+    x_dblT = torch.empty((rows, batch * L), dtype=torch.float32, device=x.device) if want_x_dbl else None
+    cw = conv1d_weight.contiguous()
+    wx = x_proj_weight.contiguous()
+    wdt = delta_proj_weight.contiguous()
+    p = _lib.MambaPreParams()
+    p.batch, p.dim, p.seqlen, p.rows = batch, dim, L, rows
+    p.x, p.x_bs, p.x_ds = x.data_ptr(), x.stride(0), x.stride(1)
+    p.conv_weight, p.conv_bias = cw.data_ptr(), _lib.ptr(conv1d_bias)
+    p.x_proj_weight, p.dt_proj_weight = wx.data_ptr(), wdt.data_ptr()
+    p.conv_out, p.conv_bs, p.conv_ds = conv.data_ptr(), conv.stride(0), conv.stride(1)
+    p.x_dbl = _lib.ptr(x_dblT)
+    p.delta, p.delta_bs, p.delta_ds = delta.data_ptr(), delta.stride(0), delta.stride(1)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().mmu_mamba_pre_small(p, _lib.stream_of(x)))
+    return conv, x_dblT, delta
 
 
 def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias):
@@ -166,13 +205,23 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     conv1d_weight = conv1d_weight.view(conv1d_weight.shape[0], conv1d_weight.shape[-1])  # "d 1 w -> d w"
     x, z = xz.chunk(2, dim=1)
     conv1d_bias = conv1d_bias.contiguous() if conv1d_bias is not None else None
-    conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
     ctx.is_variable_B = B is None
     ctx.is_variable_C = C is None
     ctx.B_proj_bias_is_None = B_proj_bias is None
     ctx.C_proj_bias_is_None = C_proj_bias is None
-    x_dblT, delta, B, C = _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias,
-                                   C_proj_bias)
+    _lib.require_gpu(x)
+    ctx.pre_small = (PRE_SMALL_FUSED and (conv1d_bias is None or conv1d_bias.dtype == torch.float32)
+                     and _pre_small_ok(x, conv1d_weight, x_proj_weight, delta_proj_weight, B, C, B_proj_bias,
+                                       C_proj_bias))
+    if ctx.pre_small:
+        batch_, _, L_ = x.shape
+        conv1d_out, x_dblT, delta = _pre_small(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, True)
+        B = _rows_as_bnl(x_dblT[1:1 + d_state], batch_, L_)
+        C = _rows_as_bnl(x_dblT[1 + d_state:], batch_, L_)
+    else:
+        conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
+        x_dblT, delta, B, C = _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias,
+                                       C_proj_bias)
     if D is not None:
         D = D.contiguous()
     # the un-gated `out` is not kept: this backward recomputes y from the states it rebuilds
@@ -207,7 +256,9 @@ def _inner_backward(ctx, dout):
     d_state = A.shape[-1]
     x, z = xz.chunk(2, dim=1)
     dim = x.shape[1]
-    if ctx.checkpoint_lvl == 1:
+    if ctx.checkpoint_lvl == 1 and ctx.pre_small:
+        conv1d_out, _, delta = _pre_small(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, False)
+    elif ctx.checkpoint_lvl == 1:
         conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
         delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
     if ctx.is_variable_B:

@@ -563,6 +563,38 @@ def test_mamba_v3_forward_bcl_matches_forward():
             close(p.grad, ga[k], 2e-3, 1e-3, k)
 
 
+@pytest.mark.parametrize("d_model", [3, 1])
+def test_mamba_small_block_fused_pre_kernel(d_model):
+    """MMConv's Mamba blocks (inner width 6 / 2, dt_rank 1): the one-kernel conv1d + x_proj + dt_proj path
+    (csrc/mamba_pre.hip) against the three-launch path -- outputs and every gradient."""
+    import mm_unet_amd.selective_scan_interface as ssi
+    from mm_unet_amd.mamba_simple import Mamba
+    torch.manual_seed(7)
+    m = Mamba(d_model=d_model, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=4).to(DEV)
+    assert m.d_inner == 2 * d_model and m.dt_rank == 1
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 1024, d_model, generator=gen).to(DEV)
+    g = torch.randn(2, 1024, d_model, generator=gen).to(DEV)
+    res = {}
+    for fused in (False, True):
+        ssi.PRE_SMALL_FUSED = fused
+        try:
+            m.zero_grad()
+            xa = x.clone().requires_grad_()
+            out = m(xa)
+            out = out[0] if isinstance(out, (tuple, list)) else out
+            out.backward(g)
+        finally:
+            ssi.PRE_SMALL_FUSED = True
+        res[fused] = (out.detach(), xa.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
+                                                      if p.grad is not None})
+    close(res[True][0], res[False][0], 1e-4, 1e-5, "out")
+    close(res[True][1], res[False][1], 1e-3, 1e-5, "d x")
+    assert res[True][2].keys() == res[False][2].keys()
+    for k, v in res[False][2].items():
+        close(res[True][2][k], v, 2e-3, 1e-4, k)
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
