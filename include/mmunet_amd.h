@@ -218,13 +218,17 @@ typedef struct {
     float *dinput;          /* bwd, optional */
     float *dweight;         /* bwd, optional: [out_channels, in_channels, 3, 3] */
     float *dbias;           /* bwd, optional (only with dweight) */
-    float *workspace;       /* fwd: mmu_conv3x3_small_fwd_splits() x (elements of out) floats when splits > 1 */
+    float *workspace;       /* fwd: mmu_conv3x3_small_fwd_splits() x (elements of out) floats when splits > 1;
+                             * bwd: mmu_conv3x3_small_wgrad_workspace_floats() floats or NULL */
 } mmu_conv3x3s_params;
 
 /* small images have too few pixels to fill the chip: the forward then slices the input channels and sums the
  * slices' partial outputs in a fixed order (reproducible); returns the number of slices (1 = no workspace) */
 int mmu_conv3x3_small_fwd_splits(int batch, int in_channels, int height, int width);
 int mmu_conv3x3_small_fwd(const mmu_conv3x3s_params *p, void *stream);
+/* bwd with dweight: floats of workspace that select the deterministic row-walking weight-gradient kernels
+ * (0 = shape not covered: width/4 must be a power of two <= 64; without workspace the atomic kernel runs) */
+size_t mmu_conv3x3_small_wgrad_workspace_floats(int batch, int in_channels, int out_channels, int height, int width);
 int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream);
 
 /* ---- token re-orderings of the tri-directional Mamba block (first step) ---- */

@@ -116,6 +116,7 @@ EXPORTS = (
     "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
+    "mmu_conv3x3_small_wgrad_workspace_floats",
     "mmu_tri_split", "mmu_tri_combine", "mmu_mamba_pre_small", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_debug_wave_scan",
 )
@@ -158,6 +159,8 @@ def lib():
         fn.argtypes = [ctypes.POINTER(st), _vp]
     L.mmu_conv3x3_small_fwd_splits.restype = ctypes.c_int
     L.mmu_conv3x3_small_fwd_splits.argtypes = [ctypes.c_int] * 4
+    L.mmu_conv3x3_small_wgrad_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_norm_fused_workspace_floats.restype = ctypes.c_size_t
     L.mmu_norm_fused_workspace_floats.argtypes = [ctypes.c_int] * 3
     L.mmu_debug_wave_scan.restype = ctypes.c_int

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 SUPPORTED_CO = (1, 2, 6, 8)
-WEIGHT_GRAD_NATIVE = False   # True: mmu_conv3x3_small_bwd also computes dweight / dbias (tests cover both)
+WEIGHT_GRAD_NATIVE = True    # False: weight / bias gradient from ATen (MIOpen); tests cover both
 
 
 def supported(x, weight):
@@ -69,11 +69,14 @@ class Conv3x3SmallFn(torch.autograd.Function):
                 p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
                 p.input, p.weight_t, p.dout = x.data_ptr(), wt.data_ptr(), g.data_ptr()
                 p.dweight, p.dbias = dw.data_ptr(), _lib.ptr(db)
+                nws = _lib.lib().mmu_conv3x3_small_wgrad_workspace_floats(B, Cin, CO, H, W)
+                ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+                p.workspace = _lib.ptr(ws)
                 with torch.cuda.device(x.device):
                     _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
             else:
-                # the reduction over all pixels is where MIOpen's implicit-GEMM weight-gradient kernel is still
-                # ahead of the direct one (45 us vs 60-250 us on the larger maps)
+                # ATen / MIOpen weight gradient (kept for comparison: its implicit-GEMM kernel plus layout
+                # transposes take 50-110 us where the row-walking kernel needs a fraction of that)
                 w = wt.permute(3, 0, 1, 2)
                 _, dw, db = torch.ops.aten.convolution_backward(
                     g, x, w, [CO] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,

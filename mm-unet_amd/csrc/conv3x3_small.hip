@@ -253,6 +253,115 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_weight_kernel(const float *_
     }
 }
 
+// ---- weight gradient, row-walking form --------------------------------------------------------------------
+// dW[co][ci][ky][kx] = sum_{b,h,w} g[b][co][h][w] x[b][ci][h+ky-1][w+kx-1] is a reduction over every pixel with
+// CO*9 results per input channel: ~0.5 GFLOP and 36 MB of reads for [8, 64, 128, 128] -- a memory-bound op that
+// MIOpen's implicit-GEMM kernel (with its NCHW->NHWC transposes and zero-fills) needs 107 us for.
+// wave = one input channel (wave-uniform), lanes = (W/4 column groups) x (64 / (W/4) row strips); a lane walks
+// down its strip with a rolling 3-row window: ONE 16-byte x load and CO 16-byte g loads per 4 pixels and
+// CO*36 FMAs; the left / right halo pixels come from the neighbouring lanes (ds_bpermute), not from memory.
+// No integer division anywhere (the first version spent its time in 64-bit div/mod).  Each wave writes its
+// CO*10 partial sums (wave_sum4 batches) to part[block][ci][*]; a second kernel adds the blocks in fixed
+// order: deterministic, no atomics, no zero-fill.
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3s_wgrad_rows_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                                  float *__restrict__ part, int Cin, int H, int W,
+                                                                  int lwq, int rs) {
+    constexpr int NV = CO * 10, NV4 = (NV + 3) & ~3;
+    const int lane = threadIdx.x & 63;
+    const int ci = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (ci >= Cin) return;
+    const int b = blockIdx.z;
+    const int wq = 1 << lwq, q = lane & (wq - 1), st = lane >> lwq, S = 64 >> lwq;
+    const int h0 = (blockIdx.x * S + st) * rs;
+    const long HW = (long)H * W;
+    const float *xp = x + ((long)b * Cin + ci) * HW + 4 * q;
+    const float *gp = g + (long)b * CO * HW + 4 * q;
+    const float lm = q > 0 ? 1.f : 0.f, rm = q < wq - 1 ? 1.f : 0.f;
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    float r0[6], r1[6], r2[6];
+    auto load_row = [&](int hh, float(&r)[6]) {
+        const float m = (hh >= 0 && hh < H) ? 1.f : 0.f;
+        const int hc = hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh);
+        const float4 c = *reinterpret_cast<const float4 *>(xp + (long)hc * W);
+        r[1] = c.x * m; r[2] = c.y * m; r[3] = c.z * m; r[4] = c.w * m;
+        r[0] = __shfl_up(r[4], 1) * lm;
+        r[5] = __shfl_down(r[1], 1) * rm;
+    };
+    load_row(h0 - 1, r0);
+    load_row(h0, r1);
+    for (int i = 0; i < rs; ++i) {
+        const int h = h0 + i;
+        load_row(h + 1, r2);
+        const float gm = h < H ? 1.f : 0.f;
+        const long go = (long)(h < H ? h : H - 1) * W;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const float4 c = *reinterpret_cast<const float4 *>(gp + co * HW + go);
+            const float gq[4] = {c.x * gm, c.y * gm, c.z * gm, c.w * gm};
+            v[CO * 9 + co] += (gq[0] + gq[1]) + (gq[2] + gq[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    v[co * 9 + kx] = fmaf(gq[j], r0[j + kx], v[co * 9 + kx]);
+                    v[co * 9 + 3 + kx] = fmaf(gq[j], r1[j + kx], v[co * 9 + 3 + kx]);
+                    v[co * 9 + 6 + kx] = fmaf(gq[j], r2[j + kx], v[co * 9 + 6 + kx]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            r0[j] = r1[j];
+            r1[j] = r2[j];
+        }
+    }
+    float *dst = part + (((long)blockIdx.z * gridDim.x + blockIdx.x) * Cin + ci) * NV4;
+#pragma unroll
+    for (int i = 0; i < NV4; i += 4) {
+        const float r = wave_sum4(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
+                                  i + 3 < NV ? v[i + 3] : 0.f);
+        if (lane >= 12 && lane < 16) dst[i + lane - 12] = r;
+    }
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3s_wgrad_sum_kernel(const float *__restrict__ part, float *__restrict__ dW,
+                                                                 float *__restrict__ dbias, int Cin, int nblk) {
+    constexpr int NV = CO * 10, NV4 = (NV + 3) & ~3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * NV4) return;
+    const int ci = idx / NV4, e = idx - ci * NV4;
+    if (e >= NV) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += part[(long)k * Cin * NV4 + idx];
+    if (e < CO * 9) {
+        const int co = e / 9, t = e - co * 9;
+        dW[((long)co * Cin + ci) * 9 + t] = s;
+    } else if (ci == 0 && dbias != nullptr) {
+        dbias[e - CO * 9] = s;
+    }
+}
+
+// rows per strip / row blocks of the row-walking weight gradient; 0 = shape not covered (W/4 must be a power
+// of two <= 64)
+bool wgrad_rows_plan(int B, int Cin, int H, int W, int &lwq, int &rs, int &nrb) {
+    if (W < 4 || (W & 3) != 0) return false;
+    const int wq = W / 4;
+    if (wq > 64 || (wq & (wq - 1)) != 0) return false;
+    lwq = 0;
+    while ((1 << lwq) < wq) ++lwq;
+    const int S = 64 / wq;
+    long want = 4096 / ((long)B * Cin);  // row blocks wanted for ~4096 waves
+    if (want < 1) want = 1;
+    long r = H / (S * want);
+    rs = r < 1 ? 1 : (r > 16 ? 16 : (int)r);
+    nrb = (H + S * rs - 1) / (S * rs);
+    return true;
+}
+
 // how many input-channel slices so that the chip sees >= ~8192 waves (8 per SIMD: the channel loop is a
 // load -> FMA chain per iteration, latency hiding comes from other waves)
 int channel_splits(long threads, int cin) {
@@ -307,6 +416,13 @@ extern "C" int mmu_conv3x3_small_fwd(const mmu_conv3x3s_params *p, void *stream)
     return 0;
 }
 
+extern "C" size_t mmu_conv3x3_small_wgrad_workspace_floats(int batch, int in_channels, int out_channels, int height,
+                                                           int width) {
+    int lwq = 0, rs = 0, nrb = 0;
+    if (batch <= 0 || in_channels <= 0 || !wgrad_rows_plan(batch, in_channels, height, width, lwq, rs, nrb)) return 0;
+    return (size_t)nrb * batch * in_channels * ((out_channels * 10 + 3) & ~3);
+}
+
 extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream) {
     if (int r = check(p, "conv3x3_small_bwd")) return r;
     MMU_CHECK(p->dout && p->weight_t, "conv3x3_small_bwd: dout and weight_t are required");
@@ -321,7 +437,22 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
                                          p->width, cps);)
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(data)");
     }
-    if (p->dweight) {
+    int lwq = 0, rs = 0, nrb = 0;
+    if (p->dweight && p->workspace && wgrad_rows_plan(p->batch, p->in_channels, p->height, p->width, lwq, rs, nrb)) {
+        MMU_CHECK(p->input, "conv3x3_small_bwd: input is required for dweight");
+        MMU_CHECK(((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->dout & 15) == 0,
+                  "conv3x3_small_bwd: input and dout must be 16-byte aligned");
+        dim3 grid(nrb, (p->in_channels + 3) / 4, p->batch);
+        CO_DISPATCH(p->out_channels, {
+            conv3x3s_wgrad_rows_kernel<CO><<<grid, 256, 0, st>>>(p->input, p->dout, p->workspace, p->in_channels,
+                                                                 p->height, p->width, lwq, rs);
+            MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight rows)");
+            constexpr int NV4 = (CO * 10 + 3) & ~3;
+            conv3x3s_wgrad_sum_kernel<CO><<<(p->in_channels * NV4 + 255) / 256, 256, 0, st>>>(
+                p->workspace, p->dweight, p->dbias, p->in_channels, nrb * p->batch);
+        })
+        MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight sum)");
+    } else if (p->dweight) {
         MMU_CHECK(p->input, "conv3x3_small_bwd: input is required for dweight");
         hipError_t e = hipMemsetAsync(p->dweight, 0, sizeof(float) * (size_t)p->out_channels * p->in_channels * 9, st);
         if (e == hipSuccess && p->dbias) e = hipMemsetAsync(p->dbias, 0, sizeof(float) * p->out_channels, st);
