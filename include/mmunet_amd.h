@@ -307,6 +307,29 @@ typedef struct {
 
 int mmu_mamba_pre_small(const mmu_mamba_pre_params *p, void *stream);
 
+/* The backward mirror (selective_scan_interface.py:268-277), inner width 2 or 6, rows = 33 (dt_rank 1, d_state 16),
+ * float32, every [dim]-row tensor laid out [dim][tokens] (tokens = batch*L, a multiple of 4), 16-byte aligned:
+ *   d dt = dt_proj_weight^T ddelta (kept in registers);  ddt_proj_weight[d] = sum_t ddelta[d][t] dt[t];
+ *   dx_proj_weight[j][d] = sum_t dx_dbl[j][t] conv_out[d][t]  (row 0 of dx_dbl = d dt, rows 1.. read from dx_dbl);
+ *   dconv_out[d][t] += sum_j x_proj_weight[j][d] dx_dbl[j][t]   (in place). */
+typedef struct {
+    int32_t dim, rows;
+    int64_t tokens;
+    const float *ddelta;          /* [dim][tokens] */
+    const float *dt;              /* [tokens] = row 0 of x_dbl */
+    const float *dx_dbl;          /* [rows][tokens]; row 0 is ignored */
+    const float *conv_out;        /* [dim][tokens] */
+    float *dconv_out;             /* [dim][tokens], in/out */
+    const float *x_proj_weight;   /* [rows][dim] */
+    const float *dt_proj_weight;  /* [dim] */
+    float *dx_proj_weight;        /* [rows][dim] out */
+    float *ddt_proj_weight;       /* [dim] out */
+    float *workspace;             /* mmu_mamba_post_small_workspace_floats() floats */
+} mmu_mamba_post_params;
+
+size_t mmu_mamba_post_small_workspace_floats(int dim, int rows, long tokens);
+int mmu_mamba_post_small(const mmu_mamba_post_params *p, void *stream);
+
 /* ---- MMConv glue around its K-channel Mamba, fused ----------------- */
 /* Replaces ~30 tiny PyTorch kernels per MMConv block and direction (src/UM_Net/MMUNet.py:122-193 +
  * requirements/mamba_simple.py:201-205,365): zig-zag token flatten + in_proj (A), and out_proj + inverse

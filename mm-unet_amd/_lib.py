@@ -102,6 +102,12 @@ class MambaPreParams(ctypes.Structure):
                 ("x_dbl", _vp), ("delta", _vp), ("delta_bs", _i64), ("delta_ds", _i64)]
 
 
+class MambaPostParams(ctypes.Structure):
+    _fields_ = ([("dim", _i32), ("rows", _i32), ("tokens", _i64)]
+                + [(n, _vp) for n in ("ddelta", "dt", "dx_dbl", "conv_out", "dconv_out", "x_proj_weight",
+                                      "dt_proj_weight", "dx_proj_weight", "ddt_proj_weight", "workspace")])
+
+
 class CoordsParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
@@ -117,7 +123,8 @@ EXPORTS = (
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
     "mmu_conv3x3_small_wgrad_workspace_floats",
-    "mmu_tri_split", "mmu_tri_combine", "mmu_mamba_pre_small", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
+    "mmu_tri_split", "mmu_tri_combine", "mmu_mamba_pre_small", "mmu_mamba_post_small",
+    "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_debug_wave_scan",
 )
 
@@ -153,7 +160,7 @@ def lib():
                      ("mmu_conv3x3_small_fwd", Conv3x3sParams), ("mmu_conv3x3_small_bwd", Conv3x3sParams),
                      ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
-                     ("mmu_mamba_pre_small", MambaPreParams)):
+                     ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -161,6 +168,8 @@ def lib():
     L.mmu_conv3x3_small_fwd_splits.argtypes = [ctypes.c_int] * 4
     L.mmu_conv3x3_small_wgrad_workspace_floats.restype = ctypes.c_size_t
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
+    L.mmu_mamba_post_small_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_mamba_post_small_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
     L.mmu_norm_fused_workspace_floats.restype = ctypes.c_size_t
     L.mmu_norm_fused_workspace_floats.argtypes = [ctypes.c_int] * 3
     L.mmu_debug_wave_scan.restype = ctypes.c_int

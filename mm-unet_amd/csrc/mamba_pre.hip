@@ -98,3 +98,139 @@ extern "C" int mmu_mamba_pre_small(const mmu_mamba_pre_params *p, void *stream) 
     MMU_HIP_LAUNCH_CHECK("mamba_pre_small");
     return 0;
 }
+
+// ---- backward mirror: everything between the scan backward and the conv1d backward of a small block ----------
+// selective_scan_interface.py:268-277: d dt = W_dt^T d delta; dW_dt = d delta . dt^T; dW_x = d x_dbl . conv^T;
+// d conv += W_x^T d x_dbl -- two split-K products with their reductions, a K = 6 GEMM and a K = 33 addmm (6-8
+// launches of 10-50 us, hipBLASLt at its worst: a [6, 2048] x [2048, 1] product takes 53 us).  Here one thread
+// takes 4 tokens, streams the R = 1 + 2N rows of d x_dbl once (row 0 is formed in registers and never stored),
+// updates d conv in place and keeps the R*D + D weight-gradient sums in registers; wave_sum4 batches + LDS give
+// one partial per workgroup, a second kernel adds the workgroups in fixed order (deterministic, no atomics).
+namespace {
+
+template <int D, int R>
+__global__ __launch_bounds__(256, 1) void mamba_post_small_kernel(const float *__restrict__ ddelta,
+                                                                  const float *__restrict__ dt,
+                                                                  const float *__restrict__ dxdbl,
+                                                                  const float *__restrict__ conv,
+                                                                  float *__restrict__ dconv,
+                                                                  const float *__restrict__ wx,
+                                                                  const float *__restrict__ wdt,
+                                                                  float *__restrict__ part, long T) {
+    constexpr int NV = R * D + D, NV4 = (NV + 3) & ~3;
+    __shared__ float red[4 * NV4];
+    const long ngroups = T >> 2;
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    {   // one group of 4 tokens per thread: a loop here makes the 198 wave-uniform weights loop invariants that
+        // the compiler pins in SGPRs (450 spilled)
+        long gi = (long)blockIdx.x * 256 + threadIdx.x;
+        const float live = gi < ngroups ? 1.f : 0.f;  // lanes past the end re-read the last group with weight 0
+        gi = gi < ngroups ? gi : ngroups - 1;
+        const long col = gi * 4;
+        float cv[D][4], dc[D][4], row[4];
+        const float4 t4 = *reinterpret_cast<const float4 *>(dt + col);
+        const float dtv[4] = {t4.x, t4.y, t4.z, t4.w};
+        row[0] = row[1] = row[2] = row[3] = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(conv + d * T + col);
+            const float4 g4 = *reinterpret_cast<const float4 *>(dconv + d * T + col);
+            const float4 e4 = *reinterpret_cast<const float4 *>(ddelta + d * T + col);
+            cv[d][0] = c4.x * live; cv[d][1] = c4.y * live; cv[d][2] = c4.z * live; cv[d][3] = c4.w * live;
+            dc[d][0] = g4.x; dc[d][1] = g4.y; dc[d][2] = g4.z; dc[d][3] = g4.w;
+            const float e[4] = {e4.x, e4.y, e4.z, e4.w};
+            const float wv = wdt[d];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                row[i] = fmaf(wv, e[i], row[i]);                                  // d dt
+                v[R * D + d] = fmaf(e[i] * live, dtv[i], v[R * D + d]);           // dW_dt
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j > 0) {
+                const float4 r4 = *reinterpret_cast<const float4 *>(dxdbl + (long)j * T + col);
+                row[0] = r4.x; row[1] = r4.y; row[2] = r4.z; row[3] = r4.w;
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float wv = wx[j * D + d];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dc[d][i] = fmaf(wv, row[i], dc[d][i]);
+                    v[j * D + d] = fmaf(row[i], cv[d][i], v[j * D + d]);
+                }
+            }
+        }
+        if (live != 0.f) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                *reinterpret_cast<float4 *>(dconv + d * T + col) = make_float4(dc[d][0], dc[d][1], dc[d][2], dc[d][3]);
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV4; i += 4) {
+        const float r = wave_sum4(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
+                                  i + 3 < NV ? v[i + 3] : 0.f);
+        if (lane >= 12 && lane < 16) red[w * NV4 + i + lane - 12] = r;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256)
+        part[(long)blockIdx.x * NV4 + i] = (red[i] + red[NV4 + i]) + (red[2 * NV4 + i] + red[3 * NV4 + i]);
+}
+
+template <int D, int R>
+__global__ __launch_bounds__(256) void mamba_post_small_sum_kernel(const float *__restrict__ part, float *__restrict__ dwx,
+                                                                   float *__restrict__ dwdt, int nblk) {
+    constexpr int NV = R * D + D, NV4 = (NV + 3) & ~3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NV) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += part[(long)k * NV4 + i];
+    if (i < R * D) dwx[i] = s;
+    else dwdt[i - R * D] = s;
+}
+
+int post_blocks(long tokens) {
+    const long g = (tokens / 4 + 255) / 256;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" size_t mmu_mamba_post_small_workspace_floats(int dim, int rows, long tokens) {
+    if (tokens <= 0 || dim <= 0 || rows <= 0) return 0;
+    return (size_t)post_blocks(tokens) * ((rows * dim + dim + 3) & ~3);
+}
+
+extern "C" int mmu_mamba_post_small(const mmu_mamba_post_params *p, void *stream) {
+    MMU_CHECK(p != nullptr, "mamba_post_small: null params");
+    MMU_CHECK((p->dim == 2 || p->dim == 6) && p->rows == 33,
+              "mamba_post_small: inner width 2 or 6 and 33 rows (dt_rank 1, d_state 16) required (got %d, %d)", p->dim,
+              p->rows);
+    MMU_CHECK(p->tokens > 0 && p->tokens % 4 == 0 && p->tokens <= (1L << 30),
+              "mamba_post_small: tokens must be a positive multiple of 4 (at most 2^30)");
+    MMU_CHECK(p->ddelta && p->dt && p->dx_dbl && p->conv_out && p->dconv_out && p->x_proj_weight &&
+                  p->dt_proj_weight && p->dx_proj_weight && p->ddt_proj_weight && p->workspace,
+              "mamba_post_small: every pointer is required");
+    const void *ptrs[] = {p->ddelta, p->dt, p->dx_dbl, p->conv_out, p->dconv_out};
+    for (const void *q : ptrs) MMU_CHECK(((uintptr_t)q & 15) == 0, "mamba_post_small: tensors must be 16-byte aligned");
+    const int nblk = post_blocks(p->tokens);
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dim == 6) {
+        mamba_post_small_kernel<6, 33><<<nblk, 256, 0, st>>>(p->ddelta, p->dt, p->dx_dbl, p->conv_out, p->dconv_out,
+                                                             p->x_proj_weight, p->dt_proj_weight, p->workspace, p->tokens);
+        MMU_HIP_LAUNCH_CHECK("mamba_post_small");
+        mamba_post_small_sum_kernel<6, 33><<<1, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
+    } else {
+        mamba_post_small_kernel<2, 33><<<nblk, 256, 0, st>>>(p->ddelta, p->dt, p->dx_dbl, p->conv_out, p->dconv_out,
+                                                             p->x_proj_weight, p->dt_proj_weight, p->workspace, p->tokens);
+        MMU_HIP_LAUNCH_CHECK("mamba_post_small");
+        mamba_post_small_sum_kernel<2, 33><<<1, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
+    }
+    MMU_HIP_LAUNCH_CHECK("mamba_post_small(sum)");
+    return 0;
+}

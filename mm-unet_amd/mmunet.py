@@ -27,6 +27,15 @@ from .tall_gemm import dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
 
+def _small_conv3x3(c, input):
+    """A 3x3 / stride 1 / padding 1 ``nn.Conv2d`` with 1, 2, 6 or 8 output channels through the direct kernels of
+    csrc/conv3x3_small.hip (a matrix core has nothing to do there); anything else stays the module's own call."""
+    if conv3x3_small.supported(input, c.weight) and c.stride == (1, 1) and c.padding == (1, 1) and \
+            c.dilation == (1, 1) and c.groups == 1:
+        return conv3x3_small.conv3x3_small(input, c.weight, c.bias)
+    return c(input)
+
+
 class MMConv(nn.Module):
     def __init__(self, in_channels: int = 1, out_channels: int = 1, kernel_size: int = 9, extend_scope: float = 1.0,
                  morph: int = 0, if_offset: bool = True, device=None, num_slices=4, d_state=16):
@@ -137,11 +146,7 @@ class MMConv(nn.Module):
             return morph_coords.coords_outproj(offset, out_z, m.out_proj.weight, self.altho, self.extend_scope)
 
     def _offset_conv(self, input):
-        c = self.offset_conv
-        if conv3x3_small.supported(input, c.weight) and c.stride == (1, 1) and c.padding == (1, 1) and \
-                c.dilation == (1, 1) and c.groups == 1:
-            return conv3x3_small.conv3x3_small(input, c.weight, c.bias)   # 6 output channels: direct kernels
-        return c(input)
+        return _small_conv3x3(self.offset_conv, input)   # 6 output channels: direct kernels
 
     def forward(self, input):
         """GroupNorm(K x 1 DSC conv(deformable samples)) -- MMUNet.py:244-265."""
@@ -394,7 +399,7 @@ class MM_Net(nn.Module):
         d5 = self.decoder5(e5)
         out5 = self.side5(d5)
         c1 = run_fused(self.cbam, e1)   # contour branch on the stride-2 stem features
-        p_c = self.line_predict(c1)
+        p_c = _small_conv3x3(self.line_predict, c1)
         r4 = self.rcg4(out5, c1, e4)
         d4 = self.decoder4(torch.cat((d5, r4), dim=1))
         out4 = self.side4(d4)

@@ -115,6 +115,7 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 # conv1d + x_proj + dt_proj of the small (inner width 2 / 6, dt_rank 1) blocks as one kernel; False keeps the
 # three-launch path (tests compare the two)
 PRE_SMALL_FUSED = True
+POST_SMALL_FUSED = True   # ... and the backward mirror (d x_dbl row 0, both weight gradients, d conv += W_x^T d x_dbl)
 
 
 def _dbl_view(t):
@@ -162,6 +163,34 @@ def _pre_small(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, 
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().mmu_mamba_pre_small(p, _lib.stream_of(x)))
     return conv, x_dblT, delta
+
+
+def _mat_of(t, batch, L):
+    """[D][B][L]-laid-out (B, D, L) tensor -> True when it is also a plain [D][B*L] matrix."""
+    return t.stride(2) == 1 and t.stride(0) == L and t.stride(1) == batch * L and t.data_ptr() % 16 == 0
+
+
+def _post_small(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_weight, delta_proj_weight):
+    """csrc/mamba_pre.hip (backward mirror): returns (dx_proj_weight, ddelta_proj_weight); dconv1d_out is
+    updated in place with W_x^T d x_dbl."""
+    batch, dim, L = ddelta.shape
+    rows = x_proj_weight.shape[0]
+    tokens = batch * L
+    dwx = torch.empty_like(x_proj_weight, memory_format=torch.contiguous_format)
+    dwdt = torch.empty((dim, 1), dtype=torch.float32, device=ddelta.device)
+    nws = _lib.lib().mmu_mamba_post_small_workspace_floats(dim, rows, tokens)
+    ws = torch.empty(nws, dtype=torch.float32, device=ddelta.device)
+    wx = x_proj_weight.contiguous()
+    wdt = delta_proj_weight.contiguous()
+    p = _lib.MambaPostParams()
+    p.dim, p.rows, p.tokens = dim, rows, tokens
+    p.ddelta, p.dt, p.dx_dbl = ddelta.data_ptr(), x_dblT.data_ptr(), dx_dblT.data_ptr()
+    p.conv_out, p.dconv_out = conv1d_out.data_ptr(), dconv1d_out.data_ptr()
+    p.x_proj_weight, p.dt_proj_weight = wx.data_ptr(), wdt.data_ptr()
+    p.dx_proj_weight, p.ddt_proj_weight, p.workspace = dwx.data_ptr(), dwdt.data_ptr(), ws.data_ptr()
+    with torch.cuda.device(ddelta.device):
+        _lib.check(_lib.lib().mmu_mamba_post_small(p, _lib.stream_of(ddelta)))
+    return dwx, dwdt
 
 
 def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias):
@@ -298,17 +327,25 @@ def _inner_backward(ctx, dout):
             _rows_as_bnl(dx_dblT[r + d_state:], batch, L).copy_(dC)
         dC_proj_bias = dx_dblT[r + d_state:].sum(1) if not ctx.C_proj_bias_is_None else None
         dC = None
-    ddelta_m = _dbl_view(ddelta)                                            # (D, B*L)
-    ddelta_proj_weight = nt_splitk(ddelta_m, x_dblT[:r]).to(delta_proj_weight.dtype)  # (D, r)      (:273)
-    torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])         # (r, B*L)              (:274)
-    conv_m = _dbl_view(conv1d_out)
-    dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
-    dconv_m = _dbl_view(dconv1d_out)                                        # (D, B*L)
-    if dconv_m.data_ptr() == dconv1d_out.data_ptr():
-        dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
-    else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
-        dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dblT)
-    dconv1d_out = dconv_m.view(dim, batch, L).permute(1, 0, 2)
+    post_small = (ctx.pre_small and POST_SMALL_FUSED and direct and x_dblT.shape[0] == 33 and x_dblT.is_contiguous()
+                  and dx_dblT.is_contiguous() and _mat_of(ddelta, batch, L) and _mat_of(conv1d_out, batch, L)
+                  and _mat_of(dconv1d_out, batch, L) and ddelta.dtype == torch.float32
+                  and dconv1d_out.dtype == torch.float32)
+    if post_small:
+        dx_proj_weight, ddelta_proj_weight = _post_small(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out,
+                                                         x_proj_weight, delta_proj_weight)
+    else:
+        ddelta_m = _dbl_view(ddelta)                                            # (D, B*L)
+        ddelta_proj_weight = nt_splitk(ddelta_m, x_dblT[:r]).to(delta_proj_weight.dtype)  # (D, r)      (:273)
+        torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])         # (r, B*L)              (:274)
+        conv_m = _dbl_view(conv1d_out)
+        dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
+        dconv_m = _dbl_view(dconv1d_out)                                        # (D, B*L)
+        if dconv_m.data_ptr() == dconv1d_out.data_ptr():
+            dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
+        else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
+            dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dblT)
+        dconv1d_out = dconv_m.view(dim, batch, L).permute(1, 0, 2)
     dx, dconv1d_weight, dconv1d_bias = causal_conv1d_hip.causal_conv1d_bwd(x, conv1d_weight, conv1d_bias,
                                                                            dconv1d_out, dx, True)
     dconv1d_bias = dconv1d_bias if conv1d_bias is not None else None

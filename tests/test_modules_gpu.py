@@ -576,8 +576,8 @@ def test_mamba_small_block_fused_pre_kernel(d_model):
     x = torch.randn(2, 1024, d_model, generator=gen).to(DEV)
     g = torch.randn(2, 1024, d_model, generator=gen).to(DEV)
     res = {}
-    for fused in (False, True):
-        ssi.PRE_SMALL_FUSED = fused
+    for mode in ((False, False), (True, False), (True, True)):
+        ssi.PRE_SMALL_FUSED, ssi.POST_SMALL_FUSED = mode
         try:
             m.zero_grad()
             xa = x.clone().requires_grad_()
@@ -585,14 +585,16 @@ def test_mamba_small_block_fused_pre_kernel(d_model):
             out = out[0] if isinstance(out, (tuple, list)) else out
             out.backward(g)
         finally:
-            ssi.PRE_SMALL_FUSED = True
-        res[fused] = (out.detach(), xa.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
-                                                      if p.grad is not None})
-    close(res[True][0], res[False][0], 1e-4, 1e-5, "out")
-    close(res[True][1], res[False][1], 1e-3, 1e-5, "d x")
-    assert res[True][2].keys() == res[False][2].keys()
-    for k, v in res[False][2].items():
-        close(res[True][2][k], v, 2e-3, 1e-4, k)
+            ssi.PRE_SMALL_FUSED = ssi.POST_SMALL_FUSED = True
+        res[mode] = (out.detach(), xa.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
+                                                     if p.grad is not None})
+    base = res[(False, False)]
+    for mode in ((True, False), (True, True)):
+        close(res[mode][0], base[0], 1e-4, 1e-5, f"out {mode}")
+        close(res[mode][1], base[1], 1e-3, 1e-5, f"d x {mode}")
+        assert res[mode][2].keys() == base[2].keys()
+        for k, v in base[2].items():
+            close(res[mode][2][k], v, 2e-3, 1e-4, f"{k} {mode}")
 
 
 def test_train_step_graph_replay_matches_eager():
