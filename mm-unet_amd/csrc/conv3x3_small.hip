@@ -327,16 +327,23 @@ __global__ __launch_bounds__(256) void conv3x3s_wgrad_rows_kernel(const float *_
     }
 }
 
+// 16 lanes per result stride over the blocks' partials (fixed order), row-local DPP sum at the end
 template <int CO>
 __global__ __launch_bounds__(256) void conv3x3s_wgrad_sum_kernel(const float *__restrict__ part, float *__restrict__ dW,
                                                                  float *__restrict__ dbias, int Cin, int nblk) {
     constexpr int NV = CO * 10, NV4 = (NV + 3) & ~3;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Cin * NV4) return;
-    const int ci = idx / NV4, e = idx - ci * NV4;
-    if (e >= NV) return;
+    const int sub = threadIdx.x & 15;
+    int idx = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = idx < Cin * NV4;
+    idx = live ? idx : Cin * NV4 - 1;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(long)k * Cin * NV4 + idx];
+    for (int k = sub; k < nblk; k += 16) s += part[(long)k * Cin * NV4 + idx];
+    s += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, s);
+    s += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, s);
+    s += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, s);
+    s += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, s);   // lane 15 of each row of 16 holds the total
+    const int ci = idx / NV4, e = idx - ci * NV4;
+    if (!live || sub != 15 || e >= NV) return;
     if (e < CO * 9) {
         const int co = e / 9, t = e - co * 9;
         dW[((long)co * Cin + ci) * 9 + t] = s;
@@ -448,7 +455,7 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
                                                                  p->height, p->width, lwq, rs);
             MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight rows)");
             constexpr int NV4 = (CO * 10 + 3) & ~3;
-            conv3x3s_wgrad_sum_kernel<CO><<<(p->in_channels * NV4 + 255) / 256, 256, 0, st>>>(
+            conv3x3s_wgrad_sum_kernel<CO><<<(p->in_channels * NV4 + 15) / 16, 256, 0, st>>>(
                 p->workspace, p->dweight, p->dbias, p->in_channels, nrb * p->batch);
         })
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight sum)");

@@ -182,16 +182,21 @@ __global__ __launch_bounds__(256, 1) void mamba_post_small_kernel(const float *_
         part[(long)blockIdx.x * NV4 + i] = (red[i] + red[NV4 + i]) + (red[2 * NV4 + i] + red[3 * NV4 + i]);
 }
 
+// one wave per result: lanes stride over the workgroups' partials, fixed-order butterfly at the end
 template <int D, int R>
 __global__ __launch_bounds__(256) void mamba_post_small_sum_kernel(const float *__restrict__ part, float *__restrict__ dwx,
                                                                    float *__restrict__ dwdt, int nblk) {
     constexpr int NV = R * D + D, NV4 = (NV + 3) & ~3;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= NV) return;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(long)k * NV4 + i];
-    if (i < R * D) dwx[i] = s;
-    else dwdt[i - R * D] = s;
+    for (int k = lane; k < nblk; k += 64) s += part[(long)k * NV4 + i];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (i < R * D) dwx[i] = s;
+        else dwdt[i - R * D] = s;
+    }
 }
 
 int post_blocks(long tokens) {
@@ -224,12 +229,12 @@ extern "C" int mmu_mamba_post_small(const mmu_mamba_post_params *p, void *stream
         mamba_post_small_kernel<6, 33><<<nblk, 256, 0, st>>>(p->ddelta, p->dt, p->dx_dbl, p->conv_out, p->dconv_out,
                                                              p->x_proj_weight, p->dt_proj_weight, p->workspace, p->tokens);
         MMU_HIP_LAUNCH_CHECK("mamba_post_small");
-        mamba_post_small_sum_kernel<6, 33><<<1, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
+        mamba_post_small_sum_kernel<6, 33><<<(33 * 6 + 6 + 3) / 4, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
     } else {
         mamba_post_small_kernel<2, 33><<<nblk, 256, 0, st>>>(p->ddelta, p->dt, p->dx_dbl, p->conv_out, p->dconv_out,
                                                              p->x_proj_weight, p->dt_proj_weight, p->workspace, p->tokens);
         MMU_HIP_LAUNCH_CHECK("mamba_post_small");
-        mamba_post_small_sum_kernel<2, 33><<<1, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
+        mamba_post_small_sum_kernel<2, 33><<<(33 * 2 + 2 + 3) / 4, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
     }
     MMU_HIP_LAUNCH_CHECK("mamba_post_small(sum)");
     return 0;
