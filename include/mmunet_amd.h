@@ -287,6 +287,26 @@ size_t mmu_norm_fused_workspace_floats(int batch, int channels, int groups);
 int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream);
 int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream);
 
+/* ---- dense 3x3 / stride 1 / padding 1 convolution on the bf16 matrix cores with float32 accuracy ------------- */
+/* nn.Conv2d(Cin, Cout, 3, padding=1) of CBAM (src/UM_Net/MMUNet.py:313-338) and of model.py's Unet (model.py:5-20),
+ * float32 NCHW; in_channels % 16 == 0, out_channels % 64 == 0, width % 4 == 0.  Each product is evaluated as
+ * xh*wh + xh*wl + xl*wh on bf16 hi/lo splits (float32 accumulation, ~2^-16 relative per product).
+ * transposed = 0: out = conv(input, weight[out_channels][in_channels][3][3]) + bias.
+ * transposed = 1: the input gradient -- `input` is dout [batch, in_channels, H, W], `weight` the forward weight
+ *   [in_channels][out_channels][3][3] (read transposed and flipped), `out` is dinput [batch, out_channels, H, W].
+ * workspace: mmu_conv3x3_mfma_workspace_bytes() bytes (prepared bf16 weights), 16-byte aligned. */
+typedef struct {
+    int32_t batch, in_channels, out_channels, height, width, transposed;
+    const float *input;
+    const float *weight;
+    const float *bias;      /* [out_channels] or NULL */
+    float *out;
+    void *workspace;
+} mmu_conv3x3_mfma_params;
+
+size_t mmu_conv3x3_mfma_workspace_bytes(int in_channels, int out_channels);
+int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream);
+
 /* ---- conv1d + SiLU + x_proj + dt_proj of a small Mamba block in one kernel (a5/a6 glue, MMConv's blocks) ---- */
 /* mamba_ssm/ops/selective_scan_interface.py:173-210 for inner width dim in {2, 6}, conv width 4, dt_rank 1,
  * float32:  conv_out = silu(causal_conv1d(x)),  x_dbl[j] = sum_d x_proj_weight[j][d] conv_out[d]  (rows = dt_rank

@@ -95,6 +95,11 @@ class NormParams(ctypes.Structure):
                                       "dpre_bias", "workspace")])
 
 
+class Conv3x3MfmaParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "in_channels", "out_channels", "height", "width", "transposed")]
+                + [(n, _vp) for n in ("input", "weight", "bias", "out", "workspace")])
+
+
 class MambaPreParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("dim", _i32), ("seqlen", _i32), ("rows", _i32),
                 ("x", _vp), ("x_bs", _i64), ("x_ds", _i64), ("conv_weight", _vp), ("conv_bias", _vp),
@@ -123,7 +128,7 @@ EXPORTS = (
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
     "mmu_conv3x3_small_wgrad_workspace_floats",
-    "mmu_tri_split", "mmu_tri_combine", "mmu_mamba_pre_small", "mmu_mamba_post_small",
+    "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_debug_wave_scan",
 )
@@ -160,7 +165,8 @@ def lib():
                      ("mmu_conv3x3_small_fwd", Conv3x3sParams), ("mmu_conv3x3_small_bwd", Conv3x3sParams),
                      ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
-                     ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams)):
+                     ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
+                     ("mmu_conv3x3_mfma", Conv3x3MfmaParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -168,6 +174,8 @@ def lib():
     L.mmu_conv3x3_small_fwd_splits.argtypes = [ctypes.c_int] * 4
     L.mmu_conv3x3_small_wgrad_workspace_floats.restype = ctypes.c_size_t
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
+    L.mmu_conv3x3_mfma_workspace_bytes.restype = ctypes.c_size_t
+    L.mmu_conv3x3_mfma_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     L.mmu_mamba_post_small_workspace_floats.restype = ctypes.c_size_t
     L.mmu_mamba_post_small_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
     L.mmu_norm_fused_workspace_floats.restype = ctypes.c_size_t

@@ -1,0 +1,76 @@
+"""``conv3x3_mfma`` -- dense ``nn.Conv2d(Cin, Cout, 3, padding=1)`` on the bf16 matrix cores with float32 accuracy
+(csrc/conv3x3_mfma.hip: implicit GEMM, LDS-staged input patch, hi/lo bf16 split, three MFMAs per product).
+
+Used for CBAM's 3x3 64->64 convolutions (src/UM_Net/MMUNet.py:313-338) and the plain Unet's conv stack
+(model.py:5-20).  Forward and input gradient run the HIP kernel (the gradient on transposed / flipped weights);
+the weight gradient is ATen's (MIOpen).  float32 NCHW, Cin % 16 == 0, Cout % 64 == 0, W % 4 == 0; anything else
+is the caller's ``F.conv2d``.
+"""
+import torch
+
+from . import _lib
+
+
+def supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] == x.shape[1] and weight.shape[1] % 16 == 0
+            and weight.shape[0] % 64 == 0 and x.shape[3] % 4 == 0 and not torch.is_autocast_enabled())
+
+
+def _run(inp, weight, bias, cin, cout, transposed):
+    B, _, H, W = inp.shape
+    out = torch.empty((B, cout, H, W), device=inp.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().mmu_conv3x3_mfma_workspace_bytes(cin, cout), device=inp.device, dtype=torch.uint8)
+    p = _lib.Conv3x3MfmaParams()
+    p.batch, p.in_channels, p.out_channels, p.height, p.width, p.transposed = B, cin, cout, H, W, int(transposed)
+    p.input, p.weight, p.bias, p.out, p.workspace = inp.data_ptr(), weight.data_ptr(), _lib.ptr(bias), out.data_ptr(), \
+        ws.data_ptr()
+    with torch.cuda.device(inp.device):
+        _lib.check(_lib.lib().mmu_conv3x3_mfma(p, _lib.stream_of(inp)))
+    return out
+
+
+class Conv3x3MfmaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_gpu(x, weight)
+        if not supported(x, weight) or (bias is not None and (bias.dtype != torch.float32
+                                                             or bias.numel() != weight.shape[0] or not bias.is_cuda)):
+            raise RuntimeError("conv3x3_mfma: float32 NCHW input with W % 4 == 0, [Cout, Cin, 3, 3] float32 weight "
+                               "with Cin % 16 == 0 and Cout % 64 == 0, float32 bias of Cout elements required")
+        x = x.contiguous()
+        weight = weight.contiguous()
+        bias = bias.contiguous() if bias is not None else None
+        out = _run(x, weight, bias, weight.shape[1], weight.shape[0], False)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        g = dout.float().contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if cin % 64 == 0 and cout % 16 == 0:
+                dx = _run(g, weight, None, cout, cin, True)
+            else:  # the transposed problem does not fit the kernel's tiling (e.g. Cin = 16): ATen
+                dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_b:
+            _, dw, db = torch.ops.aten.convolution_backward(
+                g, x, weight, [cout] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                [False, bool(ctx.needs_input_grad[1]), bool(need_b)])
+        return dx, dw, db
+
+
+def conv3x3_mfma(x, weight, bias=None):
+    return Conv3x3MfmaFn.apply(x, weight, bias)
+
+
+def module_supported(m, x):
+    """True when ``m`` is an ``nn.Conv2d`` that :func:`conv3x3_mfma` covers for the input ``x``."""
+    return (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros" and supported(x, m.weight))

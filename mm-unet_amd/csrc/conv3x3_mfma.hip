@@ -1,0 +1,263 @@
+// conv3x3_mfma.hip -- dense 3x3 / stride 1 / padding 1 convolution (Cin % 16 == 0, Cout % 64 == 0) as an
+// implicit GEMM on the bf16 matrix cores with float32 accuracy.
+//
+// Where it sits: CBAM's two 3x3 64->64 convolutions on [8, 64, 256, 256] (src/UM_Net/MMUNet.py:313-338; 27 % of the
+// model's conv FLOPs) and every 3x3 conv of model.py's plain Unet.  MIOpen runs them as
+// fp32 Winograd at ~87 TFLOP/s effective; the f32-input MFMA peaks at 157 TFLOP/s, the bf16 MFMA at 2.5 PFLOP/s.
+//
+// float32 accuracy on the bf16 pipe: x = xh + xl with xh = bf16(x), xl = bf16(x - xh) (16 mantissa bits kept), and
+//   x*w  ~=  xh*wh + xh*wl + xl*wh        (the dropped xl*wl term and the residuals are ~2^-16 relative)
+// -- three v_mfma_f32_32x32x16_bf16 per product, float32 accumulation: 833 TFLOP/s of fp32-grade peak.
+//
+// GEMM view: M = output channels (A = weights), N = pixels (B = input), K = (3x3 shift) x input channel.
+//   workgroup = 512 threads = 8 waves = an 8-row x 64-column pixel tile x 64 output channels; wave w owns tile row w:
+//   2 (M) x 2 (N) tiles of 32 x 32, 64 accumulator registers.
+//   K loop: chunks of 16 input channels.  Per chunk the workgroup stages in LDS
+//     * the (8+2) x (64+2) input patch, converted on the fly to [pixel][16 ci] bf16 (hi and lo images): the B
+//       fragment of a lane (8 consecutive ci of one pixel) is one ds_read_b128, a wave reads 2 KiB contiguous, and a
+//       3x3 shift is just another pixel offset -- this is the im2col stage, done by addressing;
+//     * the chunk's weights [shift][co][16 ci] bf16 hi / lo (prepared once per call by a small kernel).
+//   Per shift and wave: 8 ds_read_b128 feed 12 MFMAs (0.67 per MFMA; the LDS pipe allows 2).  The next chunk's
+//   global loads are issued before the MFMAs of the current one and held in registers (52 VGPRs).
+// The input gradient is the same kernel on flipped / transposed weights (prepared by the same small kernel).
+#include "mmu_common.h"
+#include "../../include/mmunet_amd.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TH = 8, TW = 64, PW = TW + 2, PH = TH + 2, CK = 16;
+constexpr int PATCH_BYTES = PH * PW * CK * 2;        // one bf16 image of the patch: 21,120 B
+constexpr int WCH_BYTES = 9 * 64 * CK * 2;           // one bf16 image of a chunk's weights: 18,432 B
+constexpr int STAGE_BYTES = 2 * PATCH_BYTES + 2 * WCH_BYTES;   // patch hi | patch lo | weights hi | weights lo: 79,104 B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;                      // double-buffered: 158,208 B of the CU's 160 KiB
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// hi / lo split of two floats -> one packed word each
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+    hi = pack_bf16(a, b);
+    const float ah = __builtin_bit_cast(float, hi << 16), bh = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pack_bf16(a - ah, b - bh);
+}
+
+// weights [Cout][Cin][3][3] f32 (flip = 0) or, for the input gradient, the ORIGINAL weight [Cin_eff][Cout_eff][3][3]
+// read transposed and spatially flipped (flip = 1)  ->  [Cout/64][Cin/16][hi|lo][9][ci half][64 co][8 ci] bf16
+__global__ __launch_bounds__(256) void conv3x3_mfma_prep_kernel(const float *__restrict__ w, unsigned short *__restrict__ out,
+                                                                int Cin, int Cout, int flip) {
+    const long n = (long)Cout * Cin * 9;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    // idx = (((cot * nch + ch) * 9 + s) * 64 + co) * 16 + k   (hi image; lo image is WCH elements further)
+    const int k = (int)(idx & 15), co = (int)((idx >> 4) & 63);
+    long r = idx >> 10;
+    const int s = (int)(r % 9);
+    r /= 9;
+    const int nch = Cin / CK;
+    const int ch = (int)(r % nch), cot = (int)(r / nch);
+    const int oc = cot * 64 + co, ic = ch * CK + k;
+    const float v = flip ? w[((long)ic * Cout + oc) * 9 + (8 - s)] : w[((long)oc * Cin + ic) * 9 + s];
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    const long base = ((long)(cot * nch + ch) * 2) * (9 * 64 * 16) + (((long)s * 2 + (k >> 3)) * 64 + co) * 8 + (k & 7);
+    out[base] = __builtin_bit_cast(unsigned short, h);
+    out[base + 9 * 64 * 16] = __builtin_bit_cast(unsigned short, l);
+}
+
+struct ConvArgsM {
+    const float *x;
+    const unsigned short *wp;
+    const float *bias;
+    float *out;
+    int B, Cin, Cout, H, W, tiles_x;
+};
+
+__global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int cot = blockIdx.y, b = blockIdx.z;
+    const int nch = p.Cin / CK;
+    const long HW = (long)p.H * p.W;
+
+    // ---- patch work items of this thread: (channel half, patch pixel), pixel fastest over the lanes -- the global
+    // loads are dword-coalesced along x and each lane's 8 channels land as ONE 16-byte LDS write, consecutive
+    // lanes on consecutive pixels (conflict-free).  1,320 items over 512 threads: 3 rounds.
+    constexpr int NPX = PH * PW, NITEM = 2 * NPX;
+    const float *isrc[3];
+    float imask[3];
+    int ioff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int q = tid + 512 * k;
+        const bool live = q < NITEM;
+        q = live ? q : NITEM - 1;
+        const int half = q / NPX, pxi = q - half * NPX;
+        const int pr = pxi / PW, pc = pxi - pr * PW;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        imask[k] = inb ? 1.f : 0.f;
+        isrc[k] = p.x + ((long)b * p.Cin + 8 * half) * HW + (inb ? (long)gy * p.W + gx : 0);
+        ioff[k] = live ? half * (NPX * 16) + pxi * 16 : -1;
+    }
+    const unsigned short *wsrc = p.wp + (long)cot * nch * (2 * 9 * 64 * 16);
+
+    float px[3][8];
+    v4u wr[5];
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float *s = isrc[k] + (long)ch * CK * HW;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) px[k][j] = s[j * HW];
+        }
+        const v4u *ws = reinterpret_cast<const v4u *>(wsrc + (long)ch * (2 * 9 * 64 * 16));
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int q = tid + 512 * j;
+            wr[j] = ws[q < 2304 ? q : 2303];
+        }
+    };
+    auto stage = [&](unsigned char *buf) {
+        unsigned char *patch_hi = buf, *patch_lo = buf + PATCH_BYTES, *w_hi = buf + 2 * PATCH_BYTES;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(px[k][2 * j] * imask[k], px[k][2 * j + 1] * imask[k], hw[j], lw[j]);
+            const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+            if (ioff[k] >= 0) {
+                *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
+                *reinterpret_cast<v4u *>(patch_lo + ioff[k]) = l;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int q = tid + 512 * j;
+            if (q < 2304) *reinterpret_cast<v4u *>(w_hi + q * 16) = wr[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    // fragment addressing: lanes 0-31 (k 0-7) and lanes 32-63 (k 8-15) read from separate planes, 16 B per row /
+    // pixel, so each half-wave reads 512 contiguous bytes (a [row][16 ci] image is a 2-way bank conflict)
+    const int a_lane = (lane >> 5) * (64 * 16) + (lane & 31) * 16;        // weights: [shift][plane][64 co][8 ci]
+    const int b_lane = (lane >> 5) * (NPX * 16) + (lane & 31) * 16;       // patch:   [plane][pixel][8 ci]
+    // Pipeline: registers hold chunk c+2 (global loads in flight), LDS buffer (c+1)&1 is being written while the
+    // MFMAs read buffer c&1 -- staging (cvt + ds_write) and MFMAs are independent instruction streams in one basic
+    // block, so they interleave in each wave and the VALU work hides in the MFMA issue gaps.  One barrier per chunk.
+    // Nothing in the loop is conditional: past the last chunk the stage / prefetch repeat the last chunk into the
+    // buffer nobody reads again (a branch around loads would cost a vmcnt(0) at its merge).
+    prefetch(0);
+    stage(lds);
+    prefetch(nch > 1 ? 1 : 0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const unsigned char *cur = lds + (ch & 1) * STAGE_BYTES;
+        const unsigned char *patch_hi = cur, *patch_lo = cur + PATCH_BYTES, *w_hi = cur + 2 * PATCH_BYTES;
+        stage(lds + ((ch + 1) & 1) * STAGE_BYTES);
+        prefetch(ch + 2 < nch ? ch + 2 : nch - 1);
+        // keep the loads ahead of the MFMAs: left alone, the scheduler sinks them behind the last MFMA (their
+        // destination registers then double as fragment registers) and every chunk waits out a full memory latency
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int kh = s / 3, kw = s - 3 * kh;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int off = s * (2 * 64 * 16) + m * (32 * 16) + a_lane;
+                ah[m] = *reinterpret_cast<const bf16x8 *>(w_hi + off);
+                al[m] = *reinterpret_cast<const bf16x8 *>(w_hi + WCH_BYTES + off);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int off = ((wv + kh) * PW + n * 32 + kw) * 16 + b_lane;
+                bh[n] = *reinterpret_cast<const bf16x8 *>(patch_hi + off);
+                bl[n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+    const int oy = y0 + wv;
+    if (oy < p.H) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int ox = x0 + n * 32 + (lane & 31);
+                if (ox >= p.W) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cot * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const float bv = p.bias ? p.bias[co] : 0.f;
+                    p.out[((long)b * p.Cout + co) * HW + (long)oy * p.W + ox] = acc[m][n][e] + bv;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mmu_conv3x3_mfma_workspace_bytes(int in_channels, int out_channels) {
+    if (in_channels <= 0 || out_channels <= 0) return 0;
+    return (size_t)in_channels * out_channels * 9 * 2 * sizeof(unsigned short);
+}
+
+extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) {
+    MMU_CHECK(p != nullptr, "conv3x3_mfma: null params");
+    MMU_CHECK(p->batch > 0 && p->height > 0 && p->width > 0, "conv3x3_mfma: empty tensor");
+    MMU_CHECK(p->in_channels > 0 && p->in_channels % 16 == 0 && p->out_channels > 0 && p->out_channels % 64 == 0,
+              "conv3x3_mfma: in_channels must be a multiple of 16 and out_channels of 64 (got %d, %d)", p->in_channels,
+              p->out_channels);
+    MMU_CHECK(p->width % 4 == 0, "conv3x3_mfma: width must be a multiple of 4 (got %d)", p->width);
+    MMU_CHECK(p->input && p->weight && p->out && p->workspace, "conv3x3_mfma: input, weight, out, workspace are required");
+    MMU_CHECK(((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->workspace & 15) == 0,
+              "conv3x3_mfma: input and workspace must be 16-byte aligned");
+    MMU_CHECK(p->batch <= 65535 && p->out_channels / 64 <= 65535, "conv3x3_mfma: batch / channel tiles exceed the grid");
+    hipStream_t st = (hipStream_t)stream;
+    const long nw = (long)p->in_channels * p->out_channels * 9;
+    conv3x3_mfma_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(
+        p->weight, (unsigned short *)p->workspace, p->in_channels, p->out_channels, p->transposed ? 1 : 0);
+    MMU_HIP_LAUNCH_CHECK("conv3x3_mfma(prep)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS_BYTES);
+        if (e != hipSuccess) return mmu_fail("conv3x3_mfma: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    ConvArgsM a;
+    a.x = p->input; a.wp = (const unsigned short *)p->workspace; a.bias = p->bias; a.out = p->out;
+    a.B = p->batch; a.Cin = p->in_channels; a.Cout = p->out_channels; a.H = p->height; a.W = p->width;
+    a.tiles_x = (p->width + TW - 1) / TW;
+    const int tiles_y = (p->height + TH - 1) / TH;
+    dim3 grid((unsigned)(a.tiles_x * tiles_y), p->out_channels / 64, p->batch);
+    conv3x3_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
+    MMU_HIP_LAUNCH_CHECK("conv3x3_mfma");
+    return 0;
+}

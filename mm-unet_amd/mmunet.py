@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba
-from . import conv3x3_small, morph_coords, norm_fused
+from . import conv3x3_mfma, conv3x3_small, morph_coords, norm_fused
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
 from .tall_gemm import dsc_gemm
@@ -214,7 +214,10 @@ def run_fused(seq, x, residual=None):
             x = norm_fused.bn_act(x, m, "relu" if relu else None)
             i += 2 if relu else 1
             continue
-        x = m(x)
+        if conv3x3_mfma.module_supported(m, x):   # dense 3x3 (CBAM): implicit GEMM on the bf16 matrix cores
+            x = conv3x3_mfma.conv3x3_mfma(x, m.weight, m.bias)
+        else:
+            x = m(x)
         i += 1
     return x if residual is None else torch.relu(x + residual)
 

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import norm_fused
+from . import conv3x3_mfma, norm_fused
 
 
 def _conv_bn_relu(seq, x):
@@ -21,7 +21,10 @@ def _conv_bn_relu(seq, x):
             x = norm_fused.bn_act(x, m, "relu" if relu else None)
             i += 2 if relu else 1
             continue
-        x = m(x)
+        if x.is_cuda and conv3x3_mfma.module_supported(m, x):   # dense 3x3: implicit GEMM on the bf16 matrix cores
+            x = conv3x3_mfma.conv3x3_mfma(x, m.weight, m.bias)
+        else:
+            x = m(x)
         i += 1
     return x
 

@@ -597,6 +597,34 @@ def test_mamba_small_block_fused_pre_kernel(d_model):
             close(res[mode][2][k], v, 2e-3, 1e-4, f"{k} {mode}")
 
 
+@pytest.mark.parametrize("case", [(2, 16, 64, 13, 20), (1, 64, 64, 32, 64), (2, 32, 128, 9, 132), (1, 64, 64, 8, 4)])
+def test_conv3x3_mfma_vs_conv2d_fp64(case):
+    """conv3x3_mfma (bf16 hi/lo split on the matrix cores) == F.conv2d in float64 on CPU: output, input gradient
+    (same kernel on flipped weights), weight / bias gradient.  float32-grade tolerance: 3 bf16 products per term
+    leave ~2^-16 relative per product."""
+    import torch.nn.functional as F
+    from mm_unet_amd.conv3x3_mfma import conv3x3_mfma, supported
+    B, Cin, Cout, H, W = case
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=gen)
+    g = torch.randn(B, Cout, H, W, generator=gen)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    ref = F.conv2d(xr, wr, br, padding=1)
+    ref.backward(g.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    assert supported(xg, wg)
+    out = conv3x3_mfma(xg, wg, bg)
+    out.backward(g.to(DEV))
+    close(out, ref.float(), 2e-5, 2e-5, "out")
+    close(xg.grad, xr.grad.float(), 2e-5, 2e-5, "d input")
+    close(wg.grad, wr.grad.float(), 1e-3, 1e-3, "d weight")
+    close(bg.grad, br.grad.float(), 1e-4, 1e-4, "d bias")
+    close(conv3x3_mfma(xg.detach(), wg.detach()), F.conv2d(x.double(), w.double(), None, padding=1).float(),
+          2e-5, 2e-5, "no bias")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
