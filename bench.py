@@ -12,6 +12,9 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
                   B=8, D=128, L=65536, N=16) timed live with HIP events on the stream it
                   is launched on; achieved = algorithmic bytes s*B*L*(4D+2N) / mean duration of one
                   mmu_selective_scan_fwd call; peak = 8 TB/s HBM3E; traffic from profiles/ if measured;
+  "roofline_conv": the MFMA-bound kernel of the path (csrc/conv3x3_mfma.hip at CBAM's shape [8,64,256,256] 64->64 and
+                  at a Unet shape [8,256,64,64] 256->256), same timing method; achieved = bf16 MFMA FLOP/s actually
+                  issued (3 passes of 2*B*Cout*H*W*Cin*9 for the hi/lo split); peak = 2.5 PFLOP/s dense bf16;
   "cpu_baseline": the CPU oracle (oracle/model_ref.py + C scan, kind "port") running the same training
                   step (fwd + loss + bwd) on one 3x512x512 image on this host's cores (N=1, rank 0 only).
 """
@@ -90,6 +93,35 @@ def scan_roofline(dev, iters=20):
             "algorithmic_bytes": alg_bytes, "ms_per_launch": round(ms, 4)}
 
 
+def conv_roofline(dev, iters=20):
+    """Live measurement of the dense 3x3 convolution on the matrix cores (forward)."""
+    from mm_unet_amd.conv3x3_mfma import conv3x3_mfma
+    out = {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s", "kernel": "conv3x3_mfma_kernel (bf16 hi/lo split, "
+           "3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)", "traffic": None, "shapes": []}
+    gen = torch.Generator(device=dev).manual_seed(0)
+    for (b, cin, cout, h, w) in ((8, 64, 64, 256, 256), (8, 256, 256, 64, 64)):
+        x = torch.randn(b, cin, h, w, device=dev, generator=gen)
+        wt = torch.randn(cout, cin, 3, 3, device=dev, generator=gen) / (3 * cin ** 0.5)
+        for _ in range(3):
+            conv3x3_mfma(x, wt, None)
+        st = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            conv3x3_mfma(x, wt, None)
+        e1.record(st)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / iters          # includes the weight-preparation kernel of each call
+        alg = 2.0 * b * cout * h * w * cin * 9
+        out["shapes"].append({"input": [b, cin, h, w], "out_channels": cout, "ms_per_launch": round(ms, 4),
+                              "algorithmic_flops": alg, "fp32_grade_tflops": round(alg / (ms * 1e-3) / 1e12, 1),
+                              "achieved": round(3 * alg / (ms * 1e-3) / 1e12, 1),
+                              "frac": round(3 * alg / (ms * 1e-3) / 1e12 / 2500.0, 4)})
+    best = max(out["shapes"], key=lambda s_: s_["frac"])
+    out["achieved"], out["frac"] = best["achieved"], best["frac"]
+    return out
+
+
 def cpu_baseline(size):
     """The oracle's training step (fwd + Dice+BCE + bwd) on ONE image, timed on this host's cores."""
     import oracle
@@ -128,7 +160,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.roofline_only:
-        print(json.dumps({"roofline": scan_roofline(dev)}), flush=True)
+        print(json.dumps({"roofline": scan_roofline(dev), "roofline_conv": conv_roofline(dev)}), flush=True)
         return
 
     if args.infer:
@@ -209,6 +241,7 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = scan_roofline(dev)
+            line["roofline_conv"] = conv_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_size)
         print(json.dumps(line), flush=True)

@@ -74,56 +74,81 @@ struct ConvArgsM {
     const unsigned short *wp;
     const float *bias;
     float *out;
-    int B, Cin, Cout, H, W, tiles_x;
+    int B, Cin, Cout, H, W, tiles_x, tiles_y, ncot, total_tiles;
 };
 
+// Persistent: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...; the chunk pipeline (registers hold
+// chunk i+2, LDS buffer (i+1)&1 is written while the MFMAs read buffer i&1) runs straight across tile boundaries,
+// so a tile's first loads, its staging and the previous tile's output stores all sit under MFMAs.  (One workgroup
+// per launch slot instead: every tile exposed a memory latency + staging + 64 stores per lane -- 32 % MFMA
+// utilisation at 64 -> 64 channels, where a tile has only 4 chunks.)
 __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int cot = blockIdx.y, b = blockIdx.z;
     const int nch = p.Cin / CK;
     const long HW = (long)p.H * p.W;
+    const int G = gridDim.x;
+    const int ntl = (p.total_tiles - (int)blockIdx.x + G - 1) / G;   // tiles of this workgroup (>= 1)
+    const int niter = ntl * nch;
 
     // ---- patch work items of this thread: (channel half, patch pixel), pixel fastest over the lanes -- the global
     // loads are dword-coalesced along x and each lane's 8 channels land as ONE 16-byte LDS write, consecutive
     // lanes on consecutive pixels (conflict-free).  1,320 items over 512 threads: 3 rounds.
     constexpr int NPX = PH * PW, NITEM = 2 * NPX;
-    const float *isrc[3];
-    float imask[3];
-    int ioff[3];
+    int ipr[3], ipc[3], ihalf[3], ioff[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int q = tid + 512 * k;
         const bool live = q < NITEM;
         q = live ? q : NITEM - 1;
-        const int half = q / NPX, pxi = q - half * NPX;
-        const int pr = pxi / PW, pc = pxi - pr * PW;
-        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
-        const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        imask[k] = inb ? 1.f : 0.f;
-        isrc[k] = p.x + ((long)b * p.Cin + 8 * half) * HW + (inb ? (long)gy * p.W + gx : 0);
-        ioff[k] = live ? half * (NPX * 16) + pxi * 16 : -1;
+        ihalf[k] = q / NPX;
+        const int pxi = q - ihalf[k] * NPX;
+        ipr[k] = pxi / PW;
+        ipc[k] = pxi - ipr[k] * PW;
+        ioff[k] = live ? ihalf[k] * (NPX * 16) + pxi * 16 : -1;
     }
-    const unsigned short *wsrc = p.wp + (long)cot * nch * (2 * 9 * 64 * 16);
+    auto decode = [&](int tj, int &b, int &cot, int &y0, int &x0) {
+        int t = (int)blockIdx.x + tj * G;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        t /= p.tiles_y;
+        cot = t % p.ncot;
+        b = t / p.ncot;
+        y0 = ty * TH;
+        x0 = tx * TW;
+    };
 
-    float px[3][8];
+    // ---- load stream (two chunks ahead of the MFMAs)
+    float px[3][8], pmask[3];
     v4u wr[5];
-    auto prefetch = [&](int ch) {
+    int l_tj = 0, l_ch = 0, l_b, l_cot, l_y0, l_x0;
+    decode(0, l_b, l_cot, l_y0, l_x0);
+    auto prefetch = [&]() {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float *s = isrc[k] + (long)ch * CK * HW;
+            const int gy = l_y0 - 1 + ipr[k], gx = l_x0 - 1 + ipc[k];
+            const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            pmask[k] = inb ? 1.f : 0.f;
+            const float *s = p.x + ((long)l_b * p.Cin + l_ch * CK + 8 * ihalf[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) px[k][j] = s[j * HW];
         }
-        const v4u *ws = reinterpret_cast<const v4u *>(wsrc + (long)ch * (2 * 9 * 64 * 16));
+        const v4u *ws = reinterpret_cast<const v4u *>(p.wp + ((long)l_cot * nch + l_ch) * (2 * 9 * 64 * 16));
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int q = tid + 512 * j;
             wr[j] = ws[q < 2304 ? q : 2303];
+        }
+        // advance; past the end the stream keeps re-reading the last chunk (nothing consumes it)
+        if (l_ch + 1 < nch) {
+            ++l_ch;
+        } else if (l_tj + 1 < ntl) {
+            l_ch = 0;
+            ++l_tj;
+            decode(l_tj, l_b, l_cot, l_y0, l_x0);
         }
     };
     auto stage = [&](unsigned char *buf) {
@@ -132,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
         for (int k = 0; k < 3; ++k) {
             unsigned hw[4], lw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split2(px[k][2 * j] * imask[k], px[k][2 * j + 1] * imask[k], hw[j], lw[j]);
+            for (int j = 0; j < 4; ++j) split2(px[k][2 * j] * pmask[k], px[k][2 * j + 1] * pmask[k], hw[j], lw[j]);
             const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
             if (ioff[k] >= 0) {
                 *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
@@ -158,20 +183,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
     // pixel, so each half-wave reads 512 contiguous bytes (a [row][16 ci] image is a 2-way bank conflict)
     const int a_lane = (lane >> 5) * (64 * 16) + (lane & 31) * 16;        // weights: [shift][plane][64 co][8 ci]
     const int b_lane = (lane >> 5) * (NPX * 16) + (lane & 31) * 16;       // patch:   [plane][pixel][8 ci]
-    // Pipeline: registers hold chunk c+2 (global loads in flight), LDS buffer (c+1)&1 is being written while the
-    // MFMAs read buffer c&1 -- staging (cvt + ds_write) and MFMAs are independent instruction streams in one basic
-    // block, so they interleave in each wave and the VALU work hides in the MFMA issue gaps.  One barrier per chunk.
-    // Nothing in the loop is conditional: past the last chunk the stage / prefetch repeat the last chunk into the
-    // buffer nobody reads again (a branch around loads would cost a vmcnt(0) at its merge).
-    prefetch(0);
+
+    // Nothing in the loop that issues loads is conditional (a branch around loads costs a vmcnt(0) at its merge);
+    // the barrier waits for LDS only (lgkmcnt), so loads and the epilogue's stores stay in flight across it.
+    prefetch();
     stage(lds);
-    prefetch(nch > 1 ? 1 : 0);
-    __syncthreads();
-    for (int ch = 0; ch < nch; ++ch) {
-        const unsigned char *cur = lds + (ch & 1) * STAGE_BYTES;
+    prefetch();
+    MMU_LDS_BARRIER();
+    int c_tj = 0, c_ch = 0;
+    for (int it = 0; it < niter; ++it) {
+        const unsigned char *cur = lds + (it & 1) * STAGE_BYTES;
         const unsigned char *patch_hi = cur, *patch_lo = cur + PATCH_BYTES, *w_hi = cur + 2 * PATCH_BYTES;
-        stage(lds + ((ch + 1) & 1) * STAGE_BYTES);
-        prefetch(ch + 2 < nch ? ch + 2 : nch - 1);
+        stage(lds + ((it + 1) & 1) * STAGE_BYTES);
+        prefetch();
         // keep the loads ahead of the MFMAs: left alone, the scheduler sinks them behind the last MFMA (their
         // destination registers then double as fragment registers) and every chunk waits out a full memory latency
         __builtin_amdgcn_sched_barrier(0);
@@ -200,24 +224,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
                 }
         }
-        __syncthreads();
-    }
-    // ---- epilogue: C layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
-    const int oy = y0 + wv;
-    if (oy < p.H) {
+        if (++c_ch == nch) {
+            // ---- tile done: C layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+            int b, cot, y0, x0;
+            decode(c_tj, b, cot, y0, x0);
+            const int oy = y0 + wv;
+            // bias values of this lane's 32 channel rows first, as one batch of loads (a load inside the store loop
+            // is a load -> vmcnt(0) -> store round trip per element: 64 serialised memory latencies per tile)
+            float bv[2][16];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int ox = x0 + n * 32 + (lane & 31);
-                if (ox >= p.W) continue;
+                for (int e = 0; e < 16; ++e) bv[m][e] = 0.f;
+            if (p.bias != nullptr) {
+                const float *bp = p.bias + cot * 64 + 4 * (lane >> 5);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = cot * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    const float bv = p.bias ? p.bias[co] : 0.f;
-                    p.out[((long)b * p.Cout + co) * HW + (long)oy * p.W + ox] = acc[m][n][e] + bv;
-                }
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) bv[m][e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
             }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int ox = x0 + n * 32 + (lane & 31);
+                    if (oy < p.H && ox < p.W) {
+                        float *op = p.out + ((long)b * p.Cout + cot * 64 + m * 32 + 4 * (lane >> 5)) * HW + (long)oy * p.W + ox;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * HW] = acc[m][n][e] + bv[m][e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+                }
+            c_ch = 0;
+            ++c_tj;
+        }
+        MMU_LDS_BARRIER();
     }
 }
 
@@ -238,7 +280,6 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     MMU_CHECK(p->input && p->weight && p->out && p->workspace, "conv3x3_mfma: input, weight, out, workspace are required");
     MMU_CHECK(((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->workspace & 15) == 0,
               "conv3x3_mfma: input and workspace must be 16-byte aligned");
-    MMU_CHECK(p->batch <= 65535 && p->out_channels / 64 <= 65535, "conv3x3_mfma: batch / channel tiles exceed the grid");
     hipStream_t st = (hipStream_t)stream;
     const long nw = (long)p->in_channels * p->out_channels * 9;
     conv3x3_mfma_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(
@@ -255,8 +296,20 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     a.x = p->input; a.wp = (const unsigned short *)p->workspace; a.bias = p->bias; a.out = p->out;
     a.B = p->batch; a.Cin = p->in_channels; a.Cout = p->out_channels; a.H = p->height; a.W = p->width;
     a.tiles_x = (p->width + TW - 1) / TW;
-    const int tiles_y = (p->height + TH - 1) / TH;
-    dim3 grid((unsigned)(a.tiles_x * tiles_y), p->out_channels / 64, p->batch);
+    a.tiles_y = (p->height + TH - 1) / TH;
+    a.ncot = p->out_channels / 64;
+    const long total = (long)a.tiles_x * a.tiles_y * a.ncot * p->batch;
+    MMU_CHECK(total < (1L << 30), "conv3x3_mfma: too many tiles");
+    a.total_tiles = (int)total;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return mmu_fail("conv3x3_mfma: cannot query the device");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = total < n_cu ? (int)total : n_cu;   // one workgroup (158 KB of LDS) per CU
     conv3x3_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("conv3x3_mfma");
     return 0;
