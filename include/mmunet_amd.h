@@ -307,6 +307,24 @@ typedef struct {
 size_t mmu_conv3x3_mfma_workspace_bytes(int in_channels, int out_channels);
 int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream);
 
+/* ---- W (rows x inner) times a tokens-last matrix, on the bf16 matrix cores with float32 accuracy ------------- */
+/* out[b] = W . X[b] for b < batch;  X[b] = x + b*x_bs, `inner` rows of `tokens` contiguous floats, row stride x_rs;
+ * out[b] = out + b*out_bs, `rows` rows, row stride out_rs (strides in elements).  rows % 64 == 0, inner % 16 == 0.
+ * transposed_weight = 0: weight is [rows][inner] with leading dimension w_ld; 1: weight is [inner][rows] (w_ld its
+ * leading dimension) and is read transposed.  MMConv's dsc_conv_x on the sampler output (src/UM_Net/MMUNet.py:262):
+ * forward = (Cout x 3Cin) . samples, input gradient = transposed weight . dout.
+ * workspace: mmu_gemm_tokens_workspace_bytes() bytes, 16-byte aligned. */
+typedef struct {
+    int32_t rows, inner, tokens, batch, transposed_weight;
+    const float *weight;  int64_t w_ld;
+    const float *x;       int64_t x_rs, x_bs;
+    float *out;           int64_t out_rs, out_bs;
+    void *workspace;
+} mmu_gemm_tokens_params;
+
+size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner);
+int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream);
+
 /* ---- conv1d + SiLU + x_proj + dt_proj of a small Mamba block in one kernel (a5/a6 glue, MMConv's blocks) ---- */
 /* mamba_ssm/ops/selective_scan_interface.py:173-210 for inner width dim in {2, 6}, conv width 4, dt_rank 1,
  * float32:  conv_out = silu(causal_conv1d(x)),  x_dbl[j] = sum_d x_proj_weight[j][d] conv_out[d]  (rows = dt_rank

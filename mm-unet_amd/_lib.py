@@ -100,6 +100,12 @@ class Conv3x3MfmaParams(ctypes.Structure):
                 + [(n, _vp) for n in ("input", "weight", "bias", "out", "workspace")])
 
 
+class GemmTokensParams(ctypes.Structure):
+    _fields_ = [("rows", _i32), ("inner", _i32), ("tokens", _i32), ("batch", _i32), ("transposed_weight", _i32),
+                ("weight", _vp), ("w_ld", _i64), ("x", _vp), ("x_rs", _i64), ("x_bs", _i64),
+                ("out", _vp), ("out_rs", _i64), ("out_bs", _i64), ("workspace", _vp)]
+
+
 class MambaPreParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("dim", _i32), ("seqlen", _i32), ("rows", _i32),
                 ("x", _vp), ("x_bs", _i64), ("x_ds", _i64), ("conv_weight", _vp), ("conv_bias", _vp),
@@ -128,7 +134,8 @@ EXPORTS = (
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
     "mmu_conv3x3_small_wgrad_workspace_floats",
-    "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_mamba_pre_small", "mmu_mamba_post_small",
+    "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_gemm_tokens_mfma",
+    "mmu_gemm_tokens_workspace_bytes", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_debug_wave_scan",
 )
@@ -166,7 +173,7 @@ def lib():
                      ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
-                     ("mmu_conv3x3_mfma", Conv3x3MfmaParams)):
+                     ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -174,6 +181,8 @@ def lib():
     L.mmu_conv3x3_small_fwd_splits.argtypes = [ctypes.c_int] * 4
     L.mmu_conv3x3_small_wgrad_workspace_floats.restype = ctypes.c_size_t
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
+    L.mmu_gemm_tokens_workspace_bytes.restype = ctypes.c_size_t
+    L.mmu_gemm_tokens_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     L.mmu_conv3x3_mfma_workspace_bytes.restype = ctypes.c_size_t
     L.mmu_conv3x3_mfma_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     L.mmu_mamba_post_small_workspace_floats.restype = ctypes.c_size_t

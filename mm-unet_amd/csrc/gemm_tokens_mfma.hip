@@ -1,0 +1,272 @@
+// gemm_tokens_mfma.hip -- out[b] = W (M x K) . X[b] (K x T tokens-last) on the bf16 matrix cores with float32
+// accuracy (the hi/lo split of conv3x3_mfma.hip: x*w ~= xh*wh + xh*wl + xl*wh, three MFMAs per product).
+//
+// Where it sits: MMConv's K x 1 DSC convolution on the tokens-last sampler output (src/UM_Net/MMUNet.py:262; 39.5 %
+// of the model's conv FLOPs) -- forward W2 (Cout x 3 Cin) . samples, input gradient W2^T . G -- which hipBLASLt runs
+// as skinny fp32 GEMMs at ~36-90 TFLOP/s (the f32-input MFMA peaks at 157).
+//
+// Workgroup = 512 threads, a 64-row x 512-token output tile; K in chunks of 16.  The eight waves are SPECIALISED:
+//   waves 4-7 (producers): dword loads of the X chunk coalesced along tokens (8 rows per lane) -> hi/lo split in
+//       registers -> one 16-byte LDS write per lane into [k half][token][8 k] images (conflict-free both ways),
+//       plus the chunk's prepared weights; their loads run one chunk ahead of their LDS writes;
+//   waves 0-3 (consumers): 128 tokens each, 2 x 4 MFMA tiles (128 accumulators), 12 ds_read_b128 + 24 MFMAs per
+//       chunk, nothing else.
+// One wave of each kind per SIMD: the matrix pipe and the VALU / VMEM / LDS-write work co-issue (a single wave
+// doing both serialises them -- the MFMA:staging ratio here is 1:1, not 9:1 as in the 3x3 conv).  LDS is
+// double-buffered (2 x 36 KB), one LDS-only barrier per chunk, persistent workgroups walk the tiles so the
+// producers' stream runs straight across tile boundaries.
+//
+// Measured (MI355X, 3.2 GFLOP each): the large-token DSC shapes are HBM-bound, not MFMA-bound -- 64 x 192 x 131,072
+// tokens moves 133 MB: 27 us = 5.0 TB/s here, 40-46 us in hipBLASLt; its input gradient (192 x 64) 32 us vs 47 us.
+// Deep-K problems with few tokens (512 x 1536 x 2,048: 64 tiles x 96 chunks) leave most CUs idle and would need
+// split-K: the Python side keeps those on hipBLASLt (mfma_gemm.MIN_TILES).  Ablation at that shape: consumers
+// alone 0.52 us per chunk (768 cycles of MFMA + LDS latency + barrier), producers alone 0.81 us, together 1.16 us:
+// the two kinds of wave still contend for VALU issue and the LDS port.
+#include "mmu_common.h"
+#include "../../include/mmunet_amd.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TT = 512, CK = 16;
+constexpr int XIMG = 2 * TT * 16;          // one bf16 image of the X chunk: [half][token][8 k] = 16,384 B
+constexpr int WIMG = 2 * 64 * 16;          // one bf16 image of the W chunk: [half][64 rows][8 k] = 2,048 B
+constexpr int STAGE = 2 * XIMG + 2 * WIMG;  // 36,864 B
+constexpr int LDS_BYTES = 2 * STAGE;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+    hi = pack_bf16(a, b);
+    const float ah = __builtin_bit_cast(float, hi << 16), bh = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pack_bf16(a - ah, b - bh);
+}
+
+// W [M][K] with leading dimension ldw (trans = 0) or W [K][M] read transposed (trans = 1)
+//   -> [M/64][K/16][hi|lo][half][64 rows][8 k] bf16
+__global__ __launch_bounds__(256) void gemm_tokens_prep_kernel(const float *__restrict__ w, long ldw,
+                                                               unsigned short *__restrict__ out, int M, int K, int trans) {
+    const long n = (long)M * K;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int k8 = (int)(idx & 7), row = (int)((idx >> 3) & 63), half = (int)((idx >> 9) & 1);
+    long r = idx >> 10;
+    const int nch = K / CK;
+    const int ch = (int)(r % nch), mt = (int)(r / nch);
+    const int m = mt * 64 + row, k = ch * CK + half * 8 + k8;
+    const float v = trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k];
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    const long base = ((long)(mt * nch + ch) * 2) * (2 * 64 * 8) + ((long)half * 64 + row) * 8 + k8;
+    out[base] = __builtin_bit_cast(unsigned short, h);
+    out[base + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+}
+
+struct GemmArgs {
+    const float *x;
+    const unsigned short *wp;
+    float *out;
+    long x_rs, x_bs, o_rs, o_bs;
+    int M, K, T, B, tiles_t, n_mt, total_tiles;
+};
+
+__global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch = p.K / CK;
+    const int G = gridDim.x;
+    const int ntl = (p.total_tiles - (int)blockIdx.x + G - 1) / G;
+    const int niter = ntl * nch;
+    auto decode = [&](int tj, int &b, int &mt, int &t0) {
+        int t = (int)blockIdx.x + tj * G;
+        const int tt = t % p.tiles_t;
+        t /= p.tiles_t;
+        mt = t % p.n_mt;
+        b = t / p.n_mt;
+        t0 = tt * TT;
+    };
+
+    const int niter_pad = (niter + 2) / 3 * 3;   // both kinds of waves run this many barriers (see the producers)
+
+    if (wv >= 4) {
+        // ================= producers: 256 threads; thread = (k half, group of 4 tokens) of the chunk: 8 x 16-byte
+        // buffer loads (scalar row offset + one per-lane token offset: no address arithmetic), hi/lo split, 8 LDS
+        // writes.  THREE chunks stay in flight (register sets c % 3): one chunk takes the consumers ~0.4 us, a
+        // memory round trip under load 1-2 us.  The loop is unrolled by three so the sets are static registers, and
+        // padded to a multiple of three so that nothing that issues loads sits in a branch (past the end the
+        // stream re-reads the last chunk into the buffer nobody reads).  Columns of tokens >= T read token 0's
+        // data: GEMM columns are independent and those outputs are never stored.
+        const int ptid = tid - 256;
+        const int half = (wv - 4) >> 1, grp = ptid & 127;   // wave-uniform: the row offset of the loads is scalar
+        v4u px[3][8], wr[3];
+        int l_tj = 0, l_ch = 0, l_b, l_mt, l_t0;
+        decode(0, l_b, l_mt, l_t0);
+        auto load = [&](v4u(&dst)[8], v4u &wdst) {
+            const rsrc_t rs = make_rsrc(p.x + (long)l_b * p.x_bs);
+            const int tok = l_t0 + 4 * grp;
+            const unsigned voff = (unsigned)(tok < p.T ? tok : 0) * 4u;
+            const unsigned row0 = (unsigned)(l_ch * CK + half * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (row0 + j) * (unsigned)p.x_rs * 4u, 0);
+            wdst = reinterpret_cast<const v4u *>(p.wp + ((long)l_mt * nch + l_ch) * (2 * 2 * 64 * 8))[ptid];
+            if (l_ch + 1 < nch) {
+                ++l_ch;
+            } else if (l_tj + 1 < ntl) {
+                l_ch = 0;
+                ++l_tj;
+                decode(l_tj, l_b, l_mt, l_t0);
+            }
+        };
+        auto stage = [&](const v4u(&src)[8], const v4u &wsrc, unsigned char *buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    split2(__uint_as_float(src[2 * j][i]), __uint_as_float(src[2 * j + 1][i]), hw[j], lw[j]);
+                const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+                const int off = (half * TT + 4 * grp + i) * 16;
+                *reinterpret_cast<v4u *>(buf + off) = h;
+                *reinterpret_cast<v4u *>(buf + XIMG + off) = l;
+            }
+            *reinterpret_cast<v4u *>(buf + 2 * XIMG + ptid * 16) = wsrc;   // 256 x 16 B = hi and lo images of W
+        };
+        load(px[0], wr[0]);
+        load(px[1], wr[1]);
+        load(px[2], wr[2]);
+        stage(px[0], wr[0], lds);
+        load(px[0], wr[0]);
+        MMU_LDS_BARRIER();
+        // iteration it: stage chunk it+1 (set (it+1) % 3) into buffer (it+1) & 1, then refill that set with chunk it+4
+        for (int it = 0; it < niter_pad; it += 3) {
+            stage(px[1], wr[1], lds + ((it + 1) & 1) * STAGE);
+            load(px[1], wr[1]);
+            MMU_LDS_BARRIER();
+            stage(px[2], wr[2], lds + ((it + 2) & 1) * STAGE);
+            load(px[2], wr[2]);
+            MMU_LDS_BARRIER();
+            stage(px[0], wr[0], lds + ((it + 3) & 1) * STAGE);
+            load(px[0], wr[0]);
+            MMU_LDS_BARRIER();
+        }
+        return;
+    }
+
+    // ===================== consumers: wave cw owns tokens [128 cw, 128 cw + 128) of the tile, 64 rows
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+    const int a_lane = (lane >> 5) * (64 * 16) + (lane & 31) * 16;
+    const int b_lane = (lane >> 5) * (TT * 16) + (wv * 128 + (lane & 31)) * 16;
+    MMU_LDS_BARRIER();
+    int c_tj = 0, c_ch = 0;
+    for (int it = 0; it < niter_pad; ++it) {
+        if (it >= niter) {   // padding iterations (the producers' loop runs in threes): barrier only
+            MMU_LDS_BARRIER();
+            continue;
+        }
+        const unsigned char *cur = lds + (it & 1) * STAGE;
+        bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ah[m] = *reinterpret_cast<const bf16x8 *>(cur + 2 * XIMG + m * (32 * 16) + a_lane);
+            al[m] = *reinterpret_cast<const bf16x8 *>(cur + 2 * XIMG + WIMG + m * (32 * 16) + a_lane);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            bh[n] = *reinterpret_cast<const bf16x8 *>(cur + n * (32 * 16) + b_lane);
+            bl[n] = *reinterpret_cast<const bf16x8 *>(cur + XIMG + n * (32 * 16) + b_lane);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+            }
+        if (++c_ch == nch) {
+            int b, mt, t0;
+            decode(c_tj, b, mt, t0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int tok = t0 + wv * 128 + n * 32 + (lane & 31);
+                    if (tok < p.T) {
+                        float *op = p.out + (long)b * p.o_bs + (long)(mt * 64 + m * 32 + 4 * (lane >> 5)) * p.o_rs + tok;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * p.o_rs] = acc[m][n][e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+                }
+            c_ch = 0;
+            ++c_tj;
+        }
+        MMU_LDS_BARRIER();
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner) {
+    if (rows <= 0 || inner <= 0) return 0;
+    return (size_t)rows * inner * 2 * sizeof(unsigned short);
+}
+
+extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream) {
+    MMU_CHECK(p != nullptr, "gemm_tokens_mfma: null params");
+    MMU_CHECK(p->rows > 0 && p->rows % 64 == 0 && p->inner > 0 && p->inner % 16 == 0,
+              "gemm_tokens_mfma: rows must be a multiple of 64 and inner of 16 (got %d, %d)", p->rows, p->inner);
+    MMU_CHECK(p->tokens > 0 && p->batch > 0, "gemm_tokens_mfma: empty problem");
+    MMU_CHECK(p->tokens % 4 == 0 && p->x_rs % 4 == 0 && p->x_bs % 4 == 0 && ((uintptr_t)p->x & 15) == 0,
+              "gemm_tokens_mfma: tokens, x_rs, x_bs must be multiples of 4 and x 16-byte aligned");
+    MMU_CHECK((long)p->inner * p->x_rs * 4 < (1L << 31), "gemm_tokens_mfma: x rows span more than 2 GB");
+    MMU_CHECK(p->weight && p->x && p->out && p->workspace, "gemm_tokens_mfma: weight, x, out, workspace are required");
+    MMU_CHECK(((uintptr_t)p->workspace & 15) == 0, "gemm_tokens_mfma: workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const long nw = (long)p->rows * p->inner;
+    gemm_tokens_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->weight, p->w_ld, (unsigned short *)p->workspace,
+                                                                         p->rows, p->inner, p->transposed_weight ? 1 : 0);
+    MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma(prep)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)gemm_tokens_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS_BYTES);
+        if (e != hipSuccess) return mmu_fail("gemm_tokens_mfma: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    GemmArgs a;
+    a.x = p->x; a.wp = (const unsigned short *)p->workspace; a.out = p->out;
+    a.x_rs = p->x_rs; a.x_bs = p->x_bs; a.o_rs = p->out_rs; a.o_bs = p->out_bs;
+    a.M = p->rows; a.K = p->inner; a.T = p->tokens; a.B = p->batch;
+    a.tiles_t = (p->tokens + TT - 1) / TT;
+    a.n_mt = p->rows / 64;
+    const long total = (long)a.tiles_t * a.n_mt * p->batch;
+    MMU_CHECK(total < (1L << 30), "gemm_tokens_mfma: too many tiles");
+    a.total_tiles = (int)total;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return mmu_fail("gemm_tokens_mfma: cannot query the device");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = total < n_cu ? (int)total : n_cu;   // persistent: one workgroup per CU (register-bound: 2 waves/SIMD)
+    gemm_tokens_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
+    MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma");
+    return 0;
+}

@@ -8,6 +8,8 @@ turns each into one strided batched GEMM + a small sum: 27 us.
 """
 import torch
 
+from . import mfma_gemm
+
 _SLAB = 2048
 
 
@@ -74,6 +76,10 @@ class _DscGemmFn(torch.autograd.Function):
         T = samples.shape[1] // batch
         ctx.save_for_backward(W2, samples)
         ctx.batch = batch
+        if mfma_gemm.supported(O, I, batch * T, W2, samples) and W2.stride(1) == 1 and samples.is_contiguous() \
+                and T % 4 == 0:
+            out = torch.empty((batch, O, T), device=samples.device, dtype=torch.float32)
+            return mfma_gemm.gemm_tokens(W2, samples, out, O, I, T, batch, batch * T, T, T, O * T)
         Xb = samples.view(I, batch, T).permute(1, 0, 2)                   # (B, I, T) view, ld = B*T
         return torch.bmm(W2.unsqueeze(0).expand(batch, O, I), Xb)         # (B, O, T) contiguous
 
@@ -89,7 +95,13 @@ class _DscGemmFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dW = nt_splitk(G2, samples).to(W2.dtype)
         if ctx.needs_input_grad[1]:
-            dX = W2.t() @ G2
+            I = W2.shape[1]
+            if mfma_gemm.supported(I, O, G2.shape[1], W2, G2) and W2.stride(1) == 1 and G2.is_contiguous():
+                NT = G2.shape[1]
+                dX = torch.empty((I, NT), device=G2.device, dtype=torch.float32)
+                mfma_gemm.gemm_tokens(W2, G2, dX, I, O, NT, 1, NT, 0, NT, 0, transposed_weight=True)
+            else:
+                dX = W2.t() @ G2
         return dW, dX, None
 
 

@@ -53,7 +53,8 @@ def test_param_structs_match_header_field_order():
                         ("mmu_tri_params", _lib.TriParams), ("mmu_norm_params", _lib.NormParams),
                         ("mmu_mamba_pre_params", _lib.MambaPreParams),
                         ("mmu_mamba_post_params", _lib.MambaPostParams),
-                        ("mmu_conv3x3_mfma_params", _lib.Conv3x3MfmaParams)):
+                        ("mmu_conv3x3_mfma_params", _lib.Conv3x3MfmaParams),
+                        ("mmu_gemm_tokens_params", _lib.GemmTokensParams)):
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 
 

@@ -625,6 +625,48 @@ def test_conv3x3_mfma_vs_conv2d_fp64(case):
           2e-5, 2e-5, "no bias")
 
 
+@pytest.mark.parametrize("case", [(64, 48, 700, 3, False), (128, 192, 512, 1, False), (192, 64, 1300, 1, True),
+                                  (64, 16, 36, 2, True)])
+def test_gemm_tokens_mfma_vs_fp64(case):
+    """gemm_tokens (bf16 hi/lo split on the matrix cores, producer / consumer waves) == W @ X[b] in float64:
+    strided batches out of one tokens-last matrix, ragged token tiles, transposed weight."""
+    from mm_unet_amd.mfma_gemm import gemm_tokens
+    M, K, T, B, trans = case
+    gen = torch.Generator().manual_seed(M + K + T)
+    W = torch.randn(M, K, generator=gen) / K ** 0.5
+    X = torch.randn(K, B * T, generator=gen)
+    ref = torch.stack([W.double() @ X[:, b * T:(b + 1) * T].double() for b in range(B)])      # (B, M, T)
+    Wd = (W.t().contiguous() if trans else W).to(DEV)
+    out = torch.full((B, M, T), float("nan"), device=DEV)
+    gemm_tokens(Wd, X.to(DEV), out, M, K, T, B, B * T, T, T, M * T, transposed_weight=trans)
+    close(out, ref.float(), 5e-5, 5e-5, "W @ X")   # three bf16 products per term: ~2^-16 relative each
+
+
+def test_dsc_gemm_mfma_path_matches_library_path():
+    """tall_gemm.dsc_gemm with the matrix-core GEMMs (forward, input gradient) against its hipBLASLt path."""
+    import mm_unet_amd.mfma_gemm as mg
+    from mm_unet_amd.tall_gemm import dsc_gemm
+    B, Cin, K, Cout, T = 2, 64, 3, 128, 24 * 33
+    gen = torch.Generator().manual_seed(21)
+    W2 = (torch.randn(Cout, Cin * K, generator=gen) / (Cin * K) ** 0.5).to(DEV)
+    S = torch.randn(Cin * K, B * T, generator=gen).to(DEV)
+    g = torch.randn(B, Cout, T, generator=gen).to(DEV)
+    res = {}
+    for on in (False, True):
+        mg.ENABLED, min_tiles = on, mg.MIN_TILES
+        mg.MIN_TILES = 1          # the size heuristic would keep this small problem on the library path
+        try:
+            w, s_ = W2.clone().requires_grad_(), S.clone().requires_grad_()
+            out = dsc_gemm(w, s_, B)
+            out.backward(g)
+        finally:
+            mg.ENABLED, mg.MIN_TILES = True, min_tiles
+        res[on] = (out.detach(), w.grad, s_.grad)
+    close(res[True][0], res[False][0], 1e-4, 1e-4, "out")
+    close(res[True][1], res[False][1], 1e-3, 1e-3, "d weight")
+    close(res[True][2], res[False][2], 1e-4, 1e-4, "d samples")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
