@@ -1,0 +1,29 @@
+"""Device time of ATen elementwise / reduction / copy ops of one MM_Net training step, grouped by op and input shape."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mm_unet_amd.loss import DICE_BCE_Loss
+from mm_unet_amd.mmunet import MM_Net
+from mm_unet_amd.train_step import TrainStep, make_optimizer
+dev = torch.device("cuda", 0)
+torch.manual_seed(50)
+model = MM_Net(num_classes=1).to(dev).train()
+step = TrainStep(model, DICE_BCE_Loss(), make_optimizer(model))
+g = torch.Generator(device=dev).manual_seed(1000)
+x = torch.randn(8, 3, 512, 512, device=dev, generator=g)
+t = (torch.rand(8, 1, 512, 512, device=dev, generator=g) > 0.88).float()
+for _ in range(3):
+    step(x, t)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    step(x, t)
+    torch.cuda.synchronize()
+skip = ("convolution", "mm", "bmm", "addmm", "Fn", "Backward", "autograd", "hip", "Memcpy", "Memset")
+rows = [e for e in prof.key_averages(group_by_input_shape=True)
+        if e.key.startswith("aten::") and e.self_device_time_total > 0 and not any(s in e.key for s in skip)]
+tot = {}
+for e in rows:
+    tot[e.key] = tot.get(e.key, 0) + e.self_device_time_total
+print({k: round(v / 1e3, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:25]})
+for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:50]:
+    print(f"{e.self_device_time_total/1e3:7.2f} ms n={e.count:3d} {e.key.replace('aten::',''):24s} {str(e.input_shapes)[:120]}")
