@@ -110,6 +110,14 @@ def dsc_gemm(W2, samples, batch):
     return _DscGemmFn.apply(W2, samples, batch)
 
 
+def _mfma_ok(rows, inner, B, L, W, X, out):
+    """One strided-batch launch of the matrix-core GEMM instead of B library calls (both operands addressed in
+    place): unit token stride, strides that keep 16-byte alignment."""
+    return (mfma_gemm.supported(rows, inner, B * L, W, X, out) and L % 4 == 0 and W.is_contiguous()
+            and X.stride(2) == 1 and out.stride(2) == 1
+            and all(t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 for t in (X, out)))
+
+
 class _ProjBclFn(torch.autograd.Function):
     """``W (O, I)`` applied per batch item between the two layouts that meet at the Mamba block of RCG
     (MMUNet.py:398-412): feature maps are ``[B][C][L]`` (batch-major), the fused Mamba path works on
@@ -128,8 +136,11 @@ class _ProjBclFn(torch.autograd.Function):
             out = torch.empty((O, B, L), device=X.device, dtype=X.dtype).permute(1, 0, 2)   # [O][B][L]
         else:
             out = torch.empty((B, O, L), device=X.device, dtype=X.dtype)
-        for b in range(B):
-            torch.mm(W, X[b], out=out[b])
+        if _mfma_ok(O, I, B, L, W, X, out):
+            mfma_gemm.gemm_tokens(W, X, out, O, I, L, B, X.stride(1), X.stride(0), out.stride(1), out.stride(0))
+        else:
+            for b in range(B):
+                torch.mm(W, X[b], out=out[b])
         ctx.save_for_backward(W, X)
         ctx.to_cb = to_cb
         return out
@@ -146,9 +157,13 @@ class _ProjBclFn(torch.autograd.Function):
                 dX = torch.empty((B, I, L), device=X.device, dtype=X.dtype)
             else:
                 dX = torch.empty((I, B, L), device=X.device, dtype=X.dtype).permute(1, 0, 2)
-            Wt = W.t()
-            for b in range(B):
-                torch.mm(Wt, G[b], out=dX[b])
+            if _mfma_ok(I, W.shape[0], B, L, W, G, dX):
+                mfma_gemm.gemm_tokens(W, G, dX, I, W.shape[0], L, B, G.stride(1), G.stride(0), dX.stride(1),
+                                      dX.stride(0), transposed_weight=True)
+            else:
+                Wt = W.t()
+                for b in range(B):
+                    torch.mm(Wt, G[b], out=dX[b])
         if ctx.needs_input_grad[0]:
             dW = nt_splitk(G[0], X[0])
             for b in range(1, B):

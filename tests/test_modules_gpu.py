@@ -667,6 +667,37 @@ def test_dsc_gemm_mfma_path_matches_library_path():
     close(res[True][2], res[False][2], 1e-4, 1e-4, "d samples")
 
 
+@pytest.mark.parametrize("to_cb", [True, False])
+def test_proj_bcl_mfma_path_matches_library_path(to_cb):
+    """tall_gemm.proj_bcl (the projections at RCG's Mamba block, both layout directions): one strided-batch
+    matrix-core GEMM against the per-batch hipBLASLt calls -- output, input gradient, weight gradient."""
+    import mm_unet_amd.mfma_gemm as mg
+    from mm_unet_amd.tall_gemm import proj_bcl
+    B, I, O, L = 2, 64, 128, 1536
+    gen = torch.Generator().manual_seed(31)
+    W = (torch.randn(O, I, generator=gen) / I ** 0.5).to(DEV)
+    X = torch.randn(B, I, L, generator=gen).to(DEV)
+    if not to_cb:
+        X = X.permute(1, 0, 2).contiguous().permute(1, 0, 2)          # laid out [I][B][L]
+    g = torch.randn(B, O, L, generator=gen).to(DEV)
+    res = {}
+    for on in (False, True):
+        mg.ENABLED, min_tiles = on, mg.MIN_TILES
+        mg.MIN_TILES = 1
+        try:
+            w, x = W.clone().requires_grad_(), X.detach().requires_grad_()
+            out = proj_bcl(w, x, to_cb)
+            out.backward(g)
+        finally:
+            mg.ENABLED, mg.MIN_TILES = True, min_tiles
+        res[on] = (out.detach(), w.grad, x.grad, out.stride())
+    assert res[True][3] == res[False][3]
+    close(res[True][0], torch.einsum("oi,bil->bol", W, X), 1e-4, 1e-4, "out vs einsum")
+    close(res[True][0], res[False][0], 1e-4, 1e-4, "out")
+    close(res[True][1], res[False][1], 1e-3, 1e-3, "d weight")
+    close(res[True][2], res[False][2], 1e-4, 1e-4, "d input")
+
+
 def test_train_step_graph_replay_matches_eager():
     """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) follows the eager trajectory."""
     from mm_unet_amd.loss import DICE_BCE_Loss
