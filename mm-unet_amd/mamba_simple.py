@@ -30,6 +30,60 @@ from . import tri_order
 from .tall_gemm import proj_bcl, proj_tokens
 
 
+# A = -exp(A_log) of every Mamba block, formed once per model forward by two multi-tensor launches (and one in the
+# backward) instead of exp / neg / mul kernels per block -- 47 blocks x 5 launches of 2.5 us each in MM_Net.
+_A_CACHE = {}
+
+
+class _NegExpAll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *params):
+        outs = torch._foreach_exp([p.detach().float() for p in params])
+        torch._foreach_neg_(outs)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*outs)
+        ctx.dtypes = [p.dtype for p in params]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        outs = ctx.saved_tensors
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        res = [None] * len(grads)
+        if idx:
+            prod = torch._foreach_mul([grads[i] for i in idx], [outs[i] for i in idx])     # dA_log = dA * A
+            for i, v in zip(idx, prod):
+                res[i] = v.to(ctx.dtypes[i])
+        return tuple(res)
+
+
+class precomputed_A:
+    """``with precomputed_A(model):`` -- every ``Mamba`` inside ``model`` takes its ``A`` from one batched
+    ``-exp(A_log)`` for the duration of the block (the cache never outlives the forward pass it was built in)."""
+
+    def __init__(self, model):
+        self.params = []
+        for m in model.modules():
+            if isinstance(m, Mamba):
+                self.params += m.used_A_params()
+
+    def __enter__(self):
+        if self.params and all(p.is_cuda for p in self.params):
+            for p, a in zip(self.params, _NegExpAll.apply(*self.params)):
+                _A_CACHE[id(p)] = a
+        return self
+
+    def __exit__(self, *exc):
+        _A_CACHE.clear()
+        return False
+
+
+def neg_exp(param):
+    """``-exp(param.float())`` (mamba_simple.py:209,230,251,304), from the per-forward cache when there is one."""
+    a = _A_CACHE.get(id(param))
+    return a if a is not None else -torch.exp(param.float())
+
+
 class Mamba(nn.Module):
     def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
                  dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False, use_fast_path=True,
@@ -103,9 +157,14 @@ class Mamba(nn.Module):
         # (RCG, MMUNet.py:409) can switch them off and save the re-ordering copy of o_3
         self.return_branch_outputs = True
 
+    def used_A_params(self):
+        """The A_log parameters this block's forward reads (the others never receive a gradient)."""
+        return {"v3": [self.A_log, self.A_b_log, self.A_s_log], "v2": [self.A_log, self.A_b_log]}.get(
+            self.bimamba_type, [self.A_log])
+
     def _branch(self, xz, suffix):
         g = lambda n: getattr(self, n + suffix)  # noqa: E731
-        A = -torch.exp(getattr(self, {"": "A_log", "_b": "A_b_log", "_s": "A_s_log"}[suffix]).float())
+        A = neg_exp(getattr(self, {"": "A_log", "_b": "A_b_log", "_s": "A_s_log"}[suffix]))
         return mamba_inner_fn_no_out_proj(xz, g("conv1d").weight, g("conv1d").bias, g("x_proj").weight,
                                           g("dt_proj").weight, A, None, None, g("D").float(),
                                           delta_bias=g("dt_proj").bias.float(), delta_softplus=True)
@@ -179,13 +238,13 @@ class Mamba(nn.Module):
                 out_b = self._branch(xz.flip([-1]), "_b")
                 out = self._out_proj(out + out_b.flip([-1]))
             else:
-                A = -torch.exp(self.A_log.float())
+                A = neg_exp(self.A_log)
                 out = mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                      self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, None, None,
                                      self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
         else:
             # un-fused path (mamba_simple.py:319-361), uni-directional
-            A = -torch.exp(self.A_log.float())
+            A = neg_exp(self.A_log)
             x, z = xz.chunk(2, dim=1)
             x = causal_conv1d_fn(x, self.conv1d.weight.view(self.d_inner, self.d_conv), self.conv1d.bias,
                                  self.activation)

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .mamba_simple import Mamba
+from .mamba_simple import Mamba, neg_exp, precomputed_A
 from . import conv3x3_mfma, conv3x3_small, morph_coords, norm_fused
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
@@ -141,7 +141,7 @@ class MMConv(nn.Module):
         with torch.autocast("cuda", enabled=False):  # a 2K-channel fp32 scan; grid_sample is fp32 anyway
             xz = morph_coords.zigzag_inproj(offset, m.in_proj.weight)
             out_z = mamba_inner_fn_no_out_proj(xz, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
-                                               m.dt_proj.weight, -torch.exp(m.A_log.float()), None, None,
+                                               m.dt_proj.weight, neg_exp(m.A_log), None, None,
                                                m.D.float(), delta_bias=m.dt_proj.bias.float(), delta_softplus=True)
             return morph_coords.coords_outproj(offset, out_z, m.out_proj.weight, self.altho, self.extend_scope)
 
@@ -391,6 +391,12 @@ class MM_Net(nn.Module):
         self.decoder2 = DecoderBlock(in_channels=128, out_channels=64, num_slices=s[0], d_state=d_state)
 
     def forward(self, x):
+        if getattr(self, "_a_batch", None) is None:
+            self._a_batch = [precomputed_A(self)]   # in a list: not a sub-module, just the parameter list found once
+        with self._a_batch[0]:          # A = -exp(A_log) of all 50 Mamba blocks in two launches
+            return self._forward(x)
+
+    def _forward(self, x):
         size = x.size()[2:]
         up = lambda t: bilinear_resize(t, size=size)  # noqa: E731
         e1 = run_fused(self.encoder1, x)
