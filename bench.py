@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512, help="image side (BASELINE: 512)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="compute dtype; f32 = what the reference's train.py runs (no autocast)")
+    ap.add_argument("--d-state", type=int, default=16, help="Mamba state size (BASELINE config 5: 64)")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -167,7 +168,7 @@ def main():
         from mm_unet_amd.mmunet import MM_Net
         from mm_unet_amd.train_step import InferStep
         torch.manual_seed(50)
-        step = InferStep(MM_Net(num_classes=1).to(dev), amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
+        step = InferStep(MM_Net(num_classes=1, d_state=args.d_state).to(dev), amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
                          use_graph=not args.no_graph)
         gen = torch.Generator(device=dev).manual_seed(1000 + rank)
         images = torch.randn(args.batch, 3, args.size, args.size, device=dev, generator=gen)
@@ -193,7 +194,7 @@ def main():
     from mm_unet_amd.train_step import TrainStep, make_optimizer
 
     torch.manual_seed(50)  # reference: same_seeds(50), train.py:160
-    model = MM_Net(num_classes=1).to(dev).train()
+    model = MM_Net(num_classes=1, d_state=args.d_state).to(dev).train()
     if world > 1:
         broadcast_module_state(model)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
@@ -228,12 +229,13 @@ def main():
         ms = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
         line = {
-            "metric": "images/sec fwd+bwd, MM-UNet 3x512x512 bs=8 per GPU",
+            "metric": f"images/sec fwd+bwd, MM-UNet 3x{args.size}x{args.size} bs={args.batch} per GPU",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"MM_Net train step (fwd + Dice+BCE + bwd + grad all-reduce + AdamW), "
-                                   f"3x{args.size}x{args.size}, bs={args.batch}/GPU, random-init seed 50",
+                                   f"3x{args.size}x{args.size}, bs={args.batch}/GPU, random-init seed 50"
+                                   + (f", d_state={args.d_state}" if args.d_state != 16 else ""),
                        "global_batch": args.batch * world, "image": [3, args.size, args.size],
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": step.reducer.payload_bytes(),
                        "launch": "hip-graph replay" if graph else "eager",
