@@ -142,14 +142,16 @@ def bn_act_supported(x, bn):
         (bn.track_running_stats or bn.training) and bn.momentum is not None
 
 
-def bn_act(x, bn, act=None, residual=None):
-    """``act(bn(x))`` for an ``nn.BatchNorm2d`` (training or eval statistics): the same two-pass kernels with
-    the GroupNorm stage switched off -- BatchNorm and ReLU read and write the activation once each way
-    together instead of once each."""
+def bn_act(x, bn, act=None, residual=None, pre_bias=None):
+    """``act(bn(x + pre_bias[None, :, None, None]))`` for an ``nn.BatchNorm2d`` (training or eval statistics): the
+    same two-pass kernels with the GroupNorm stage switched off -- BatchNorm and ReLU read and write the
+    activation once each way together instead of once each.  ``pre_bias``: the bias of the convolution that
+    produced ``x``, folded into the statistics (its gradient comes out of the same backward algebra, so the
+    convolution needs neither a bias add nor a bias-gradient reduction over the whole activation)."""
     training = bool(bn.training or not bn.track_running_stats)
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return GnBnActFn.apply(x, None, None, bn.weight, bn.bias, None, bn.running_mean, bn.running_var, x.shape[1],
+    return GnBnActFn.apply(x, None, None, bn.weight, bn.bias, pre_bias, bn.running_mean, bn.running_var, x.shape[1],
                            -1.0, True, training, bn.eps, bn.momentum, ACT[act], False, residual)
 
 

@@ -22,7 +22,18 @@ def _conv_bn_relu(seq, x):
             i += 2 if relu else 1
             continue
         if x.is_cuda and conv3x3_mfma.module_supported(m, x):   # dense 3x3: implicit GEMM on the bf16 matrix cores
-            x = conv3x3_mfma.conv3x3_mfma(x, m.weight, m.bias)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if m.bias is not None and isinstance(nxt, nn.BatchNorm2d) and m.bias.dtype == torch.float32:
+                # Conv2d(+bias) -> BatchNorm2d [-> ReLU]: the bias is folded into the normalisation
+                x = conv3x3_mfma.conv3x3_mfma(x, m.weight, None)
+                if norm_fused.bn_act_supported(x, nxt):
+                    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                    x = norm_fused.bn_act(x, nxt, "relu" if relu else None, pre_bias=m.bias)
+                    i += 3 if relu else 2
+                    continue
+                x = x + m.bias.view(1, -1, 1, 1)
+            else:
+                x = conv3x3_mfma.conv3x3_mfma(x, m.weight, m.bias)
         else:
             x = m(x)
         i += 1

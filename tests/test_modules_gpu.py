@@ -506,15 +506,20 @@ def test_gn_bn_act_vs_modules(cfg):
         assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked)
 
 
+@pytest.mark.parametrize("with_bias", [False, True])
 @pytest.mark.parametrize("cfg", [((2, 8, 12, 10), "relu", True), ((3, 5, 7, 9), None, True), ((2, 16, 8, 8), "relu", False)])
-def test_bn_act_vs_modules(cfg):
-    """bn_act == act(BatchNorm2d(x)) (the GroupNorm stage of the fused normalisation switched off)."""
+def test_bn_act_vs_modules(cfg, with_bias):
+    """bn_act == act(BatchNorm2d(x [+ bias])) (the GroupNorm stage of the fused normalisation switched off);
+    with_bias: the producing convolution's bias folded into the statistics, its gradient from the same algebra
+    (in training mode analytically zero -- BatchNorm removes a per-channel shift -- so compared with an absolute
+    floor)."""
     import copy
     from mm_unet_amd.norm_fused import bn_act
     (B, C, H, W), actn, train = cfg
     gen = torch.Generator().manual_seed(43)
     x = torch.randn(B, C, H, W, generator=gen) * 1.3 - 0.2
     g = torch.randn(B, C, H, W, generator=gen)
+    pb = (torch.randn(C, generator=gen) * 0.7) if with_bias else None
     bn = torch.nn.BatchNorm2d(C)
     with torch.no_grad():
         bn.weight.copy_(torch.randn(C, generator=gen) * 0.5 + 1)
@@ -525,10 +530,12 @@ def test_bn_act_vs_modules(cfg):
     bn.train(train), bn_d.train(train)
     act = {None: lambda t: t, "relu": torch.relu}[actn]
     xr = x.clone().requires_grad_()
-    ref = act(bn(xr))
+    pbr = pb.clone().requires_grad_() if with_bias else None
+    ref = act(bn(xr + pbr.view(1, -1, 1, 1) if with_bias else xr))
     ref.backward(g)
     xg = x.to(DEV).requires_grad_()
-    out = bn_act(xg, bn_d, actn)
+    pbg = pb.to(DEV).requires_grad_() if with_bias else None
+    out = bn_act(xg, bn_d, actn, pre_bias=pbg)
     out.backward(g.to(DEV))
     close(out, ref, 1e-4, 1e-4, "out")
     close(xg.grad, xr.grad, 1e-3, 1e-4, "d input")
@@ -536,6 +543,8 @@ def test_bn_act_vs_modules(cfg):
     close(bn_d.bias.grad, bn.bias.grad, 1e-3, 1e-3, "d bias")
     close(bn_d.running_mean, bn.running_mean, 1e-5, 1e-5, "running_mean")
     close(bn_d.running_var, bn.running_var, 1e-4, 1e-5, "running_var")
+    if with_bias:
+        close(pbg.grad, pbr.grad, 1e-3, 2e-4, "d pre_bias")
 
 
 def test_mamba_v3_forward_bcl_matches_forward():
