@@ -120,6 +120,16 @@ def conv_roofline(dev, iters=20):
                               "frac": round(3 * alg / (ms * 1e-3) / 1e12 / 2500.0, 4)})
     best = max(out["shapes"], key=lambda s_: s_["frac"])
     out["achieved"], out["frac"] = best["achieved"], best["frac"]
+    tpath = os.path.join(ROOT, "profiles", "conv3x3_mfma_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            for s_ in out["shapes"]:
+                key = "x".join(str(v) for v in s_["input"]) + "->" + str(s_["out_channels"])
+                s_["traffic"] = tj.get(key, {}).get("hbm_bytes_per_launch")
+            out["traffic"] = best.get("traffic")
+        except Exception:
+            pass
     return out
 
 
