@@ -307,6 +307,14 @@ typedef struct {
 size_t mmu_conv3x3_mfma_workspace_bytes(int in_channels, int out_channels);
 int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream);
 
+/* The weight gradient of the same convolution (in_channels % 32 == 0, out_channels % 64 == 0, width % 4 == 0), same
+ * struct read as: input = x [batch, in_channels, H, W], weight = dout [batch, out_channels, H, W] (16-byte aligned),
+ * out = dweight [out_channels][in_channels][3][3]; bias / transposed are ignored.  The contraction runs over pixels: the
+ * patch operand is read from LDS with ds_read_b64_tr_b16.  Deterministic (per-workgroup partials added in fixed
+ * order).  workspace: mmu_conv3x3_wgrad_mfma_workspace_floats() floats. */
+size_t mmu_conv3x3_wgrad_mfma_workspace_floats(int batch, int in_channels, int out_channels, int height, int width);
+int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *stream);
+
 /* ---- W (rows x inner) times a tokens-last matrix, on the bf16 matrix cores with float32 accuracy ------------- */
 /* out[b] = W . X[b] for b < batch;  X[b] = x + b*x_bs, `inner` rows of `tokens` contiguous floats, row stride x_rs;
  * out[b] = out + b*out_bs, `rows` rows, row stride out_rs (strides in elements).  rows % 64 == 0, inner % 16 == 0.

@@ -134,7 +134,8 @@ EXPORTS = (
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
     "mmu_conv3x3_small_wgrad_workspace_floats",
-    "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_gemm_tokens_mfma",
+    "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
+    "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
     "mmu_gemm_tokens_workspace_bytes", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_debug_wave_scan",
@@ -173,7 +174,7 @@ def lib():
                      ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
-                     ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams)):
+                     ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -183,6 +184,8 @@ def lib():
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_gemm_tokens_workspace_bytes.restype = ctypes.c_size_t
     L.mmu_gemm_tokens_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mmu_conv3x3_wgrad_mfma_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_conv3x3_wgrad_mfma_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_conv3x3_mfma_workspace_bytes.restype = ctypes.c_size_t
     L.mmu_conv3x3_mfma_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     L.mmu_mamba_post_small_workspace_floats.restype = ctypes.c_size_t

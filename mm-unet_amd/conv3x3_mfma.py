@@ -3,7 +3,8 @@
 
 Used for CBAM's 3x3 64->64 convolutions (src/UM_Net/MMUNet.py:313-338) and the plain Unet's conv stack
 (model.py:5-20).  Forward and input gradient run the HIP kernel (the gradient on transposed / flipped weights);
-the weight gradient is ATen's (MIOpen).  float32 NCHW, Cin % 16 == 0, Cout % 64 == 0, W % 4 == 0; anything else
+the weight gradient has its own matrix-core kernel (csrc/conv3x3_wgrad_mfma.hip, Cin % 32 == 0) and falls back to
+ATen's (MIOpen) otherwise.  float32 NCHW, Cin % 16 == 0, Cout % 64 == 0, W % 4 == 0; anything else
 is the caller's ``F.conv2d``.
 """
 import torch
@@ -28,6 +29,27 @@ def _run(inp, weight, bias, cin, cout, transposed):
     with torch.cuda.device(inp.device):
         _lib.check(_lib.lib().mmu_conv3x3_mfma(p, _lib.stream_of(inp)))
     return out
+
+
+WGRAD_MFMA = True   # False: the weight gradient comes from ATen / MIOpen (tests compare the two)
+
+
+def wgrad_supported(x, cout):
+    return WGRAD_MFMA and x.shape[1] % 32 == 0 and cout % 64 == 0 and x.shape[3] % 4 == 0
+
+
+def _wgrad(x, g, cout):
+    """dW of conv2d(x, W, padding=1) from x [B, Cin, H, W] and dout g [B, Cout, H, W] (csrc/conv3x3_wgrad_mfma.hip)."""
+    B, cin, H, W = x.shape
+    dw = torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().mmu_conv3x3_wgrad_mfma_workspace_floats(B, cin, cout, H, W), device=x.device,
+                     dtype=torch.float32)
+    p = _lib.Conv3x3MfmaParams()
+    p.batch, p.in_channels, p.out_channels, p.height, p.width, p.transposed = B, cin, cout, H, W, 0
+    p.input, p.weight, p.out, p.workspace = x.data_ptr(), g.data_ptr(), dw.data_ptr(), ws.data_ptr()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().mmu_conv3x3_wgrad_mfma(p, _lib.stream_of(x)))
+    return dw
 
 
 class Conv3x3MfmaFn(torch.autograd.Function):
@@ -59,7 +81,10 @@ class Conv3x3MfmaFn(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or need_b:
+        if ctx.needs_input_grad[1] and wgrad_supported(x, cout) and g.data_ptr() % 16 == 0:
+            dw = _wgrad(x, g, cout)
+            db = g.sum(dim=(0, 2, 3)) if need_b else None
+        elif ctx.needs_input_grad[1] or need_b:
             _, dw, db = torch.ops.aten.convolution_backward(
                 g, x, weight, [cout] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                 [False, bool(ctx.needs_input_grad[1]), bool(need_b)])

@@ -637,7 +637,8 @@ def test_mamba_small_block_fused_pre_kernel(d_model):
             close(res[mode][2][k], v, 2e-3, 1e-4, f"{k} {mode}")
 
 
-@pytest.mark.parametrize("case", [(2, 16, 64, 13, 20), (1, 64, 64, 32, 64), (2, 32, 128, 9, 132), (1, 64, 64, 8, 4)])
+@pytest.mark.parametrize("case", [(2, 16, 64, 13, 20), (1, 64, 64, 32, 64), (2, 32, 128, 9, 132), (1, 64, 64, 8, 4),
+                                  (3, 64, 64, 70, 136)])
 def test_conv3x3_mfma_vs_conv2d_fp64(case):
     """conv3x3_mfma (bf16 hi/lo split on the matrix cores) == F.conv2d in float64 on CPU: output, input gradient
     (same kernel on flipped weights), weight / bias gradient.  float32-grade tolerance: 3 bf16 products per term
@@ -657,12 +658,13 @@ def test_conv3x3_mfma_vs_conv2d_fp64(case):
     assert supported(xg, wg)
     out = conv3x3_mfma(xg, wg, bg)
     out.backward(g.to(DEV))
-    close(out, ref.float(), 2e-5, 2e-5, "out")
-    close(xg.grad, xr.grad.float(), 2e-5, 2e-5, "d input")
-    close(wg.grad, wr.grad.float(), 1e-3, 1e-3, "d weight")
+    close(out, ref.float(), 5e-5, 5e-5, "out")
+    close(xg.grad, xr.grad.float(), 5e-5, 5e-5, "d input")
+    # Cin % 32 == 0: the matrix-core weight gradient (transposed LDS reads); otherwise ATen's
+    close(wg.grad, wr.grad.float(), 1e-4, 1e-4 * float(wr.grad.abs().max()), "d weight")
     close(bg.grad, br.grad.float(), 1e-4, 1e-4, "d bias")
     close(conv3x3_mfma(xg.detach(), wg.detach()), F.conv2d(x.double(), w.double(), None, padding=1).float(),
-          2e-5, 2e-5, "no bias")
+          5e-5, 5e-5, "no bias")
 
 
 @pytest.mark.parametrize("case", [(64, 48, 700, 3, False), (128, 192, 512, 1, False), (192, 64, 1300, 1, True),

@@ -1,6 +1,6 @@
 """model.py's plain Unet (every layer a dense 3x3 conv, 64-1024 channels), training step
-fwd + Dice+BCE + bwd on 8 x 3 x 512 x 512, with the matrix-core convolution (csrc/conv3x3_mfma.hip: forward and input
-gradient) and with MIOpen only."""
+fwd + Dice+BCE + bwd on 8 x 3 x 512 x 512, with the matrix-core convolutions (csrc/conv3x3_mfma.hip: forward and input
+gradient; csrc/conv3x3_wgrad_mfma.hip: weight gradient) and with MIOpen only."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mm_unet_amd.conv3x3_mfma as cm
@@ -18,7 +18,7 @@ def run(n):
         model.zero_grad(set_to_none=True)
         loss_fn(model(x), t).backward()
     torch.cuda.synchronize()
-for name, on in (("matrix-core conv3x3_mfma (fwd + dgrad), MIOpen wgrad", True), ("MIOpen only", False)):
+for name, on in (("matrix-core convolutions (forward, input gradient, weight gradient)", True), ("MIOpen only", False)):
     cm.supported = supported if on else (lambda x_, w_: False)
     run(3)
     t0 = time.perf_counter()
