@@ -116,12 +116,18 @@ __device__ __forceinline__ void buf_load8<bf16_t>(rsrc_t r, unsigned voff, unsig
         o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
 }
+// Stores of MORE than 64 bits never carry a register in soffset: the store reads its data registers after it
+// has issued, a VALU write of them within two wait states corrupts the data, and LLVM's hazard recogniser pads
+// that case only when soffset is not a register (the GCN3 rule "an SGPR offset needs no wait states") -- on
+// gfx950 the exemption does not hold (seen in the streaming scan: buffer_store_dwordx4 v[2:5] ... s0 offen
+// followed directly by v_mul_f32 v2 corrupted element 0 of some lanes).  The scalar part goes into the VGPR
+// offset (one v_add), and the compiler pads.
 template <typename T>
 __device__ __forceinline__ void buf_store8(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[8]);
 template <>
 __device__ __forceinline__ void buf_store8<float>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[8]) {
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, voff, soff, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, r, voff + 16, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, voff + soff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, r, voff + soff + 16, 0, 0);
 }
 template <>
 __device__ __forceinline__ void buf_store8<bf16_t>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[8]) {
@@ -129,7 +135,7 @@ __device__ __forceinline__ void buf_store8<bf16_t>(rsrc_t r, unsigned voff, unsi
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         w[i] = (unsigned)from_f32<bf16_t>(v[2 * i]).bits | ((unsigned)from_f32<bf16_t>(v[2 * i + 1]).bits << 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{w[0], w[1], w[2], w[3]}, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{w[0], w[1], w[2], w[3]}, r, voff + soff, 0, 0);
 }
 
 // 4-token forms (one 16-B / 8-B access per lane)
@@ -151,7 +157,7 @@ template <typename T>
 __device__ __forceinline__ void buf_store4(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[4]);
 template <>
 __device__ __forceinline__ void buf_store4<float>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[4]) {
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, voff + soff, 0, 0);
 }
 template <>
 __device__ __forceinline__ void buf_store4<bf16_t>(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[4]) {

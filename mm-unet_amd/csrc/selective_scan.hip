@@ -33,27 +33,11 @@
 //   adjoint: gamma_t = a_t (C_t dy_t + gamma_{t+1});  g_t = C_t dy_t + gamma_{t+1}
 #include <algorithm>
 #include "mmu_common.h"
+#include "scan_common.h"
 #include "../../include/mmunet_amd.h"
 
 namespace {
 
-struct ScanArgs {
-    int batch, dim, seqlen, dstate, ngroups, n_chunks, softplus;
-    int vec_io;   // u/delta/z/out/... K-groups naturally aligned
-    int vec_bc;   // B/C rows K-aligned
-    int vec_dbc;  // dB/dC rows K-aligned
-    const void *u, *delta, *z, *B, *C, *dout;
-    const float *A, *D, *delta_bias;
-    void *out, *out_z, *du, *ddelta, *dz;
-    float *x;        // [B][D][nc][N][2]  (P, H)
-    float *gx;       // [B][D][nc][N][2]  (Q, Gamma)   (bwd)
-    float *dB, *dC;  // [B][G][N][L] fp32
-    float *part;     // [B][nc][D][N+2]   (bwd partials of dA, dD, dbias)
-    long u_bs, u_ds, delta_bs, delta_ds, z_bs, z_ds, out_bs, out_ds, out_z_bs, out_z_ds;
-    long dout_bs, dout_ds, du_bs, du_ds, ddelta_bs, ddelta_ds, dz_bs, dz_ds;
-    long A_ds, A_ns, B_bs, B_gs, B_ns, C_bs, C_gs, C_ns;
-    long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
-};
 
 // Stage one [N][T] tile of B or C (tokens [t0, t0+T) of batch b, group g) into LDS as fp32.
 template <typename io_t, int K, bool FULL>
@@ -173,35 +157,6 @@ __global__ __launch_bounds__(1024) void chunk_reduce_kernel(ScanArgs p) {
 // Every ds_read_b128 of a wave is 1 KiB contiguous (conflict-free; the natural [n][512] order put lanes
 // 32 B apart = 2-way conflicts, 42 % of the LDS cycles of the first version).  An odd dstate gets a
 // zero partner row: B = C = 0, A = 0, h0 = 0 contribute nothing.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f exp2_2(v2f x) { return v2f{fast_exp2(x.x), fast_exp2(x.y)}; }
-// x * s[HI] on both halves in one v_pk_mul_f32 (op_sel broadcast): per-token scalars stay packed two to
-// a register pair instead of being splatted (16 fewer VGPRs in the forward apply kernel).
-// NEVER feed it a fresh v_exp / v_log / v_rcp result: gfx950 needs a wait state between a transcendental
-// op and a VALU consumer, and the compiler's hazard recogniser does not look inside inline asm (seen as
-// stale odd-state sums in chunk_reduce8).  Exp results go to compiler-generated v_pk_fma only.
-template <int HI>
-__device__ __forceinline__ v2f mul_bcast(v2f s, v2f x) {
-    v2f r;
-    if constexpr (HI)
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(s), "v"(x));
-    else
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(s), "v"(x));
-    return r;
-}
-
-// x * s[HI] + c in one v_pk_fma_f32 (same rule: no fresh transcendental results as inputs)
-template <int HI>
-__device__ __forceinline__ v2f fma_bcast(v2f s, v2f x, v2f c) {
-    v2f r;
-    if constexpr (HI)
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(s), "v"(x), "v"(c));
-    else
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(s), "v"(x), "v"(c));
-    return r;
-}
-
 template <typename io_t, bool FULL>
 __device__ __forceinline__ void stage_pair8(float *__restrict__ s, const io_t *__restrict__ g, long row_stride,
                                             int N, int t0, int L, bool vec) {
@@ -223,15 +178,6 @@ __device__ __forceinline__ void stage_pair8(float *__restrict__ s, const io_t *_
     }
 }
 
-__device__ __forceinline__ void pair8_read(const float *tile, int pr, int lane, v2f (&v)[8]) {
-    const float4 *src = reinterpret_cast<const float4 *>(tile) + pr * 256 + lane;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 f = src[q * 64];
-        v[2 * q] = v2f{f.x, f.y};
-        v[2 * q + 1] = v2f{f.z, f.w};
-    }
-}
 
 // ---------------------------------------------------------------------------
 // K1 (fast form, 128-token chunks): per-chunk aggregates with 8 tokens per lane, so one wave covers
@@ -1585,27 +1531,6 @@ inline int items_per_lane(int dstate) { return dstate <= 16 ? 2 : (dstate <= 32 
 inline bool aligned_to(const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; }
 inline bool mult(long v, int k) { return (v % k) == 0; }
 
-template <typename F>
-int set_lds(F kernel, size_t bytes) {
-    if (bytes > 160 * 1024) return mmu_fail("selective_scan: needs %zu B of LDS (> 160 KiB)", bytes);
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return mmu_fail("hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    return 0;
-}
-
-// runtime bool -> template bool
-#define MMU_BOOL(cond, NAME, ...)        \
-    do {                                 \
-        if (cond) {                      \
-            constexpr bool NAME = true;  \
-            __VA_ARGS__                  \
-        } else {                         \
-            constexpr bool NAME = false; \
-            __VA_ARGS__                  \
-        }                                \
-    } while (0)
 
 // K1 in its fast (8 tokens / lane, 4 chunks per wave) or generic form
 template <typename io_t, int K, bool BWD>
@@ -1643,6 +1568,8 @@ int launch_fwd(const ScanArgs &a, hipStream_t st) {
     const int W = dpg < 16 ? dpg : 16;
     dim3 grid(a.n_chunks, a.batch, a.ngroups);
     const bool full = a.vec_io && a.vec_bc && a.seqlen % T == 0;  // no ragged tail, everything aligned
+    // enough (batch, channel) rows to fill the chip: stream each row front to back (selective_scan_stream.hip)
+    if (const int r = mmu_scan_fwd_stream(a, sizeof(io_t) == 4 ? MMU_DTYPE_F32 : MMU_DTYPE_BF16, st)) return r < 0;
     if (int r = launch_reduce<io_t, K, false>(a, W, st)) return r;
     if (int r = launch_carry(a.x, a.batch, a.dim, N, a.n_chunks, 0, st)) return r;
     {

@@ -1,0 +1,275 @@
+// selective_scan_stream.hip -- streaming selective-scan forward for gfx950 (MI355X).
+//
+// Same math as the reference kernel (requirements/Mamba/mamba/csrc/selective_scan/selective_scan_fwd_kernel.cuh:147-298)
+//   dl = softplus(delta + bias) ;  a = exp2(dl * A * log2e) ;  h_t = a h_{t-1} + dl u B ;  y = sum_n C h + D u ;
+//   out_z = y * silu(z)
+// and the same walk as the reference -- every (batch, channel) row is scanned front to back with the state
+// carried in registers -- but cut for this chip: the chunk-parallel kernels of selective_scan.hip pay for their
+// parallelism over L with a second exp per element (chunk aggregates, K1) and the chunk-record traffic (K2);
+// when batch * dim alone fills the chip (>= 512 rows; the three large Mamba blocks of MM-UNet have 1,024) that
+// price buys nothing.  Here:
+//
+//   workgroup = 8 waves = 4 channels x 2 state-halves of ONE batch item; it walks the sequence in 512-token tiles.
+//   wave (c, hf) owns channel c and the state pairs 4hf .. 4hf+3 for the whole sequence: lane l holds tokens
+//   8l .. 8l+7 of the tile, the 8-token recurrence of a state pair runs in registers on packed math, lanes are
+//   joined by the DPP affine scan, and the state that leaves lane 63 enters lane 0 of the next tile through
+//   two SGPRs per pair (v_readlane).  No chunk aggregates, no carry kernel, one exp per (d, n, t).
+//   The B / C tile is staged in LDS once per tile for the 4 channels (pair-interleaved, conflict-free);
+//   what is per (channel, token) -- softplus, delta * u, the D u term, the z gate, the loads and stores --
+//   is split between the two waves of a channel by TOKEN (wave hf owns tokens 256hf .. 256hf+255 of the
+//   tile, 4 per lane, fully coalesced 1-KiB rows) and meets the per-state work through LDS:
+//       phase C(k-1): softplus of tile k -> sDL / sDU ; B / C of tile k -> sBC        | barrier 1
+//       phase B(k)  : 4 state pairs over the tile, partial y -> sY                    | barrier 2
+//       phase C(k)  : y = both halves + D u, gate, store ; prepare tile k+1 ; issue the loads of tile k+2
+//   Loads run a whole tile ahead of their use and the barriers order LDS only (no vmcnt drain).
+//
+// Chunk states: x[b, d, c, 2n+1] = h_n at the end of 128-token chunk c (what the backward kernels and
+// last_state read); x[b, d, c, 2n] = decay product from the start of the chunk's 512-token tile to the end
+// of the chunk (nothing reads it).
+#include <algorithm>
+#include <stdlib.h>
+#include "scan_common.h"
+#include "../../include/mmunet_amd.h"
+
+namespace {
+
+constexpr int ST_TT = 512;                   // tokens per tile
+constexpr int ST_CH = 4;                     // channels per workgroup
+constexpr int ST_QDL = 68;                   // float4 stride between the two token-quarters of sDL / sDU rows
+constexpr int ST_QY = 72;                    // the same for sY
+constexpr int ST_BC4 = 2 * 8 * 256;          // float4: [B|C][8 pairs][4][64]
+constexpr int ST_DL4 = ST_CH * 2 * 2 * ST_QDL;   // float4: [channel][DL|DU][2][68]
+constexpr int ST_Y4 = ST_CH * 2 * 2 * ST_QY;     // float4: [channel][half][2][72]
+constexpr size_t ST_LDS = sizeof(float4) * (ST_BC4 + ST_DL4 + ST_Y4);
+
+// One state pair over this lane's 8 tokens (see fwd_pair8 in selective_scan.hip): exps and the lane's local
+// composition, the cross-lane scan with the carry folded into lane 0, then the true recurrence and y.
+// hc: state of the pair entering the tile; leaves holding the state at the end of the tile.
+__device__ __forceinline__ void stream_pair(const v2f (&dl)[4], const v2f (&du)[4], float dlsum, v2f (&yp)[8],
+                                            const v2f a2, v2f &hc, const float *tileB, const float *tileC, int pr,
+                                            int lane, float4 &rec) {
+    v2f a[8], bb[8], Bv[8], Cv[8];
+    pair8_read(tileB, pr, lane, Bv);  // lands behind the 16 exps
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a[2 * q] = exp2_2(mul_bcast<0>(dl[q], a2));
+        a[2 * q + 1] = exp2_2(mul_bcast<1>(dl[q], a2));
+    }
+    const v2f P = exp2_2(a2 * dlsum);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bb[2 * q] = mul_bcast<0>(du[q], Bv[2 * q]);
+        bb[2 * q + 1] = mul_bcast<1>(du[q], Bv[2 * q + 1]);
+    }
+    v2f S = bb[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) S = fma2(a[i], S, bb[i]);
+    const v2f S_in = fma2(P, hc, S);
+    S = lane == 0 ? S_in : S;
+    float P0 = P.x, S0 = S.x, P1 = P.y, S1 = S.y;
+    __builtin_amdgcn_sched_barrier(0);
+    pair8_read(tileC, pr, lane, Cv);  // lands during the scan
+    wave_scan_affine_x2(P0, S0, P1, S1);
+    v2f h = v2f{wave_shift_up1(S0, hc.x), wave_shift_up1(S1, hc.y)};  // states entering this lane's tokens
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h = fma2(a[i], h, bb[i]);
+        yp[i] = fma2(Cv[i], h, yp[i]);
+    }
+    rec = make_float4(P0, S0, P1, S1);
+    hc = v2f{wave_bcast_last(S0), wave_bcast_last(S1)};
+    asm volatile("" : "+v"(hc));  // carried in VGPRs (see a2)
+}
+
+template <typename io_t, bool HAS_Z, bool SOFTPLUS, bool HAS_OUT>
+__global__ __launch_bounds__(512, 2) void scan_fwd_stream_kernel(ScanArgs p) {
+    constexpr unsigned ES = sizeof(io_t);
+    constexpr int N = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4 *sBC = reinterpret_cast<float4 *>(smem);
+    float4 *sDL = sBC + ST_BC4;
+    float4 *sY = sDL + ST_DL4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = w & 3, hf = w >> 2;
+    // batch fastest: the workgroups of one batch item land on one XCD (round-robin dispatch) and share its L2
+    // for the B / C tiles they all read.  Speed only.
+    const int b = blockIdx.x % p.batch, dg = blockIdx.x / p.batch;
+    const int d = dg * ST_CH + c;
+    const int g = (dg * ST_CH) / (p.dim / p.ngroups);
+    const int nt = p.seqlen / ST_TT;
+
+    const rsrc_t r_delta = make_rsrc((const io_t *)p.delta + (long)b * p.delta_bs + (long)d * p.delta_ds);
+    const rsrc_t r_u = make_rsrc((const io_t *)p.u + (long)b * p.u_bs + (long)d * p.u_ds);
+    const rsrc_t r_z = make_rsrc(HAS_Z ? (const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds : (const io_t *)p.u);
+    const rsrc_t r_oz = make_rsrc(HAS_Z ? (io_t *)p.out_z + (long)b * p.out_z_bs + (long)d * p.out_z_ds : (io_t *)p.out);
+    // No control flow inside the tile loop (a branch splits the block, the scheduling fences stop holding and
+    // the pair bodies smear into each other: 256 VGPRs + scratch): `out` is a template flag, and the lanes that
+    // own no chunk record carry an offset beyond the record resource, whose range check drops their store.
+    const rsrc_t r_out = make_rsrc(HAS_OUT ? (io_t *)p.out + (long)b * p.out_bs + (long)d * p.out_ds : (io_t *)p.u);
+    // this wave stages state pair w of the B tile and of the C tile (rows 2w, 2w+1)
+    const rsrc_t r_B = make_rsrc((const io_t *)p.B + (long)b * p.B_bs + (long)g * p.B_gs + (long)(2 * w) * p.B_ns);
+    const rsrc_t r_C = make_rsrc((const io_t *)p.C + (long)b * p.C_bs + (long)g * p.C_gs + (long)(2 * w) * p.C_ns);
+    const rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + ((long)b * p.dim + d) * p.n_chunks * 2 * N), 0,
+                                                         p.n_chunks * 2 * N * 4, 0x00020000);
+    const unsigned voff_io = (256 * hf + 4 * lane) * ES;  // this wave's 4 tokens per lane of a tile
+    const unsigned voff_bc = 8 * lane * ES;
+    const unsigned row1_B = (unsigned)p.B_ns * ES, row1_C = (unsigned)p.C_ns * ES;
+
+    // loop constants of this wave: A * log2e of its 8 states, bias, D
+    v2f a2[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const float *Ap = p.A + (long)d * p.A_ds + (long)(8 * hf + 2 * pr) * p.A_ns;
+        a2[pr] = v2f{Ap[0] * MMU_LOG2E, Ap[p.A_ns] * MMU_LOG2E};
+        asm volatile("" : "+v"(a2[pr]));  // loop constants live in VGPRs: the SGPR file is full of buffer resources
+    }
+    const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+    const float Dv = p.D ? p.D[d] : 0.f;
+
+    // where this lane's 4 I/O tokens live in the [2 quarters][64 lanes] float4 rows of sDL / sDU / sY:
+    // tokens 256hf + 4lane .. +3 of the tile = state-lane 32hf + lane/2, quarter lane&1
+    const int io_dl = (lane & 1) * ST_QDL + 32 * hf + (lane >> 1);
+    const int io_y = (lane & 1) * ST_QY + 32 * hf + (lane >> 1);
+    float4 *sDLc = sDL + c * 4 * ST_QDL, *sDUc = sDLc + 2 * ST_QDL;
+    float4 *sYc = sY + c * 4 * ST_QY;
+
+    float dl_n[4], u_n[4], z_n[4], u_cur[4], bB0[8], bB1[8], bC0[8], bC1[8];
+    auto fetch = [&](int kt) {  // delta, u and the B / C share of tile kt
+        const unsigned so = __builtin_amdgcn_readfirstlane(kt) * (unsigned)(ST_TT * ES);
+        buf_load4<io_t>(r_delta, voff_io, so, dl_n);
+        buf_load4<io_t>(r_u, voff_io, so, u_n);
+        buf_load8<io_t>(r_B, voff_bc, so, bB0);
+        buf_load8<io_t>(r_B, voff_bc, so + row1_B, bB1);
+        buf_load8<io_t>(r_C, voff_bc, so, bC0);
+        buf_load8<io_t>(r_C, voff_bc, so + row1_C, bC1);
+    };
+    auto fetch_z = [&](int kt) {
+        if constexpr (HAS_Z) {
+            const unsigned so = __builtin_amdgcn_readfirstlane(kt) * (unsigned)(ST_TT * ES);
+            buf_load4<io_t>(r_z, voff_io, so, z_n);
+        }
+    };
+    auto prepare = [&]() {  // what phase B of the next tile reads from LDS
+        float dl[4], du[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = dl_n[i] + bias;
+            if constexpr (SOFTPLUS) v = softplus_thr(v);
+            dl[i] = v;
+            du[i] = v * u_n[i];
+            u_cur[i] = u_n[i];
+        }
+        sDLc[io_dl] = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        sDUc[io_dl] = make_float4(du[0], du[1], du[2], du[3]);
+        float4 *dB = sBC + w * 256 + lane, *dC = sBC + (8 + w) * 256 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dB[q * 64] = make_float4(bB0[2 * q], bB1[2 * q], bB0[2 * q + 1], bB1[2 * q + 1]);
+            dC[q * 64] = make_float4(bC0[2 * q], bC1[2 * q], bC0[2 * q + 1], bC1[2 * q + 1]);
+        }
+    };
+
+    fetch(0);
+    fetch_z(0);
+    prepare();
+    fetch(nt > 1 ? 1 : 0);
+
+    v2f hc[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) hc[pr] = v2f{0.f, 0.f};
+    const float *tileB = reinterpret_cast<const float *>(sBC);
+    const float *tileC = reinterpret_cast<const float *>(sBC + 8 * 256);
+    // chunk records: lanes 15, 31, 47, 63 hold the states at the ends of the tile's four 128-token chunks
+    unsigned voff_x = (lane & 15) == 15 ? ((lane >> 4) * 2 * N + 16 * hf) * 4u : 0x80000000u;
+
+    for (int k = 0; k < nt; ++k) {
+        MMU_LDS_BARRIER();  // tile k's B / C, dl, dl*u are in LDS
+        // ---- phase B: this wave's 4 state pairs over the tile ----
+        v2f dl2[4], du2[4], yp[8];
+        float dlsum;
+        {
+            const float4 d0 = sDLc[lane], d1 = sDLc[ST_QDL + lane];
+            const float4 e0 = sDUc[lane], e1 = sDUc[ST_QDL + lane];
+            dl2[0] = v2f{d0.x, d0.y}; dl2[1] = v2f{d0.z, d0.w}; dl2[2] = v2f{d1.x, d1.y}; dl2[3] = v2f{d1.z, d1.w};
+            du2[0] = v2f{e0.x, e0.y}; du2[1] = v2f{e0.z, e0.w}; du2[2] = v2f{e1.x, e1.y}; du2[3] = v2f{e1.z, e1.w};
+            dlsum = ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yp[i] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            float4 rec;
+            stream_pair(dl2, du2, dlsum, yp, a2[pr], hc[pr], tileB, tileC, 4 * hf + pr, lane, rec);
+            __builtin_amdgcn_raw_buffer_store_b128(
+                v4u{__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z), __float_as_uint(rec.w)},
+                r_x, voff_x + 16u * pr, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // one pair at a time: interleaving two doubles the live registers
+        }
+        voff_x += 4 * 2 * N * 4;
+        sYc[hf * 2 * ST_QY + lane] = make_float4(yp[0].x + yp[0].y, yp[1].x + yp[1].y, yp[2].x + yp[2].y, yp[3].x + yp[3].y);
+        sYc[hf * 2 * ST_QY + ST_QY + lane] = make_float4(yp[4].x + yp[4].y, yp[5].x + yp[5].y, yp[6].x + yp[6].y, yp[7].x + yp[7].y);
+        MMU_LDS_BARRIER();  // both halves' partial y are in LDS; everyone is done with tile k's B / C, dl, dl*u
+        // ---- phase C: finish tile k on this wave's tokens, prepare tile k+1, fetch tile k+2 ----
+        {
+            const float4 ya = sYc[io_y], yb = sYc[2 * ST_QY + io_y];
+            float y[4] = {ya.x + yb.x, ya.y + yb.y, ya.z + yb.z, ya.w + yb.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = fmaf(Dv, u_cur[i], y[i]);
+            const unsigned so = __builtin_amdgcn_readfirstlane(k) * (unsigned)(ST_TT * ES);
+            if constexpr (HAS_OUT) buf_store4<io_t>(r_out, voff_io, so, y);
+            if constexpr (HAS_Z) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] *= z_n[i] * sigmoidf_(z_n[i]);
+                buf_store4<io_t>(r_oz, voff_io, so, y);
+            }
+        }
+        prepare();  // consumes the loads issued one iteration ago
+        fetch(k + 2 < nt ? k + 2 : nt - 1);  // (the last iterations re-read the last tile: L2 hits)
+        fetch_z(k + 1 < nt ? k + 1 : nt - 1);
+    }
+}
+
+inline bool al16(const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 0; }
+inline bool m4(long v) { return (v & 3) == 0; }
+
+}  // namespace
+
+int mmu_scan_fwd_stream(const ScanArgs &a, int dtype, hipStream_t st) {
+    // MMU_SCAN_STREAM=0 keeps every call on the chunk-parallel kernels (A/B runs, tests/test_hip_kernels.py)
+    if (const char *e = getenv("MMU_SCAN_STREAM"); e && e[0] == '0') return 0;
+    const int es = dtype == MMU_DTYPE_F32 ? 4 : 2;
+    const long bcm = dtype == MMU_DTYPE_F32 ? 3 : 7;  // B / C rows are read 8 tokens (16 or 32 B) per lane
+    if (a.dstate != 16 || a.seqlen % ST_TT != 0 || a.dim % a.ngroups != 0 || (a.dim / a.ngroups) % ST_CH != 0) return 0;
+    if ((long)a.batch * a.dim < 512) return 0;  // too few rows to fill the chip: the chunk-parallel kernels win
+    if ((a.z == nullptr) != (a.out_z == nullptr)) return 0;
+    const bool ok = al16(a.u) && al16(a.delta) && al16(a.z) && al16(a.out) && al16(a.out_z) && al16(a.B) && al16(a.C) &&
+                    m4(a.u_bs) && m4(a.u_ds) && m4(a.delta_bs) && m4(a.delta_ds) &&
+                    (!a.z || (m4(a.z_bs) && m4(a.z_ds) && m4(a.out_z_bs) && m4(a.out_z_ds))) &&
+                    (!a.out || (m4(a.out_bs) && m4(a.out_ds))) && !(a.B_bs & bcm) && !(a.B_gs & bcm) &&
+                    !(a.B_ns & bcm) && !(a.C_bs & bcm) && !(a.C_gs & bcm) && !(a.C_ns & bcm);
+    if (!ok) return 0;
+    // buffer addressing: 32-bit byte offsets inside one (batch, channel) row / one B or C row pair
+    if ((long)a.seqlen * es >= (1L << 31) || (std::max(a.B_ns, a.C_ns) + a.seqlen) * es >= (1L << 31) ||
+        (long)a.n_chunks * 2 * 16 * 4 >= (1L << 31))
+        return 0;
+    const unsigned grid = (unsigned)a.batch * (a.dim / ST_CH);
+    int r = 0;
+#define ST_LAUNCH(T)                                                                   \
+    MMU_BOOL(a.z != nullptr, HAS_Z, MMU_BOOL(a.softplus != 0, SOFTPLUS, MMU_BOOL(a.out != nullptr, HAS_OUT, { \
+        r = set_lds(scan_fwd_stream_kernel<T, HAS_Z, SOFTPLUS, HAS_OUT>, ST_LDS);                            \
+        if (!r) scan_fwd_stream_kernel<T, HAS_Z, SOFTPLUS, HAS_OUT><<<grid, 512, ST_LDS, st>>>(a);           \
+    });););
+    if (dtype == MMU_DTYPE_F32) {
+        ST_LAUNCH(float);
+    } else {
+        ST_LAUNCH(bf16_t);
+    }
+#undef ST_LAUNCH
+    if (r) return -1;
+    if (hipGetLastError() != hipSuccess) {
+        mmu_fail("scan_fwd_stream: launch failed");
+        return -1;
+    }
+    return 1;
+}

@@ -178,6 +178,80 @@ def test_scan_fwd_bwd_vs_oracle_mamba_layout(shape):
     close(r[8], o_outz, RTOL, ATOL, "out_z (recomputed)")
 
 
+@pytest.mark.parametrize("case", [
+    # (batch, dim, L, groups, dtype, layout, has_z, want_out)
+    (4, 128, 1024, 1, torch.float32, "dbl", True, True),
+    (8, 64, 2048, 1, torch.float32, "dbl", True, False),
+    (1, 512, 1536, 1, torch.float32, "bdl", True, True),
+    (2, 256, 512, 2, torch.float32, "bdl", False, True),
+    (4, 128, 1024, 1, torch.bfloat16, "dbl", True, True),
+])
+def test_scan_fwd_stream_vs_oracle_and_chunk_path(case):
+    """The streaming forward (selective_scan_stream.hip: taken when batch*dim >= 512, dstate 16, L % 512 == 0)
+    against the CPU oracle, and against the chunk-parallel kernels on the same inputs (MMU_SCAN_STREAM=0):
+    outputs, every chunk state the backward reads, and a backward pass fed with the streamed states."""
+    import oracle
+    from mm_unet_amd import selective_scan_hip as ss
+    b, d, l, g, dt, layout, has_z, want_out = case
+    n = 16
+    gen = torch.Generator().manual_seed(21)
+    c = _rand_case(b, d, l, n, seed=21)
+    c["B"] = torch.randn(b, g, n, l, generator=gen)
+    c["C"] = torch.randn(b, g, n, l, generator=gen)
+    if dt == torch.bfloat16:
+        c = {k: (v.bfloat16().float() if k in ("u", "delta", "z", "B", "C", "dout") else v) for k, v in c.items()}
+
+    def put(t):
+        t = t.to(dt)
+        if layout == "dbl":
+            return t.permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)
+        return t.to(DEV)
+
+    u, delta, z, dout = put(c["u"]), put(c["delta"]), put(c["z"]) if has_z else None, put(c["dout"])
+    A, D, bias = (c[k].to(DEV) for k in ("A", "D", "delta_bias"))
+    B, C = c["B"].to(dt).to(DEV), c["C"].to(dt).to(DEV)
+    assert os.environ.get("MMU_SCAN_STREAM", "1") != "0"
+    res = ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=want_out)
+    os.environ["MMU_SCAN_STREAM"] = "0"
+    try:
+        ref = ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=want_out)
+    finally:
+        del os.environ["MMU_SCAN_STREAM"]
+    torch.cuda.synchronize()
+    # oracle (per group: the C oracle takes one group at a time)
+    dpg = d // g
+    o_out = torch.empty(b, d, l)
+    o_outz = torch.empty(b, d, l)
+    o_last = torch.empty(b, d, n)
+    for gi in range(g):
+        sl = slice(gi * dpg, (gi + 1) * dpg)
+        oo, oz, ol = oracle.selective_scan_fwd(c["u"][:, sl], c["delta"][:, sl], c["A"][sl], c["B"][:, gi:gi + 1],
+                                               c["C"][:, gi:gi + 1], c["D"][sl], c["z"][:, sl] if has_z else None,
+                                               c["delta_bias"][sl], True)
+        o_out[:, sl], o_last[:, sl] = oo, ol
+        if has_z:
+            o_outz[:, sl] = oz
+    rt, at = (RTOL, ATOL) if dt == torch.float32 else (3e-2, 5e-2)
+    if want_out:
+        close(res[0], o_out, rt, at, "out vs oracle")
+        close(res[0], ref[0], rt, at, "out vs chunk path")
+    else:
+        assert res[0] is None
+    if has_z:
+        close(res[2], o_outz, rt, at, "out_z vs oracle")
+        close(res[2], ref[2], rt, at, "out_z vs chunk path")
+    close(res[1][:, :, -1, 1::2], o_last, RTOL, ATOL, "last_state vs oracle")
+    close(res[1][..., 1::2], ref[1][..., 1::2], RTOL, ATOL, "chunk states vs chunk path")
+    if g == 1 and has_z and dt == torch.float32:
+        r = ss.bwd(u, delta, A, B, C, D, z, bias, dout, res[1], None, None, True, False)
+        og = oracle.selective_scan_bwd(c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"],
+                                       c["dout"], True)
+        close(r[0], og["du"], RTOL * 2, ATOL * 2, "du (streamed states)")
+        close(r[1], og["ddelta"], RTOL * 5, ATOL * 10, "ddelta (streamed states)")
+        close(r[3], og["dB"], RTOL, ATOL * max(1, d // 32), "dB (streamed states)")
+        close(r[4], og["dC"], RTOL, ATOL * max(1, d // 32), "dC (streamed states)")
+
+
 def test_scan_bwd_reproducibility():
     """Every gradient of the dstate-16 backward (K4p / K4s: register dB/dC sums, no atomics anywhere) is
     bit-identical run to run; the reference uses global float atomics for dA/dB/dC/dD/dbias
