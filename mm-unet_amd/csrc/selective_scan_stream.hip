@@ -19,9 +19,9 @@
 //   is split between the two waves of a channel by TOKEN (wave hf owns tokens 256hf .. 256hf+255 of the
 //   tile, 4 per lane, fully coalesced 1-KiB rows) and meets the per-state work through LDS:
 //       phase C(k-1): softplus of tile k -> sDL / sDU ; B / C of tile k -> sBC        | barrier 1
-//       phase B(k)  : 4 state pairs over the tile, partial y -> sY                    | barrier 2
-//       phase C(k)  : y = both halves + D u, gate, store ; prepare tile k+1 ; issue the loads of tile k+2
-//   Loads run a whole tile ahead of their use and the barriers order LDS only (no vmcnt drain).
+//       phase B(k)  : (loads of tile k+1 issued) 4 state pairs over the tile, partial y -> sY  | barrier 2
+//       phase C(k)  : y = both halves + D u, gate, store ; prepare tile k+1 from the loads
+//   Loads run a phase B ahead of their use and the barriers order LDS only (no vmcnt drain).
 //
 // Chunk states: x[b, d, c, 2n+1] = h_n at the end of 128-token chunk c (what the backward kernels and
 // last_state read); x[b, d, c, 2n] = decay product from the start of the chunk's 512-token tile to the end
@@ -31,16 +31,28 @@
 #include "scan_common.h"
 #include "../../include/mmunet_amd.h"
 
+// Diagnostic build only (-DMMU_STREAM_STAMPS, tools/stream_stamps.sh): s_memtime at the phase boundaries of a few
+// tiles, read back through mmu_debug_stream_stamps.  In the product build no stamp executes.
+#ifdef MMU_STREAM_STAMPS
+__device__ unsigned long long g_stream_stamps[2 * 8 * 8 * 16];  // [block sel][wave][tile 16..23][slot]
+#define ST_STAMP(slot)                                                                                     \
+    do {                                                                                                   \
+        if ((blockIdx.x == 0 || blockIdx.x == 131) && k >= 16 && k < 24 && lane == 0)                      \
+            g_stream_stamps[(((blockIdx.x != 0) * 8 + w) * 8 + (k - 16)) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ST_STAMP(slot)
+#endif
+
 namespace {
 
 constexpr int ST_TT = 512;                   // tokens per tile
 constexpr int ST_CH = 4;                     // channels per workgroup
-constexpr int ST_QDL = 68;                   // float4 stride between the two token-quarters of sDL / sDU rows
-constexpr int ST_QY = 72;                    // the same for sY
-constexpr int ST_BC4 = 2 * 8 * 256;          // float4: [B|C][8 pairs][4][64]
-constexpr int ST_DL4 = ST_CH * 2 * 2 * ST_QDL;   // float4: [channel][DL|DU][2][68]
-constexpr int ST_Y4 = ST_CH * 2 * 2 * ST_QY;     // float4: [channel][half][2][72]
-constexpr size_t ST_LDS = sizeof(float4) * (ST_BC4 + ST_DL4 + ST_Y4);
+constexpr int ST_BC4 = 2 * 8 * 256;          // float4 per buffer: [B|C][8 pairs][4][64]
+constexpr int ST_DL4 = ST_CH * 2 * 2 * 64;   // float4: [channel][DL|DU][2][64]
+constexpr int ST_Y4 = ST_CH * 2 * 2 * 64;    // float4: [channel][half][2][64]
+constexpr size_t ST_LDS = sizeof(float4) * (2 * ST_BC4 + ST_DL4 + ST_Y4);  // 160 KiB: the whole LDS of a CU
+static_assert(ST_LDS == 160 * 1024, "the double-buffered B / C tile + exchange rows fill the LDS exactly");
 
 // One state pair over this lane's 8 tokens (see fwd_pair8 in selective_scan.hip): exps and the lane's local
 // composition, the cross-lane scan with the carry folded into lane 0, then the true recurrence and y.
@@ -87,9 +99,9 @@ __global__ __launch_bounds__(512, 2) void scan_fwd_stream_kernel(ScanArgs p) {
     constexpr unsigned ES = sizeof(io_t);
     constexpr int N = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float4 *sBC = reinterpret_cast<float4 *>(smem);
-    float4 *sDL = sBC + ST_BC4;
-    float4 *sY = sDL + ST_DL4;
+    float4 *sBC = reinterpret_cast<float4 *>(smem);  // [2 buffers][B|C][8 pairs][4][64]
+    float4 *sDL = sBC + 2 * ST_BC4;                   // [channel][DL|DU][2][64]
+    float4 *sY = sDL + ST_DL4;                        // [channel][half][2][64]
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = w & 3, hf = w >> 2;
     // batch fastest: the workgroups of one batch item land on one XCD (round-robin dispatch) and share its L2
@@ -129,28 +141,63 @@ __global__ __launch_bounds__(512, 2) void scan_fwd_stream_kernel(ScanArgs p) {
 
     // where this lane's 4 I/O tokens live in the [2 quarters][64 lanes] float4 rows of sDL / sDU / sY:
     // tokens 256hf + 4lane .. +3 of the tile = state-lane 32hf + lane/2, quarter lane&1
-    const int io_dl = (lane & 1) * ST_QDL + 32 * hf + (lane >> 1);
-    const int io_y = (lane & 1) * ST_QY + 32 * hf + (lane >> 1);
-    float4 *sDLc = sDL + c * 4 * ST_QDL, *sDUc = sDLc + 2 * ST_QDL;
-    float4 *sYc = sY + c * 4 * ST_QY;
+    const int io_q = (lane & 1) * 64 + 32 * hf + (lane >> 1);
+    float4 *sDLc = sDL + c * 256, *sDUc = sDLc + 128;
+    float4 *sYc = sY + c * 256;
 
-    float dl_n[4], u_n[4], z_n[4], u_cur[4], bB0[8], bB1[8], bC0[8], bC1[8];
-    auto fetch = [&](int kt) {  // delta, u and the B / C share of tile kt
-        const unsigned so = __builtin_amdgcn_readfirstlane(kt) * (unsigned)(ST_TT * ES);
-        buf_load4<io_t>(r_delta, voff_io, so, dl_n);
-        buf_load4<io_t>(r_u, voff_io, so, u_n);
-        buf_load8<io_t>(r_B, voff_bc, so, bB0);
-        buf_load8<io_t>(r_B, voff_bc, so + row1_B, bB1);
-        buf_load8<io_t>(r_C, voff_bc, so, bC0);
-        buf_load8<io_t>(r_C, voff_bc, so + row1_C, bC1);
-    };
-    auto fetch_z = [&](int kt) {
-        if constexpr (HAS_Z) {
-            const unsigned so = __builtin_amdgcn_readfirstlane(kt) * (unsigned)(ST_TT * ES);
-            buf_load4<io_t>(r_z, voff_io, so, z_n);
+    // staging registers of the B / C rows: the raw 16-byte tuples as loaded (NQ per row: 2 for float, 1 for bf16).
+    // They are carried over the loop's back-edge while the loads are in flight, so nothing may touch them in
+    // between: kept as whole tuples and pinned (empty asm) at the point of use, otherwise the compiler places
+    // the copies of the pair interleave right behind the loads -- one iteration early, a vmcnt(0) wait.
+    constexpr int NQ = ES == 4 ? 2 : 1;
+    float dl_n[4], u_n[4], z_n[4], u_cur[4];
+    v4u rB[2 * NQ], rC[2 * NQ];
+    auto tile_off = [&](int kt) { return (unsigned)__builtin_amdgcn_readfirstlane(kt) * (unsigned)(ST_TT * ES); };
+    auto fetch_rows = [&](rsrc_t r, unsigned row1, int kt, v4u (&q)[2 * NQ]) {
+        const unsigned so = tile_off(kt);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            q[j] = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bc + 16 * j, so, 0);
+            q[NQ + j] = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bc + 16 * j, so + row1, 0);
         }
     };
-    auto prepare = [&]() {  // what phase B of the next tile reads from LDS
+    auto fetch_B = [&](int kt) { fetch_rows(r_B, row1_B, kt, rB); };
+    auto fetch_C = [&](int kt) { fetch_rows(r_C, row1_C, kt, rC); };
+    auto fetch_io = [&](int kt) {
+        const unsigned so = tile_off(kt);
+        buf_load4<io_t>(r_delta, voff_io, so, dl_n);
+        buf_load4<io_t>(r_u, voff_io, so, u_n);
+    };
+    auto fetch_z = [&](int kt) {
+        if constexpr (HAS_Z) buf_load4<io_t>(r_z, voff_io, tile_off(kt), z_n);
+    };
+    // pair-interleaved image of this wave's two rows (see stage_pair8 in selective_scan.hip)
+    auto put_rows = [&](v4u (&q)[2 * NQ], float4 *dst) {
+#pragma unroll
+        for (int j = 0; j < 2 * NQ; ++j) asm volatile("" : "+v"(q[j]));
+        float r0[8], r1[8];
+        if constexpr (ES == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                r0[4 * j] = __uint_as_float(q[j].x); r0[4 * j + 1] = __uint_as_float(q[j].y);
+                r0[4 * j + 2] = __uint_as_float(q[j].z); r0[4 * j + 3] = __uint_as_float(q[j].w);
+                r1[4 * j] = __uint_as_float(q[2 + j].x); r1[4 * j + 1] = __uint_as_float(q[2 + j].y);
+                r1[4 * j + 2] = __uint_as_float(q[2 + j].z); r1[4 * j + 3] = __uint_as_float(q[2 + j].w);
+            }
+        } else {
+            const unsigned w0[4] = {q[0].x, q[0].y, q[0].z, q[0].w}, w1[4] = {q[1].x, q[1].y, q[1].z, q[1].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r0[2 * i] = __uint_as_float(w0[i] << 16); r0[2 * i + 1] = __uint_as_float(w0[i] & 0xffff0000u);
+                r1[2 * i] = __uint_as_float(w1[i] << 16); r1[2 * i + 1] = __uint_as_float(w1[i] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i * 64] = make_float4(r0[2 * i], r1[2 * i], r0[2 * i + 1], r1[2 * i + 1]);
+    };
+    auto put_B = [&](int buf) { put_rows(rB, sBC + buf * ST_BC4 + w * 256 + lane); };
+    auto put_C = [&](int buf) { put_rows(rC, sBC + buf * ST_BC4 + (8 + w) * 256 + lane); };
+    auto prepare = [&]() {  // softplus and delta * u of this wave's tokens of the next tile
         float dl[4], du[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -160,43 +207,65 @@ __global__ __launch_bounds__(512, 2) void scan_fwd_stream_kernel(ScanArgs p) {
             du[i] = v * u_n[i];
             u_cur[i] = u_n[i];
         }
-        sDLc[io_dl] = make_float4(dl[0], dl[1], dl[2], dl[3]);
-        sDUc[io_dl] = make_float4(du[0], du[1], du[2], du[3]);
-        float4 *dB = sBC + w * 256 + lane, *dC = sBC + (8 + w) * 256 + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dB[q * 64] = make_float4(bB0[2 * q], bB1[2 * q], bB0[2 * q + 1], bB1[2 * q + 1]);
-            dC[q * 64] = make_float4(bC0[2 * q], bC1[2 * q], bC0[2 * q + 1], bC1[2 * q + 1]);
-        }
+        sDLc[io_q] = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        sDUc[io_q] = make_float4(du[0], du[1], du[2], du[3]);
     };
 
-    fetch(0);
-    fetch_z(0);
+    // tile 0 -> LDS; the B / C rows of tile 1 -> staging registers
+    fetch_io(0);
+    fetch_B(0);
+    fetch_C(0);
     prepare();
-    fetch(nt > 1 ? 1 : 0);
+    put_B(0);
+    put_C(0);
+    fetch_B(nt > 1 ? 1 : 0);
+    fetch_C(nt > 1 ? 1 : 0);
 
     v2f hc[4];
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) hc[pr] = v2f{0.f, 0.f};
-    const float *tileB = reinterpret_cast<const float *>(sBC);
-    const float *tileC = reinterpret_cast<const float *>(sBC + 8 * 256);
     // chunk records: lanes 15, 31, 47, 63 hold the states at the ends of the tile's four 128-token chunks
     unsigned voff_x = (lane & 15) == 15 ? ((lane >> 4) * 2 * N + 16 * hf) * 4u : 0x80000000u;
 
     for (int k = 0; k < nt; ++k) {
-        MMU_LDS_BARRIER();  // tile k's B / C, dl, dl*u are in LDS
-        // ---- phase B: this wave's 4 state pairs over the tile ----
+        const int cur = k & 1;
+        const float *tileB = reinterpret_cast<const float *>(sBC + cur * ST_BC4);
+        const float *tileC = reinterpret_cast<const float *>(sBC + cur * ST_BC4 + 8 * 256);
+        // The per-token streams are loaded and consumed inside ONE iteration (phase B lies between): a load
+        // result carried over the back-edge AND copied (u_cur) gets its copy at the loop top, i.e. a vmcnt wait
+        // for loads that were just issued.
+        ST_STAMP(0);
+        fetch_io(k + 1 < nt ? k + 1 : k);  // (the last iteration re-reads its own tile: L2 hits)
+        fetch_z(k);
+        ST_STAMP(1);
+        MMU_LDS_BARRIER();  // tile k's B / C (written during phase B of tile k-1), dl, dl*u are in LDS
+        ST_STAMP(2);
+        // ---- phase B: this wave's 4 state pairs over the tile; between them, in the issue slots the VALU
+        // leaves free, the staging of the NEXT tiles: registers (tile k+1) -> the other LDS buffer, then the
+        // loads of tile k+2 into the same registers.  Done as a block before / after the pairs, all eight waves
+        // queue on the LDS store path (~13 cycles per ds_write_b128) and the texture path (16 per 1-KiB load)
+        // at the same time with the VALU idle: 3,400 of 10,900 cycles per tile (tools/stream_stamps.py).
         v2f dl2[4], du2[4], yp[8];
         float dlsum;
         {
-            const float4 d0 = sDLc[lane], d1 = sDLc[ST_QDL + lane];
-            const float4 e0 = sDUc[lane], e1 = sDUc[ST_QDL + lane];
+            const float4 d0 = sDLc[lane], d1 = sDLc[64 + lane];
+            const float4 e0 = sDUc[lane], e1 = sDUc[64 + lane];
             dl2[0] = v2f{d0.x, d0.y}; dl2[1] = v2f{d0.z, d0.w}; dl2[2] = v2f{d1.x, d1.y}; dl2[3] = v2f{d1.z, d1.w};
             du2[0] = v2f{e0.x, e0.y}; du2[1] = v2f{e0.z, e0.w}; du2[2] = v2f{e1.x, e1.y}; du2[3] = v2f{e1.z, e1.w};
             dlsum = ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) yp[i] = v2f{0.f, 0.f};
+#ifdef MMU_STREAM_STAMPS
+        asm volatile("" : "+v"(dlsum));
+#endif
+        ST_STAMP(3);
+        const int kn = k + 2 < nt ? k + 2 : nt - 1;
+        // The two waves of a SIMD (c, 0) and (c, 1) run the same program; VALU issue goes to the older one first,
+        // which then runs its four pairs at the single-wave rate while the younger gets the leftover slots and
+        // ends up finishing two pairs alone (stamps: 750 vs 1,500 cycles per pair, 5,000 instead of ~4,000 for
+        // the phase).  The younger half leads for the first two pairs instead.
+        if (hf) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
             float4 rec;
@@ -204,19 +273,34 @@ __global__ __launch_bounds__(512, 2) void scan_fwd_stream_kernel(ScanArgs p) {
             __builtin_amdgcn_raw_buffer_store_b128(
                 v4u{__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z), __float_as_uint(rec.w)},
                 r_x, voff_x + 16u * pr, 0, 0);
+            if (pr == 0) {
+                put_B(cur ^ 1);
+                fetch_B(kn);  // a whole tile ahead of its use: every CU asks for the same tiles at the same time
+            }
+            if (pr == 1) {
+                put_C(cur ^ 1);
+                fetch_C(kn);
+                if (hf) __builtin_amdgcn_s_setprio(0);
+            }
             __builtin_amdgcn_sched_barrier(0);  // one pair at a time: interleaving two doubles the live registers
+#ifdef MMU_STREAM_STAMPS
+            asm volatile("" : "+v"(yp[0]), "+v"(yp[7]));
+#endif
+            ST_STAMP(4 + pr);
         }
         voff_x += 4 * 2 * N * 4;
-        sYc[hf * 2 * ST_QY + lane] = make_float4(yp[0].x + yp[0].y, yp[1].x + yp[1].y, yp[2].x + yp[2].y, yp[3].x + yp[3].y);
-        sYc[hf * 2 * ST_QY + ST_QY + lane] = make_float4(yp[4].x + yp[4].y, yp[5].x + yp[5].y, yp[6].x + yp[6].y, yp[7].x + yp[7].y);
-        MMU_LDS_BARRIER();  // both halves' partial y are in LDS; everyone is done with tile k's B / C, dl, dl*u
-        // ---- phase C: finish tile k on this wave's tokens, prepare tile k+1, fetch tile k+2 ----
+        sYc[hf * 128 + lane] = make_float4(yp[0].x + yp[0].y, yp[1].x + yp[1].y, yp[2].x + yp[2].y, yp[3].x + yp[3].y);
+        sYc[hf * 128 + 64 + lane] = make_float4(yp[4].x + yp[4].y, yp[5].x + yp[5].y, yp[6].x + yp[6].y, yp[7].x + yp[7].y);
+        ST_STAMP(8);
+        MMU_LDS_BARRIER();  // both halves' partial y are in LDS; everyone is done with tile k's dl, dl*u
+        ST_STAMP(9);
+        // ---- phase C: finish tile k on this wave's tokens, prepare tile k+1 ----
         {
-            const float4 ya = sYc[io_y], yb = sYc[2 * ST_QY + io_y];
+            const float4 ya = sYc[io_q], yb = sYc[128 + io_q];
             float y[4] = {ya.x + yb.x, ya.y + yb.y, ya.z + yb.z, ya.w + yb.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] = fmaf(Dv, u_cur[i], y[i]);
-            const unsigned so = __builtin_amdgcn_readfirstlane(k) * (unsigned)(ST_TT * ES);
+            const unsigned so = tile_off(k);
             if constexpr (HAS_OUT) buf_store4<io_t>(r_out, voff_io, so, y);
             if constexpr (HAS_Z) {
 #pragma unroll
@@ -224,9 +308,9 @@ __global__ __launch_bounds__(512, 2) void scan_fwd_stream_kernel(ScanArgs p) {
                 buf_store4<io_t>(r_oz, voff_io, so, y);
             }
         }
-        prepare();  // consumes the loads issued one iteration ago
-        fetch(k + 2 < nt ? k + 2 : nt - 1);  // (the last iterations re-read the last tile: L2 hits)
-        fetch_z(k + 1 < nt ? k + 1 : nt - 1);
+        ST_STAMP(10);
+        prepare();  // tile k+1: consumes the loads issued at the top of this iteration
+        ST_STAMP(11);
     }
 }
 
@@ -234,6 +318,12 @@ inline bool al16(const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 
 inline bool m4(long v) { return (v & 3) == 0; }
 
 }  // namespace
+
+#ifdef MMU_STREAM_STAMPS
+extern "C" int mmu_debug_stream_stamps(unsigned long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stream_stamps), sizeof(g_stream_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int mmu_scan_fwd_stream(const ScanArgs &a, int dtype, hipStream_t st) {
     // MMU_SCAN_STREAM=0 keeps every call on the chunk-parallel kernels (A/B runs, tests/test_hip_kernels.py)
