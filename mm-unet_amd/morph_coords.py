@@ -34,11 +34,23 @@ def _dbl(t, rows, B, L):
     return v if v.is_contiguous() else v.contiguous()
 
 
+def _check_offset(offset, rows, w, what):
+    """The kernels read raw float32 pointers: everything is brought to contiguous float32 here and shapes are
+    checked before a pointer is taken (a bf16 buffer read as float32 is an out-of-bounds read: DESIGN.md 7.1)."""
+    _lib.require_gpu(offset, w)
+    if offset.dim() != 4 or offset.shape[1] % 2 != 0 or offset.shape[1] // 2 not in (1, 3):
+        raise RuntimeError(f"{what}: offset must be (B, 2K, H, W) with K in (1, 3)")
+    K = offset.shape[1] // 2
+    if tuple(w.shape) != rows(K):
+        raise RuntimeError(f"{what}: projection weight shape {tuple(w.shape)} != {rows(K)}")
+    return offset.float().contiguous(), w.float().contiguous()
+
+
 class ZigzagInProjFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, offset, w_in):
-        offset = offset.contiguous()
-        w = w_in.float().contiguous()
+        ctx.off_dtype = offset.dtype
+        offset, w = _check_offset(offset, lambda K: (4 * K, K), w_in, "zigzag_inproj")
         B, C2, H, W = offset.shape
         K = C2 // 2
         buf = torch.empty((4 * K, B, H * W), device=offset.device, dtype=torch.float32)
@@ -63,17 +75,21 @@ class ZigzagInProjFn(torch.autograd.Function):
             dw.data_ptr()
         with torch.cuda.device(offset.device):
             _lib.check(_lib.lib().mmu_zigzag_inproj_bwd(p, _lib.stream_of(offset)))
-        return doff, dw.to(ctx.w_dtype)
+        return doff.to(ctx.off_dtype), dw.to(ctx.w_dtype)
 
 
 class CoordsOutProjFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, offset, out_z, w_out, altho, scope):
-        offset = offset.contiguous()
-        w = w_out.float().contiguous()
+        ctx.off_dtype, ctx.oz_dtype = offset.dtype, out_z.dtype
+        offset, w = _check_offset(offset, lambda K: (K, 2 * K), w_out, "coords_outproj")
+        if altho.numel() != 1:
+            raise RuntimeError("coords_outproj: altho must hold one element")
         al = altho.float().reshape(1).contiguous()
         B, C2, H, W = offset.shape
         K = C2 // 2
+        if tuple(out_z.shape) != (B, 2 * K, H * W):
+            raise RuntimeError(f"coords_outproj: out_z shape {tuple(out_z.shape)} != {(B, 2 * K, H * W)}")
         oz = _dbl(out_z.float(), 2 * K, B, H * W)
         y = torch.empty((B, K, H, W), device=offset.device, dtype=torch.float32)
         p = _params(offset, K, scope)
@@ -100,7 +116,8 @@ class CoordsOutProjFn(torch.autograd.Function):
             da.data_ptr()
         with torch.cuda.device(offset.device):
             _lib.check(_lib.lib().mmu_coords_outproj_bwd(p, _lib.stream_of(offset)))
-        return doff, doz.permute(1, 0, 2), dw.to(ctx.w_dtype), da.reshape(ctx.a_shape).to(ctx.a_dtype), None
+        return (doff.to(ctx.off_dtype), doz.permute(1, 0, 2).to(ctx.oz_dtype), dw.to(ctx.w_dtype),
+                da.reshape(ctx.a_shape).to(ctx.a_dtype), None)
 
 
 def zigzag_inproj(offset, in_proj_weight):

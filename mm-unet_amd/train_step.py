@@ -4,7 +4,8 @@ step -> zero_grad.  The per-step host syncs of the reference (``float(loss)`` an
 the training batch, train.py:42-48,61) are not part of the step; the loss is returned as a device tensor.
 
 ``make_optimizer`` mirrors the reference's ``create_optimizer_v2('adamw', lr 1e-3, weight_decay .05,
-betas (.9,.95))`` (train.py:197-201): decoupled weight decay, none on 1-D parameters / biases.
+betas (.9,.95))`` (train.py:197-201): decoupled weight decay, none on 1-D parameters / biases, groups in
+timm's order.
 
 ``use_graph=True`` captures the step into a HIP graph (``torch.cuda.CUDAGraph``): a step is ~7,700
 kernel launches and the host needs as long to issue them (108 ms, measured) as the GPU needs to run
@@ -19,6 +20,22 @@ from .dp import GradAllReducer
 
 
 def make_optimizer(module, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.95), fused=None, capturable=False):
+    """AdamW as the reference builds it (train.py:197-201: timm ``create_optimizer_v2(model, opt='adamw', lr,
+    weight_decay=.05, betas=(.9,.95))``): decoupled weight decay, none on parameters with ``ndim <= 1`` or a name
+    ending in ``.bias``.
+
+    timm is not in the image, so the rule is restated from its published source (``optim_factory.py``:
+    ``param_groups_weight_decay`` in 0.9.7 = pyproject.toml's pin; ``add_weight_decay`` in 0.4.12 =
+    requirements.txt's pin, which tests ``len(shape) == 1`` and therefore decays MMConv's 0-dim ``altho``):
+    **parity unpinned**.  Both versions return the groups in the order ``[no_decay (wd 0), decay]``;
+    ``optimizer.state_dict()`` numbers parameters in group order, so a reference-trained ``optimizer.bin`` loads
+    (checkpoint.py) only if that order is kept -- it is.
+
+    ``capturable=True`` (the optimizer step is recorded into a HIP graph, ``TrainStep(use_graph=True)`` on one
+    rank): the learning rate is a device tensor.  A Python-float lr is passed to the fused kernel by value and
+    baked into the captured launch -- the reference steps a warm-up + cosine scheduler every epoch from
+    ``warmup_start_lr = 0`` (src/optimizer.py:26,56), i.e. a graph captured in epoch 0 would train at lr 0 for
+    ever.  Schedulers (and ``set_lr`` below) update the tensor in place, replays see it."""
     decay, no_decay = [], []
     for name, p in module.named_parameters():
         if not p.requires_grad:
@@ -26,9 +43,21 @@ def make_optimizer(module, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.95), fused=
         (no_decay if p.ndim <= 1 or name.endswith(".bias") else decay).append(p)
     if fused is None:
         fused = all(p.is_cuda for p in decay + no_decay)
-    return torch.optim.AdamW([{"params": decay, "weight_decay": weight_decay},
-                              {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=betas, fused=fused,
-                             capturable=capturable and fused)
+    capturable = capturable and fused
+    if capturable:
+        lr = torch.tensor(float(lr), dtype=torch.float32, device=(decay + no_decay)[0].device)
+    return torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0},
+                              {"params": decay, "weight_decay": weight_decay}], lr=lr, betas=betas, fused=fused,
+                             capturable=capturable)
+
+
+def set_lr(optimizer, lr):
+    """Sets the learning rate of every group; in place when it is a device tensor (captured optimizer step)."""
+    for g in optimizer.param_groups:
+        if isinstance(g["lr"], torch.Tensor):
+            g["lr"].fill_(float(lr))
+        else:
+            g["lr"] = float(lr)
 
 
 class TrainStep:

@@ -1,0 +1,119 @@
+"""One driver-run GPU test per single-GPU BASELINE.json config (configs[1], [2], [4]; config [3] is the 8-GPU
+data-parallel run, covered on CPU by tests/test_dp_gloo.py and on one device by tests/test_dp_gpu.py):
+
+  C2  MM-UNet inference bs=8 3x512x512 fp32          -> the graph-replayed bs-8 forward == eight bs-1 forwards
+  C3  MM-UNet fwd+bwd bf16 bs=16 3x512x512, Dice+BCE -> finite step, live-gradient set, loss / logits vs the fp32 run
+  C5  MM-UNet 3x1024x1024 bf16, d_state=64           -> d_state-64 model vs the CPU oracle (fp32, 256x256, <= 1e-3),
+                                                        and one finite bf16 training step at 1024x1024
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(d_state=16):
+    import mm_unet_amd.mmunet as pm
+    torch.manual_seed(50)
+    m = pm.MM_Net(num_classes=1, d_state=d_state)  # on CPU: the reference's RNG draw order
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    return m
+
+
+def test_config2_inference_bs8_512_matches_single_image_forwards():
+    """BASELINE config 2.  In eval mode every op of MM_Net is per-sample (BatchNorm running statistics, GroupNorm,
+    fixed coordinate ranges MMUNet.py:229-241), so the bs-8 forward must reproduce the eight bs-1 forwards.  The two
+    take different kernels (bs 8: streaming scan, batch*dim = 1,024 rows; bs 1: chunk-parallel scan; different
+    GEMM tilings), so this also cross-checks those paths at BASELINE's size.  Bound: the north star's 1e-3."""
+    from mm_unet_amd.train_step import InferStep
+    m = _model().to(DEV).eval()
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 3, 512, 512, generator=gen).to(DEV)
+    step = InferStep(m)
+    step(x)                        # eager warm-up
+    out = step(x).clone()          # captured + replayed
+    assert step._graph is not None and out.shape == (8, 1, 512, 512)
+    out2 = step(x.flip(0)).clone()  # a replay with other data in the static buffer
+    worst = 0.0
+    with torch.no_grad():
+        for i in range(8):
+            ref = m(x[i:i + 1])
+            worst = max(worst, float((out[i:i + 1] - ref).abs().max()), float((out2[7 - i:8 - i] - ref).abs().max()))
+    assert torch.isfinite(out).all()
+    assert worst <= 1e-3, f"bs-8 graph forward differs from the bs-1 forwards by {worst:.3e}"
+
+
+def test_config3_bf16_autocast_train_step_bs16_512():
+    """BASELINE config 3: one bf16-autocast training step (fwd + Dice+BCE + bwd + AdamW) at bs 16, 3x512x512:
+    finite loss and gradients, exactly the live parameter set receives gradients and moves, and the autocast
+    forward agrees with the fp32 forward of the same weights in loss (5 %) and in logit correlation."""
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    from mm_unet_amd.train_step import TrainStep, make_optimizer
+    m = _model().to(DEV).train()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(16, 3, 512, 512, generator=gen).to(DEV)
+    t = (torch.rand(16, 1, 512, 512, generator=gen) > 0.88).float().to(DEV)
+    # bf16 vs fp32 on the same weights.  Element-wise agreement of the logits is not a meaningful bound here: the
+    # reference's OWN train-mode logits move by 6e-3 under a 1e-6 input perturbation (fixture mmnet_64,
+    # ``train_logits_sens``: bilinear sampling at learned coordinates + batch statistics), an amplification of
+    # ~6,000, and bf16 rounds at 4e-3.  What must hold: finite, same loss level, correlated logits.
+    loss_fn = DICE_BCE_Loss()
+    with torch.no_grad():
+        state = {k: v.clone() for k, v in m.state_dict().items()}
+        ref = m(x[:4])                                   # fp32, train-mode statistics of the first 4 images
+        m.load_state_dict(state)                         # undo the running-statistics update
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lb = m(x[:4])
+        m.load_state_dict(state)
+        l32, l16 = float(loss_fn(ref, t[:4])), float(loss_fn(lb.float(), t[:4]))
+    assert torch.isfinite(lb).all()
+    a, b_ = ref.flatten() - ref.mean(), lb.float().flatten() - lb.float().mean()
+    corr = float((a * b_).sum() / (a.norm() * b_.norm()))
+    rel = float((lb.float() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"C3: fp32 loss {l32:.4f}, bf16-autocast loss {l16:.4f}, logits correlation {corr:.3f}, relative RMS {rel:.2f}")
+    assert abs(l16 - l32) < 0.05 * l32, (l32, l16)
+    assert corr > 0.5, f"bf16-autocast logits are uncorrelated with the fp32 logits ({corr:.3f})"
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    step = TrainStep(m, DICE_BCE_Loss(), make_optimizer(m), amp_dtype=torch.bfloat16)
+    loss = step.forward_backward(x, t)
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert torch.isfinite(loss) and 0.5 < float(loss) < 3.0, float(loss)
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    assert sum(g.numel() for g in grads.values()) == 9562699  # the live set of BASELINE.md (38.25 MB fp32)
+    step.optimizer.step()
+    moved = sum(int((p.detach() != before[k]).any()) for k, p in m.named_parameters() if k in grads)
+    assert moved == len(grads)
+
+
+def test_config5_dstate64_vs_oracle_and_1024_bf16_step():
+    """BASELINE config 5 (deep encoder, d_state = 64; the reference hard-codes 16 at MMUNet.py:29,355 -- the build
+    exposes it): (a) MM_Net(d_state=64) eval logits on 1x3x256x256 against oracle/model_ref.py on identical
+    weights, north-star bound 1e-3 (generic-dstate scan kernels, N = 64 states); (b) one bf16-autocast training
+    step on a 3x1024x1024 tile: finite loss and gradients."""
+    from oracle import model_ref
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    m = _model(d_state=64)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert sd["rcg4.mamba.A_log"].shape[-1] == 64 and sd["encoder2.0.block1.0.mamba.A_log"].shape[-1] == 64
+    m = m.to(DEV).eval()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, 256, 256, generator=gen)
+    with torch.no_grad():
+        logits = m(x.to(DEV)).cpu()
+        ref = model_ref.mm_net(sd, x, training=False)
+    err = float((logits - ref).abs().max())
+    assert err <= 1e-3, f"d_state=64 forward differs from the oracle by {err:.3e}"
+    m.train()
+    xb = torch.randn(1, 3, 1024, 1024, generator=gen).to(DEV)
+    tb = (torch.rand(1, 1, 1024, 1024, generator=gen) > 0.88).float().to(DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(xb)
+    loss = DICE_BCE_Loss()(out.float(), tb)
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert np.isfinite(float(loss))

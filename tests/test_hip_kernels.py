@@ -348,6 +348,105 @@ def test_scan_rejects_bad_arguments():
                torch.zeros(1, 1, 200, 64, device=DEV), None, None, None, False)
 
 
+# --------------------------------------------------------------------------- autograd wrappers (SSI:14-83, CCI:10-46)
+@pytest.mark.parametrize("name", SCAN)
+def test_selective_scan_fn_autograd_golden(name):
+    """Backpropagates through the public ``selective_scan_fn`` (SelectiveScanFn.backward), with and without
+    ``return_last_state``, against the reference's selective_scan_ref fixtures."""
+    from mm_unet_amd.selective_scan_interface import selective_scan_fn
+    g = golden(name)
+    leaves = {k: _g(g, k) for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias")}
+    for v in leaves.values():
+        if v is not None:
+            v.requires_grad_()
+    sp = bool(g["softplus"])
+    out, last = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"],
+                                  leaves["z"], leaves["delta_bias"], sp, return_last_state=True)
+    close(out, g["out"], RTOL, ATOL, "out")
+    close(last, g["last_state"], RTOL, ATOL, "last_state")
+    assert not last.requires_grad or last.grad_fn is not None
+    out.backward(_g(g, "dout"))
+    close(leaves["u"].grad, g["du"], RTOL * 2, ATOL * 2, "du")
+    close(leaves["delta"].grad, g["ddelta"], RTOL * 5, ATOL * 10, "ddelta")
+    close(leaves["A"].grad, g["dA"], RTOLW, ATOLW * 5, "dA")
+    close(leaves["B"].grad, g["dB"], RTOL, ATOL, "dB")
+    close(leaves["C"].grad, g["dC"], RTOL, ATOL, "dC")
+    for k, gk in (("D", "dD"), ("delta_bias", "ddelta_bias"), ("z", "dz")):
+        if gk in g:
+            close(leaves[k].grad, g[gk], RTOLW, ATOLW, gk)
+    # plain call (no last state) gives the same output object semantics
+    out2 = selective_scan_fn(*(v.detach() if v is not None else None for v in
+                               (leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"],
+                                leaves["z"], leaves["delta_bias"])), sp)
+    assert torch.equal(out2, out.detach())
+
+
+@pytest.mark.parametrize("name", CONV)
+def test_causal_conv1d_fn_autograd_golden(name):
+    """Backpropagates through the public ``causal_conv1d_fn`` against the reference's causal_conv1d_ref fixtures."""
+    from mm_unet_amd.causal_conv1d_interface import causal_conv1d_fn
+    g = golden(name)
+    x, w, b = _g(g, "x").requires_grad_(), _g(g, "weight").requires_grad_(), _g(g, "bias")
+    if b is not None:
+        b.requires_grad_()
+    out = causal_conv1d_fn(x, w, b, "silu" if bool(g["silu"]) else None)
+    close(out, g["out"], 3e-4, 1e-3, "out")
+    out.backward(_g(g, "dout"))
+    close(x.grad, g["dx"], 3e-4, 1e-3, "dx")
+    close(w.grad, g["dweight"], 1e-3, 1e-3, "dweight")
+    if "dbias" in g:
+        close(b.grad, g["dbias"], 1e-3, 1e-3, "dbias")
+
+
+def test_bimamba_inner_fn_vs_oracle_composition():
+    """``bimamba_inner_fn`` (exported by the reference, SSI:616-624; not called by MM-UNet) forward + every
+    gradient against bimamba_inner_ref's steps (SSI:673-709) composed from the CPU oracle's differentiable
+    conv1d / scan and torch CPU linear algebra."""
+    import oracle
+    import torch.nn.functional as F
+    from mm_unet_amd.selective_scan_interface import BiMambaInnerFn, bimamba_inner_fn
+    gen = torch.Generator().manual_seed(33)
+    b, d, l, n, r, e = 2, 8, 192, 16, 2, 4
+
+    def rnd(*s, scale=1.0):
+        return (scale * torch.randn(*s, generator=gen))
+
+    P = dict(xz=rnd(b, 2 * d, l), conv_w=rnd(d, 1, 4, scale=0.5), conv_b=rnd(d, scale=0.1),
+             x_proj=rnd(r + 2 * n, d, scale=0.3), dt_proj=rnd(d, r, scale=0.5), out_proj=rnd(e, d, scale=0.3),
+             out_bias=rnd(e, scale=0.1), A=-torch.rand(d, n, generator=gen) - 0.1,
+             A_b=-torch.rand(d, n, generator=gen) - 0.1, D=rnd(d), dt_bias=0.5 * torch.rand(d, generator=gen))
+    dout = rnd(b, l, e)
+
+    def ref(p):
+        x, z = p["xz"].chunk(2, dim=1)
+        x = oracle.causal_conv1d(x.contiguous(), p["conv_w"].view(d, 4), p["conv_b"], "silu")
+        x_dbl = F.linear(x.permute(0, 2, 1).reshape(b * l, d), p["x_proj"])
+        delta = (p["dt_proj"] @ x_dbl[:, :r].t()).view(d, b, l).permute(1, 0, 2).contiguous()
+        B = x_dbl[:, r:r + n].view(b, l, n).permute(0, 2, 1).contiguous()
+        C = x_dbl[:, -n:].view(b, l, n).permute(0, 2, 1).contiguous()
+        z = z.contiguous()
+        y = oracle.selective_scan(x, delta, p["A"], B, C, p["D"], z, p["dt_bias"], True)
+        y_b = oracle.selective_scan(x.flip([-1]).contiguous(), delta.flip([-1]).contiguous(), p["A_b"],
+                                    B.flip([-1]).contiguous(), C.flip([-1]).contiguous(), p["D"],
+                                    z.flip([-1]).contiguous(), p["dt_bias"], True)
+        y = y + y_b.flip([-1])
+        return F.linear(y.permute(0, 2, 1), p["out_proj"], p["out_bias"])
+
+    pc = {k: v.clone().requires_grad_() for k, v in P.items()}
+    o_ref = ref(pc)
+    o_ref.backward(dout)
+    pg = {k: v.clone().to(DEV).requires_grad_() for k, v in P.items()}
+    args = (pg["xz"], pg["conv_w"], pg["conv_b"], pg["x_proj"], pg["dt_proj"], pg["out_proj"], pg["out_bias"],
+            pg["A"], pg["A_b"], None, None, pg["D"], pg["dt_bias"], None, None, True)
+    out = bimamba_inner_fn(*args)
+    close(out, o_ref, RTOL, ATOL, "out")
+    assert torch.equal(BiMambaInnerFn.apply(*args), out)
+    out.backward(dout.to(DEV))
+    for k in P:
+        scale = float(pc[k].grad.abs().max())
+        close(pg[k].grad, pc[k].grad, 2e-3, 2e-3 * max(scale, 1.0), f"d{k}")
+
+
 # --------------------------------------------------------------------------- causal conv1d
 @pytest.mark.parametrize("name", CONV)
 def test_conv1d_golden(name):

@@ -59,6 +59,40 @@ def test_mmconv_oracle_vs_reference(name):
             close(sd[kk[5:]].grad, g[kk], 2e-3, 2e-3, kk)
 
 
+BLOCK_FNS = {
+    "block_residual_32": lambda p, ins, cx: M.residual_block(p, ins[0], 32, 32, False, cx, 4),
+    "block_residual_down_32to64": lambda p, ins, cx: M.residual_block(p, ins[0], 32, 64, True, cx, 4),
+    "block_decoder_64to32": lambda p, ins, cx: M.decoder_block(p, ins[0], 64, 32, cx, 4),
+    "block_sideout_64": lambda p, ins, cx: M.sideout(p, ins[0], cx, 4),
+    "block_cbam_64": lambda p, ins, cx: M.cbam(p, ins[0]),
+    "block_rcg_ns4": lambda p, ins, cx: M.rcg(p, ins[0], ins[1], ins[2], cx, 4),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BLOCK_FNS))
+def test_block_oracle_vs_reference(name):
+    """ResidualBlock / DecoderBlock / SideoutBlock / CBAM / RCG of the oracle against the reference's own modules
+    (train mode, every parameter gradient; tolerances as in tests/test_modules_gpu.py::test_block_vs_reference)."""
+    g = golden(name)
+    sd = _sd(g)
+    ins = []
+    while f"in{len(ins)}" in g:
+        ins.append(torch.from_numpy(g[f"in{len(ins)}"]).requires_grad_())
+    out = BLOCK_FNS[name](M.P(sd), ins, M.Ctx(True))
+    close(out, g["out"], 1e-4, max(2e-4, 4 * float(g["sens_out"])), "out")
+    out.backward(torch.from_numpy(g["dout"]))
+
+    def check(t, ref, sens, what):
+        scale = float(np.abs(ref).max())
+        close(t, ref, 2e-3, max(2e-3 * scale, 4 * float(sens), 2e-6), what)
+
+    for j, x in enumerate(ins):
+        check(x.grad, g[f"din{j}"], g[f"sens.din{j}"], f"din{j}")
+    for kk in g:
+        if kk.startswith("grad."):
+            check(sd[kk[5:]].grad, g[kk], g["sens." + kk[5:]], kk)
+
+
 def _seeded_state(cls_name):
     """Weights by RNG draw order: seed 50 then construct (identity with the reference proven by the
     checksum test in test_host_logic.py)."""

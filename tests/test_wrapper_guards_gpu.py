@@ -1,0 +1,176 @@
+"""Negative tests for every Python wrapper that hands raw device pointers to a float32 HIP kernel.
+
+Round 1 lost a test process to ``Fatal Python error: Aborted``: the first version of the fused
+residual tail passed the bf16 shortcut tensor of an autocast run to a kernel that reads float32 -- twice the
+buffer, an out-of-bounds read, a GPU memory fault reported at the next ATen call.  The rule since: a wrapper takes
+``data_ptr()`` only of tensors it has itself brought to (or checked to be) contiguous float32 of the expected shape.
+Here every wrapper is fed a bf16 tensor, a non-contiguous view and a wrong shape; it must either raise
+``RuntimeError`` or return what the float32 / contiguous call returns -- never launch on the foreign buffer."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).to(DEV)
+
+
+def _same_or_raises(fn, ref, tol=0.0):
+    """fn() raises RuntimeError, or returns ref (within tol, after conversion to float32)."""
+    try:
+        out = fn()
+    except RuntimeError:
+        return "raised"
+    torch.cuda.synchronize()
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    refs = ref if isinstance(ref, (tuple, list)) else (ref,)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape
+        assert float((o.float() - r.float()).abs().max()) <= tol * max(1.0, float(r.abs().max())), "wrong result"
+    return "converted"
+
+
+def test_norm_fused_guards():
+    from mm_unet_amd import norm_fused
+    gn, bn = torch.nn.GroupNorm(2, 8).to(DEV), torch.nn.BatchNorm2d(8).to(DEV).eval()
+    x = _rnd(2, 8, 6, 10)
+    ref = norm_fused.gn_bn_act(x, gn, bn, "relu")
+    assert _same_or_raises(lambda: norm_fused.gn_bn_act(x.bfloat16(), gn, bn, "relu"), ref, 2e-2) in ("raised", "converted")
+    assert not norm_fused.supported(x.bfloat16(), gn, bn)          # what mmunet.run_fused consults first
+    xc = x.to(memory_format=torch.channels_last)
+    assert _same_or_raises(lambda: norm_fused.gn_bn_act(xc, gn, bn, "relu"), ref, 1e-6) == "converted"
+    with pytest.raises(RuntimeError):                               # 6 channels into 8-channel norms
+        norm_fused.gn_bn_act(x[:, :6].contiguous(), gn, bn, "relu")
+    # the residual tail: bf16 shortcut (what autocast produces) and a wrong-shaped one
+    res = _rnd(2, 8, 6, 10, seed=1)
+    ref_r = norm_fused.gn_bn_act(x, gn, bn, "relu", residual=res)
+    assert _same_or_raises(lambda: norm_fused.gn_bn_act(x, gn, bn, "relu", residual=res.bfloat16()), ref_r, 2e-2) == "converted"
+    with pytest.raises(RuntimeError):
+        norm_fused.gn_bn_act(x, gn, bn, "relu", residual=res[:, :, :3])
+    ref_b = norm_fused.bn_act(x, bn, "relu")
+    assert _same_or_raises(lambda: norm_fused.bn_act(x.bfloat16(), bn, "relu"), ref_b, 2e-2) in ("raised", "converted")
+    # the incoming gradient may be bf16 / non-contiguous: backward normalises it
+    xg = x.clone().requires_grad_()
+    out = norm_fused.gn_bn_act(xg, gn, bn, "relu")
+    out.backward(torch.ones_like(out).to(memory_format=torch.channels_last))
+    g1 = xg.grad.clone()
+    xg.grad = None
+    norm_fused.gn_bn_act(xg, gn, bn, "relu").backward(torch.ones_like(out))
+    assert torch.allclose(g1, xg.grad, atol=1e-6)
+
+
+def test_conv3x3_small_guards():
+    from mm_unet_amd.conv3x3_small import conv3x3_small
+    x, w, b = _rnd(2, 16, 9, 12), _rnd(6, 16, 3, 3, seed=1), _rnd(6, seed=2)
+    ref = F.conv2d(x, w, b, padding=1)
+    assert _same_or_raises(lambda: conv3x3_small(x, w, b), ref, 1e-5) == "converted"
+    assert _same_or_raises(lambda: conv3x3_small(x.bfloat16(), w, b), ref, 3e-2) in ("raised", "converted")
+    assert _same_or_raises(lambda: conv3x3_small(x.to(memory_format=torch.channels_last), w, b), ref, 1e-5) == "converted"
+    assert _same_or_raises(lambda: conv3x3_small(x, w.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2), b), ref, 1e-5) == "converted"
+    with pytest.raises(RuntimeError):
+        conv3x3_small(x, _rnd(6, 8, 3, 3), b)                       # Cin mismatch
+    with pytest.raises(RuntimeError):
+        conv3x3_small(x, w, _rnd(5))                                # bias length
+
+
+def test_morph_sample_and_coords_guards():
+    from mm_unet_amd import morph_coords
+    from mm_unet_amd.morph_sample import morph_sample
+    x, y = _rnd(2, 5, 8, 12), 3.5 + _rnd(2, 3, 8, 12, seed=1)
+    ref = morph_sample(x, y)
+    assert _same_or_raises(lambda: morph_sample(x.bfloat16(), y), ref, 3e-2) == "converted"
+    assert _same_or_raises(lambda: morph_sample(x.to(memory_format=torch.channels_last), y), ref, 1e-6) == "converted"
+    with pytest.raises(RuntimeError):
+        morph_sample(x, y[:, :, :4])
+    with pytest.raises(RuntimeError):
+        morph_sample(x, y[:, :2])                                   # even number of taps
+    off, w_in = _rnd(2, 6, 8, 12, seed=2), _rnd(12, 3, seed=3)
+    ref = morph_coords.zigzag_inproj(off, w_in)
+    assert _same_or_raises(lambda: morph_coords.zigzag_inproj(off.bfloat16(), w_in), ref, 3e-2) == "converted"
+    assert _same_or_raises(lambda: morph_coords.zigzag_inproj(off.to(memory_format=torch.channels_last), w_in), ref, 1e-6) == "converted"
+    with pytest.raises(RuntimeError):
+        morph_coords.zigzag_inproj(off, _rnd(12, 4))                # wrong projection shape
+    with pytest.raises(RuntimeError):
+        morph_coords.zigzag_inproj(off[:, :4], w_in)                # K = 2
+    oz, w_out, al = _rnd(2, 6, 96, seed=4), _rnd(3, 6, seed=5), torch.tensor(0.54, device=DEV)
+    ref = morph_coords.coords_outproj(off, oz, w_out, al)
+    assert _same_or_raises(lambda: morph_coords.coords_outproj(off.bfloat16(), oz.bfloat16(), w_out, al), ref, 5e-2) == "converted"
+    with pytest.raises(RuntimeError):
+        morph_coords.coords_outproj(off, oz[:, :, :50], w_out, al)  # token count != H*W
+
+
+def test_resize_and_tri_order_guards():
+    from mm_unet_amd.resize import bilinear_resize
+    from mm_unet_amd.tri_order import tri_combine, tri_split
+    x = _rnd(2, 3, 7, 9)
+    ref = F.interpolate(x, size=(14, 18), mode="bilinear", align_corners=True)
+    assert _same_or_raises(lambda: bilinear_resize(x, size=(14, 18)), ref, 1e-5) == "converted"
+    assert _same_or_raises(lambda: bilinear_resize(x.bfloat16(), size=(14, 18)), ref, 3e-2) == "converted"
+    assert _same_or_raises(lambda: bilinear_resize(x.to(memory_format=torch.channels_last), size=(14, 18)), ref, 1e-5) == "converted"
+    with pytest.raises(RuntimeError):
+        bilinear_resize(x[0], size=(14, 18))
+    t = _rnd(2, 4, 64)
+    a, f, s = tri_split(t, 4)
+    assert torch.equal(f, t.flip(-1))
+    assert _same_or_raises(lambda: tri_split(t.bfloat16(), 4), (a, f, s), 3e-2) in ("raised", "converted")
+    assert _same_or_raises(lambda: tri_split(t.transpose(1, 2).contiguous().transpose(1, 2), 4), (a, f, s), 0.0) in ("raised", "converted")
+    with pytest.raises(RuntimeError):
+        tri_split(t, 5)                                             # L not divisible by nslices
+    ref = tri_combine(a, f, s, 4)
+    assert _same_or_raises(lambda: tri_combine(a, f.bfloat16(), s, 4), ref, 3e-2) in ("raised", "converted")
+
+
+def test_mfma_wrappers_guards():
+    from mm_unet_amd import mfma_gemm
+    from mm_unet_amd.conv3x3_mfma import Conv3x3MfmaFn, supported
+    x, w = _rnd(1, 16, 8, 16), _rnd(64, 16, 3, 3, seed=1)
+    ref = F.conv2d(x, w, None, padding=1)
+    assert _same_or_raises(lambda: Conv3x3MfmaFn.apply(x, w, None), ref, 1e-4) == "converted"
+    assert not supported(x.bfloat16(), w)
+    assert _same_or_raises(lambda: Conv3x3MfmaFn.apply(x.bfloat16(), w, None), ref, 3e-2) in ("raised", "converted")
+    assert _same_or_raises(lambda: Conv3x3MfmaFn.apply(x.to(memory_format=torch.channels_last), w, None), ref, 1e-4) in ("raised", "converted")
+    with pytest.raises(RuntimeError):
+        Conv3x3MfmaFn.apply(x, _rnd(64, 32, 3, 3), None)
+    rows, inner, tokens = 64, 32, 1024
+    wt, xm, out = _rnd(rows, inner), _rnd(inner, tokens, seed=2), torch.empty(rows, tokens, device=DEV)
+    mfma_gemm.gemm_tokens(wt, xm, out, rows, inner, tokens, 1, tokens, 0, tokens, 0)
+    torch.cuda.synchronize()
+    assert float((out - wt @ xm).abs().max()) < 1e-3
+    with pytest.raises(RuntimeError):
+        mfma_gemm.gemm_tokens(wt.bfloat16(), xm, out, rows, inner, tokens, 1, tokens, 0, tokens, 0)
+    with pytest.raises(RuntimeError):
+        mfma_gemm.gemm_tokens(wt, xm.bfloat16(), out, rows, inner, tokens, 1, tokens, 0, tokens, 0)
+    with pytest.raises(RuntimeError):
+        mfma_gemm.gemm_tokens(wt[:, :16], xm, out, rows, inner, tokens, 1, tokens, 0, tokens, 0)
+    assert not mfma_gemm.supported(rows, inner, tokens, wt.bfloat16(), xm, out)
+
+
+def test_conv1d_and_scan_extension_guards():
+    from mm_unet_amd import causal_conv1d_hip as cc, selective_scan_hip as ss
+    x, w, b = _rnd(2, 8, 64), _rnd(8, 4, seed=1), _rnd(8, seed=2)
+    ref = cc.causal_conv1d_fwd(x, w, b, True)
+    with pytest.raises(RuntimeError):
+        cc.causal_conv1d_fwd(x.half(), w.half(), b.half(), True)    # no float16 I/O
+    with pytest.raises(RuntimeError):
+        cc.causal_conv1d_fwd(x, w[:6], b, True)                     # weight rows != channels
+    with pytest.raises(RuntimeError):
+        cc.causal_conv1d_fwd(x, _rnd(8, 5), b, True)                # width 5
+    with pytest.raises(RuntimeError):
+        cc.causal_conv1d_bwd(x, w, b, _rnd(2, 8, 32), None, True)   # dout length
+    assert _same_or_raises(lambda: cc.causal_conv1d_fwd(x.transpose(0, 1).contiguous().transpose(0, 1), w, b, True), ref, 1e-6) == "converted"
+    u, delta = _rnd(1, 4, 64), 0.5 * torch.rand(1, 4, 64, device=DEV)
+    A, B, C = -torch.rand(4, 16, device=DEV), _rnd(1, 1, 16, 64, seed=3), _rnd(1, 1, 16, 64, seed=4)
+    with pytest.raises(RuntimeError):
+        ss.fwd(u, delta.bfloat16(), A, B, C, None, None, None, False)   # mixed I/O dtypes
+    with pytest.raises(RuntimeError):
+        ss.fwd(u, delta, A.bfloat16(), B, C, None, None, None, False)   # A must be float32
+    with pytest.raises(RuntimeError):
+        ss.fwd(u, delta, A, B[..., :32], C, None, None, None, False)    # B length
+    with pytest.raises(RuntimeError):
+        ss.fwd(u, delta, A, B, C, torch.zeros(3, device=DEV), None, None, False)  # D length
+    out, xs = ss.fwd(u, delta, A, B, C, None, None, None, False)
+    with pytest.raises(RuntimeError):
+        ss.bwd(u, delta, A, B, C, None, None, None, _rnd(1, 4, 32), xs, out, None, False, False)  # dout length

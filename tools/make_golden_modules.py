@@ -167,12 +167,69 @@ def make_loss(R):
     save("loss_dice_bce", logits=_np(logits), targets=_np(t), loss=np.array(float(loss)), dlogits=_np(logits.grad))
 
 
+def make_blocks(R):
+    """Block-level fixtures of the reference's ResidualBlock (both forms), DecoderBlock, SideoutBlock, CBAM and RCG
+    (MMUNet.py:313-467): train mode (BatchNorm batch statistics), Dropout2d p forced to 0, output + input gradients
+    + every parameter gradient.  The reference's own response to a 1e-6 input perturbation is stored with each
+    fixture (``sens_out`` / ``sens_grad``): a parity test may not ask for better agreement than that."""
+    def run(name, build, inputs):
+        torch.manual_seed(11)
+        m = build()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        m.train()
+        state0 = {k: v.clone() for k, v in m.state_dict().items()}
+        torch.manual_seed(12)
+        xs = [torch.randn(*shp) for shp in inputs]
+        noise = [torch.randn(*shp) for shp in inputs]
+        g = None
+
+        def step(eps):
+            nonlocal g
+            m.load_state_dict(state0)
+            m.zero_grad(set_to_none=True)
+            ins = [(x + eps * nz).requires_grad_(True) for x, nz in zip(xs, noise)]
+            out = m(*ins)
+            if g is None:
+                g = torch.randn_like(out)
+            out.backward(g)
+            return out.detach(), [i.grad for i in ins], {k: p.grad.clone() for k, p in m.named_parameters()
+                                                         if p.grad is not None}
+        out, dins, grads = step(0.0)
+        out1, dins1, grads1 = step(1e-6)
+        sens_out = float((out - out1).abs().max())
+        # per-tensor response (absolute): gradients that are analytically zero (a GroupNorm bias in front of a
+        # train-mode BatchNorm) are pure rounding noise and respond by 100 % of themselves
+        sens = {"sens." + k: np.array(float((grads[k] - grads1[k]).abs().max())) for k in grads}
+        sens.update({f"sens.din{i}": np.array(float((a - b).abs().max())) for i, (a, b) in enumerate(zip(dins, dins1))})
+        sens_grad = max(float((grads[k] - grads1[k]).abs().max() / max(float(grads[k].abs().max()), 1e-30))
+                        for k in grads if float(grads[k].abs().max()) > 1e-3)
+        arrs = {f"in{i}": _np(x) for i, x in enumerate(xs)}
+        arrs.update({f"din{i}": _np(d) for i, d in enumerate(dins)})
+        arrs.update({"grad." + k: _np(v) for k, v in grads.items()})
+        arrs.update(sens)
+        sd = {"sd." + k: _np(v) for k, v in state0.items()}
+        save("block_" + name, out=_np(out), dout=_np(g), sens_out=np.array(sens_out), sens_grad=np.array(sens_grad),
+             **arrs, **sd)
+        print(f"    {name}: response of out / grads to 1e-6 input noise {sens_out:.2e} / {sens_grad:.2e}")
+
+    run("residual_32", lambda: R.ResidualBlock(32, 32, 4, downsample=False), [(2, 32, 16, 16)])
+    run("residual_down_32to64", lambda: R.ResidualBlock(32, 64, 4, downsample=True), [(2, 32, 16, 16)])
+    run("decoder_64to32", lambda: R.DecoderBlock(64, 32, num_slices=4), [(2, 64, 8, 8)])
+    run("sideout_64", lambda: R.SideoutBlock(64, 1, num_slices=4), [(2, 64, 16, 16)])
+    run("cbam_64", lambda: R.CBAM(64), [(2, 64, 16, 16)])
+    run("rcg_ns4", lambda: R.RCG(num_slices=4), [(2, 1, 8, 8), (2, 64, 16, 16), (2, 64, 8, 8)])
+
+
 def main():
     R = ref_import.load_reference_model()
     print("Mamba fixtures (reference mamba_simple.Mamba on CPU)")
     make_mamba(R)
     print("MMConv fixtures")
     make_mmconv(R)
+    print("block fixtures")
+    make_blocks(R)
     print("loss fixture")
     make_loss(R)
     print("Unet fixture")

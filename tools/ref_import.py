@@ -148,5 +148,6 @@ def load_reference_model():
     spec.loader.exec_module(loss)
 
     return types.SimpleNamespace(Mamba=Mamba, MMConv=mmu.MMConv, RCG=mmu.RCG, MM_Net=mmu.MM_Net,
-                                 CBAM=mmu.CBAM, Unet=model.Unet, DICE_BCE_Loss=loss.DICE_BCE_Loss,
+                                 CBAM=mmu.CBAM, ResidualBlock=mmu.ResidualBlock, DecoderBlock=mmu.DecoderBlock,
+                                 SideoutBlock=mmu.SideoutBlock, Unet=model.Unet, DICE_BCE_Loss=loss.DICE_BCE_Loss,
                                  selective_scan_ref=selective_scan_ref, causal_conv1d_ref=causal_conv1d_ref)
