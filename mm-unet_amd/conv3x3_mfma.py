@@ -42,8 +42,9 @@ def _wgrad(x, g, cout):
     """dW of conv2d(x, W, padding=1) from x [B, Cin, H, W] and dout g [B, Cout, H, W] (csrc/conv3x3_wgrad_mfma.hip)."""
     B, cin, H, W = x.shape
     dw = torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
-    ws = torch.empty(_lib.lib().mmu_conv3x3_wgrad_mfma_workspace_floats(B, cin, cout, H, W), device=x.device,
-                     dtype=torch.float32)
+    with torch.cuda.device(x.device):   # the workspace size follows the CU count of the device that runs the kernel
+        nws = _lib.lib().mmu_conv3x3_wgrad_mfma_workspace_floats(B, cin, cout, H, W)
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32)
     p = _lib.Conv3x3MfmaParams()
     p.batch, p.in_channels, p.out_channels, p.height, p.width, p.transposed = B, cin, cout, H, W, 0
     p.input, p.weight, p.out, p.workspace = x.data_ptr(), g.data_ptr(), dw.data_ptr(), ws.data_ptr()

@@ -285,13 +285,9 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     conv3x3_mfma_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(
         p->weight, (unsigned short *)p->workspace, p->in_channels, p->out_channels, p->transposed ? 1 : 0);
     MMU_HIP_LAUNCH_CHECK("conv3x3_mfma(prep)");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           LDS_BYTES);
-        if (e != hipSuccess) return mmu_fail("conv3x3_mfma: LDS attribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;  // per device
+    if (hipError_t e = mmu_set_lds_once(conv3x3_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
+        return mmu_fail("conv3x3_mfma: LDS attribute: %s", hipGetErrorString(e));
     ConvArgsM a;
     a.x = p->input; a.wp = (const unsigned short *)p->workspace; a.bias = p->bias; a.out = p->out;
     a.B = p->batch; a.Cin = p->in_channels; a.Cout = p->out_channels; a.H = p->height; a.W = p->width;
@@ -301,14 +297,7 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     const long total = (long)a.tiles_x * a.tiles_y * a.ncot * p->batch;
     MMU_CHECK(total < (1L << 30), "conv3x3_mfma: too many tiles");
     a.total_tiles = (int)total;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return mmu_fail("conv3x3_mfma: cannot query the device");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;   // one workgroup (158 KB of LDS) per CU
     conv3x3_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("conv3x3_mfma");

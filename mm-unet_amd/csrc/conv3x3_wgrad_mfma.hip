@@ -8,7 +8,7 @@
 // wants 8 consecutive pixels of one channel at an arbitrary pixel offset -- 16-byte LDS reads misalign.  gfx950's
 // ds_read_b64_tr_b16 reads a 4-row x 16-column block of 16-bit elements and delivers it column-major: with the input
 // patch staged as [pixel][32 ci] (64-byte rows) a B fragment is two such reads whose rows are 8 consecutive pixels,
-// and a 3x3 shift is again just an address offset.  (tools/_abl/tr_probe.hip pins the lane mapping with exact data.)
+// and a 3x3 shift is again just an address offset.  (tools/ubench/tr_probe.hip pins the lane mapping with exact data.)
 //
 // Workgroup = 9 waves = the 9 shifts; tile = 4 rows x 64 columns of pixels (16 k-steps of 16 pixels), 64 output
 // channels x 32 input channels: wave s keeps dW[64][32] of ITS shift in 32 accumulator registers and reads, per
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
         for (int k = 0; k < 3; ++k) {
             const int gy = y0 - 1 + p_pr[k], gx = x0 - 1 + p_pc[k];
             const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            pm[k] = inb ? 1.f : 0.f;
+            pm[k] = inb ? 1.f : 0.f;  // (selects below: 0 * a non-finite pixel (0, 0) would poison every padded tap)
             const float *s = p.x + ((long)b * p.Cin + cic * CI + 8 * p_cg[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) px[k][j] = s[j * HW];
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
         for (int k = 0; k < 3; ++k) {
             unsigned hw[4], lw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split2(px[k][2 * j] * pm[k], px[k][2 * j + 1] * pm[k], hw[j], lw[j]);
+            for (int j = 0; j < 4; ++j)
+                split2(pm[k] != 0.f ? px[k][2 * j] : 0.f, pm[k] != 0.f ? px[k][2 * j + 1] : 0.f, hw[j], lw[j]);
             if (p_off[k] >= 0) {
                 *reinterpret_cast<v4u *>(patch_hi + p_off[k]) = v4u{hw[0], hw[1], hw[2], hw[3]};
                 *reinterpret_cast<v4u *>(patch_lo + p_off[k]) = v4u{lw[0], lw[1], lw[2], lw[3]};
@@ -219,16 +220,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_sum_kernel(const float *__r
     if (live && sub == 15) dW[i] = a;
 }
 
-int n_cu_cached() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n_cu;
-}
+int n_cu_cached() { return mmu_cu_count(); }
 
 int wg_per_cc_for(int batch, int cin, int cout, int h, int w) {
     const int ncc = (cin / CI) * (cout / CO);
@@ -260,13 +252,9 @@ extern "C" int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *st
     MMU_CHECK(p->input && p->weight && p->out && p->workspace, "conv3x3_wgrad_mfma: input, dout, dweight, workspace required");
     MMU_CHECK(((uintptr_t)p->weight & 15) == 0, "conv3x3_wgrad_mfma: dout must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_wgrad_mfma_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return mmu_fail("conv3x3_wgrad_mfma: LDS attribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;  // per device
+    if (hipError_t e = mmu_set_lds_once(conv3x3_wgrad_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
+        return mmu_fail("conv3x3_wgrad_mfma: LDS attribute: %s", hipGetErrorString(e));
     WgArgs a;
     a.x = p->input; a.g = p->weight; a.ws = (float *)p->workspace;
     a.B = p->batch; a.Cin = p->in_channels; a.Cout = p->out_channels; a.H = p->height; a.W = p->width;

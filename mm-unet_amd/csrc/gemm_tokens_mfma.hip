@@ -241,13 +241,9 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     gemm_tokens_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->weight, p->w_ld, (unsigned short *)p->workspace,
                                                                          p->rows, p->inner, p->transposed_weight ? 1 : 0);
     MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma(prep)");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)gemm_tokens_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           LDS_BYTES);
-        if (e != hipSuccess) return mmu_fail("gemm_tokens_mfma: LDS attribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;  // per device
+    if (hipError_t e = mmu_set_lds_once(gemm_tokens_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
+        return mmu_fail("gemm_tokens_mfma: LDS attribute: %s", hipGetErrorString(e));
     GemmArgs a;
     a.x = p->x; a.wp = (const unsigned short *)p->workspace; a.out = p->out;
     a.x_rs = p->x_rs; a.x_bs = p->x_bs; a.o_rs = p->out_rs; a.o_bs = p->out_bs;
@@ -257,14 +253,7 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     const long total = (long)a.tiles_t * a.n_mt * p->batch;
     MMU_CHECK(total < (1L << 30), "gemm_tokens_mfma: too many tiles");
     a.total_tiles = (int)total;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return mmu_fail("gemm_tokens_mfma: cannot query the device");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;   // persistent: one workgroup per CU (register-bound: 2 waves/SIMD)
     gemm_tokens_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma");

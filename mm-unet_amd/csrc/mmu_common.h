@@ -26,6 +26,30 @@ int mmu_fail(const char *fmt, ...);
         if (e__ != hipSuccess) return mmu_fail("%s: %s", what, hipGetErrorString(e__));   \
     } while (0)
 
+// Per-DEVICE one-time setup: one process may drive several GPUs -- a function attribute set while device 0 was
+// current is not set on device 1, and the CU count is a property of the device, not of the process.
+inline int mmu_cu_count() {
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    dev &= 63;
+    if (n[dev] == 0) {
+        hipDeviceProp_t prop;
+        n[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n[dev];
+}
+template <typename F>
+inline hipError_t mmu_set_lds_once(F kernel, int bytes, unsigned long long &done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((done_mask >> (dev & 63)) & 1ull) return hipSuccess;
+    e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done_mask |= 1ull << (dev & 63);
+    return e;
+}
+
 // ---------------------------------------------------------------------------
 // I/O element types
 // ---------------------------------------------------------------------------

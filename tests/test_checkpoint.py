@@ -90,3 +90,47 @@ def test_directory_written_here_loads_through_accelerate(tmp_path, safe):
     for k, v in acc.unwrap_model(m2).state_dict().items():
         assert torch.equal(v, m.state_dict()[k]), k
     assert sch2.state_dict()["last_epoch"] == 2
+
+
+def test_optimizer_bin_in_timm_group_order_round_trips_through_make_optimizer(tmp_path):
+    """The reference's optimizer is timm's ``create_optimizer_v2`` (train.py:197-201), whose parameter groups are
+    ``[no_decay (weight_decay 0), decay]`` (optim_factory.py: param_groups_weight_decay / add_weight_decay).
+    ``optimizer.state_dict()`` numbers the parameters in group order, so an ``optimizer.bin`` written by the
+    reference's training run loads into ``make_optimizer``'s optimizer only if the groups are laid out the same way:
+    a state dict built in timm's order by an INDEPENDENT restatement must load, attach every moment to the parameter
+    it belongs to, and keep the weight-decay assignment."""
+    from mm_unet_amd.checkpoint import load_state, save_state
+    from mm_unet_amd.train_step import make_optimizer
+    m = _model()
+    # "reference side": groups exactly as timm builds them
+    named = list(m.named_parameters())
+    no_decay = [p for n, p in named if p.ndim <= 1 or n.endswith(".bias")]
+    decay = [p for n, p in named if not (p.ndim <= 1 or n.endswith(".bias"))]
+    assert len(no_decay) != len(decay)          # a swapped order could not even load
+    ref_opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.05}],
+                                lr=1e-3, betas=(0.9, 0.95))
+    sch = torch.optim.lr_scheduler.StepLR(ref_opt, 1, gamma=0.5)
+    _train_a_little(m, ref_opt, sch)
+    d = str(tmp_path / "checkpoint")
+    save_state(d, m, ref_opt, sch, epoch=1, best_acc=0.1, best_class=[0.1])
+    moments = {n: ref_opt.state[p]["exp_avg"].clone() for n, p in named}
+
+    m2 = _model()
+    opt2 = make_optimizer(m2, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.95), fused=False)
+    load_state(d, m2, opt2)                      # raises ValueError on a group-size mismatch
+    assert [g["weight_decay"] for g in opt2.param_groups] == [0.0, 0.05]
+    for n, p in m2.named_parameters():
+        assert torch.equal(opt2.state[p]["exp_avg"], moments[n]), f"moment of {n} attached to another parameter"
+        wd = next(g["weight_decay"] for g in opt2.param_groups if any(q is p for q in g["params"]))
+        assert wd == (0.0 if (p.ndim <= 1 or n.endswith(".bias")) else 0.05), n
+    # and the other direction: a directory written from make_optimizer's optimizer loads into the timm-ordered one
+    d2 = str(tmp_path / "best")
+    save_state(d2, m2, opt2)
+    m3 = _model()
+    named3 = list(m3.named_parameters())
+    opt3 = torch.optim.AdamW([{"params": [p for n, p in named3 if p.ndim <= 1 or n.endswith(".bias")], "weight_decay": 0.0},
+                              {"params": [p for n, p in named3 if not (p.ndim <= 1 or n.endswith(".bias"))],
+                               "weight_decay": 0.05}], lr=1e-3, betas=(0.9, 0.95))
+    load_state(d2, m3, opt3)
+    for n, p in named3:
+        assert torch.equal(opt3.state[p]["exp_avg"], moments[n]), n
