@@ -12,6 +12,9 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
                   B=8, D=128, L=65536, N=16) timed live with HIP events on the stream it
                   is launched on; achieved = algorithmic bytes s*B*L*(4D+2N) / mean duration of one
                   mmu_selective_scan_fwd call; peak = 8 TB/s HBM3E; traffic from profiles/ if measured;
+  "roofline_bwd", "roofline_d6", "roofline_bwd_d6", "roofline_conv1d", "roofline_conv1d_bwd":
+                  the same for the scan backward (bytes s*B*L*(8D+2N) + 4*B*L*2N), for both at the 6-channel census
+                  shape of MMConv's Mamba blocks (B=8, D=6, L=65536), and for causal conv1d (2 / 3 * s*B*D*L);
   "roofline_conv": the MFMA-bound kernel of the path (csrc/conv3x3_mfma.hip at CBAM's shape [8,64,256,256] 64->64 and
                   at a Unet shape [8,256,64,64] 256->256), same timing method; achieved = bf16 MFMA FLOP/s actually
                   issued (3 passes of 2*B*Cout*H*W*Cin*9 for the hi/lo split); peak = 2.5 PFLOP/s dense bf16;
@@ -53,45 +56,97 @@ def parse():
     return ap.parse_args()
 
 
-def scan_roofline(dev, iters=20):
-    """Live measurement of the selective-scan forward at the headline shape."""
-    from mm_unet_amd import selective_scan_hip as ss
-    b, d, l, n = 8, 128, 65536, 16
+def _timed(dev, fn, iters):
+    """Mean duration (ms) of fn() over `iters` calls, HIP events on the stream the kernels are launched on."""
+    for _ in range(3):
+        fn()
+    st = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _traffic(name):
+    tpath = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(tpath):
+        try:
+            return json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def _scan_case(dev, b, d, l, n, layout):
+    """Inputs with the reference test's distributions (tests/ops/test_selective_scan.py:53-88).  layout "dbl": u, delta,
+    z, dout physically [D][B][L] (what mamba_inner hands the kernels); "bdl": contiguous."""
     gen = torch.Generator(device=dev).manual_seed(0)
     A = -0.5 * torch.rand(d, n, device=dev, generator=gen)
     B = torch.randn(b, 1, n, l, device=dev, generator=gen)
     C = torch.randn(b, 1, n, l, device=dev, generator=gen)
     D = torch.randn(d, device=dev, generator=gen)
-    z = torch.randn(b, d, l, device=dev, generator=gen)
     bias = 0.5 * torch.rand(d, device=dev, generator=gen)
-    u = torch.randn(b, d, l, device=dev, generator=gen)
-    delta = 0.5 * torch.rand(b, d, l, device=dev, generator=gen)
-    for _ in range(3):
-        ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False)
-    st = torch.cuda.current_stream(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False)
-    e1.record(st)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    alg_bytes = 4 * b * l * (4 * d + 2 * n)  # fp32: u, delta, z read + out_z written + B, C read once
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "scan_fwd_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-            "kernel": "mmu_selective_scan_fwd = chunk_reduce8 + chunk_carry_par + chunk_apply_fwd8 (one call)",
-            "binding": "VALU / transcendental issue, not HBM: SQ_ACTIVE_INST_VALU 85-87 % of kernel cycles in "
-                       "chunk_reduce8 / chunk_apply_fwd8 (DESIGN.md 4.1)",
-            "shape": {"batch": b, "dim": d, "seqlen": l, "dstate": n, "dtype": "f32"},
-            "algorithmic_bytes": alg_bytes, "ms_per_launch": round(ms, 4)}
+
+    def mk(scale_rand=False):
+        shape = (d, b, l) if layout == "dbl" else (b, d, l)
+        t = 0.5 * torch.rand(*shape, device=dev, generator=gen) if scale_rand else torch.randn(*shape, device=dev, generator=gen)
+        return t.permute(1, 0, 2) if layout == "dbl" else t
+    u, z, dout = mk(), mk(), mk()
+    delta = mk(True)
+    return u, delta, A, B, C, D, z, bias, dout
+
+
+def scan_rooflines(dev, iters=20):
+    """Live measurement of the hand-written streaming kernels against the HBM roofline (algorithmic bytes of
+    SURVEY.md 8d / DESIGN.md 4): selective-scan forward and backward at the headline shape, the same at the
+    6-channel census shape (MMConv's Mamba blocks), and causal conv1d forward / backward."""
+    from mm_unet_amd import causal_conv1d_hip as cc, selective_scan_hip as ss
+    s_ = 4  # fp32
+    legs = {}
+
+    def leg(name, kernel, shape, alg_bytes, ms, binding, traffic=None):
+        ach = alg_bytes / (ms * 1e-3) / 1e9
+        legs[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                      "frac": round(ach / 8000.0, 4), "traffic": traffic, "kernel": kernel, "binding": binding,
+                      "shape": shape, "algorithmic_bytes": alg_bytes, "ms_per_launch": round(ms, 4)}
+
+    for (b, d, l, n, tag) in ((8, 128, 65536, 16, ""), (8, 6, 65536, 16, "_d6")):
+        u, delta, A, B, C, D, z, bias, dout = _scan_case(dev, b, d, l, n, "bdl" if tag == "" else "dbl")
+        shape = {"batch": b, "dim": d, "seqlen": l, "dstate": n, "dtype": "f32"}
+        ms_f = _timed(dev, lambda: ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False), iters)
+        x = ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False)[1]
+        ms_b = _timed(dev, lambda: ss.bwd(u, delta, A, B, C, D, z, bias, dout, x, None, None, True, False), iters)
+        streaming = b * d >= 512
+        leg("roofline" + tag,
+            "mmu_selective_scan_fwd = scan_fwd_stream_kernel (one launch: every (batch, channel) row scanned front to "
+            "back, state carried in registers)" if streaming else
+            "mmu_selective_scan_fwd = chunk_reduce8 + chunk_carry_par + chunk_apply_fwd8 (chunk-parallel: too few "
+            "rows to stream)", shape, s_ * b * l * (4 * d + 2 * n), ms_f,
+            "VALU issue, not HBM: one v_exp_f32 + ~5.6 VALU instructions per (d, n, t) element group against a budget "
+            "of ~6.5 issue slots at 70 % of HBM (DESIGN.md 4.1)", _traffic("scan_fwd_traffic.json") if tag == "" else None)
+        leg("roofline_bwd" + tag,
+            "mmu_selective_scan_bwd = chunk_reduce8<bwd> + chunk_carry_par + chunk_apply_bwd_p4 + reduce_partials",
+            shape, s_ * b * l * (8 * d + 2 * n) + 4 * b * l * 2 * n, ms_b,
+            "VALU issue: ~29 VALU instructions per (d, n, t) element group (recompute + adjoint scan + 8 gradient "
+            "streams), DESIGN.md 4.2", _traffic("scan_bwd_traffic.json") if tag == "" else None)
+        if tag == "":
+            w = torch.randn(d, 4, device=dev)
+            cb = torch.randn(d, device=dev)
+            ms_cf = _timed(dev, lambda: cc.causal_conv1d_fwd(u, w, cb, True), iters)
+            ms_cb = _timed(dev, lambda: cc.causal_conv1d_bwd(u, w, cb, dout, None, True), iters)
+            cshape = {"batch": b, "dim": d, "seqlen": l, "width": 4, "dtype": "f32"}
+            leg("roofline_conv1d", "mmu_causal_conv1d_fwd (width 4 + bias + SiLU)", cshape, 2 * s_ * b * d * l, ms_cf,
+                "HBM (streaming)")
+            leg("roofline_conv1d_bwd", "mmu_causal_conv1d_bwd (dx, dW, db)", cshape, 3 * s_ * b * d * l, ms_cb,
+                "HBM (streaming) + per-block reductions for dW / db")
+    return legs
+
+
+def scan_roofline(dev, iters=20):
+    return scan_rooflines(dev, iters)["roofline"]
 
 
 def conv_roofline(dev, iters=20):
@@ -171,7 +226,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.roofline_only:
-        print(json.dumps({"roofline": scan_roofline(dev), "roofline_conv": conv_roofline(dev)}), flush=True)
+        legs = scan_rooflines(dev)
+        legs["roofline_conv"] = conv_roofline(dev)
+        print(json.dumps(legs), flush=True)
         return
 
     if args.infer:
@@ -252,7 +309,7 @@ def main():
                        "final_loss": round(float(loss), 5)},
         }
         if not args.no_roofline:
-            line["roofline"] = scan_roofline(dev)
+            line.update(scan_rooflines(dev))
             line["roofline_conv"] = conv_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_size)

@@ -1337,14 +1337,16 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
                     const v2f Ct = hsel ? v2f{fc.z, fc.w} : v2f{fc.x, fc.y};
                     const v2f gt = hsel ? fma_bcast<1>(dy2[k], Ct, gam) : fma_bcast<0>(dy2[k], Ct, gam);
                     gam = a[i] * gt;
-                    const v2f ahp = bb[i];
-                    const v2f gdl = hsel ? mul_bcast<1>(dl2[k], gt) : mul_bcast<0>(dl2[k], gt);
-                    const v2f uB = hsel ? mul_bcast<1>(u2[k], Bt) : mul_bcast<0>(u2[k], Bt);
-                    du2[i] = fma2(gdl, Bt, du2[i]);
-                    dd2[i] = fma2(gt, fma2(An, ahp, uB), dd2[i]);
-                    dAp = fma2(gdl, ahp, dAp);
+                    // With q_t = sum_n g B (summed over the states, then over the four waves):
+                    //   du = delta q + D dy ;  ddelta' = u q + sum_n A (g a h_prev) ;  dA = sum_t delta (g a h_prev) ;
+                    //   dB = (delta u) g  -- two packed instructions per token and pair fewer than forming
+                    //   g delta and u B first; the q -> du / ddelta step runs once per token in the epilogue.
+                    const v2f gah = gt * bb[i];  // g_t * a_t h_{t-1}
+                    du2[i] = fma2(gt, Bt, du2[i]);          // q
+                    dd2[i] = fma2(An, gah, dd2[i]);
+                    dAp = hsel ? fma_bcast<1>(dl2[k], gah, dAp) : fma_bcast<0>(dl2[k], gah, dAp);
                     y2[i] = fma2(Ct, hh[i], y2[i]);
-                    accB[pi][i] = hsel ? fma_bcast<1>(u2[k], gdl, accB[pi][i]) : fma_bcast<0>(u2[k], gdl, accB[pi][i]);
+                    accB[pi][i] = hsel ? fma_bcast<1>(dlu2[k], gt, accB[pi][i]) : fma_bcast<0>(dlu2[k], gt, accB[pi][i]);
                     accC[pi][i] = hsel ? fma_bcast<1>(dy2[k], hh[i], accC[pi][i]) : fma_bcast<0>(dy2[k], hh[i], accC[pi][i]);
                 }
             }
@@ -1360,12 +1362,19 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
         xc[(w * 3 + 1) * 64 + lane] = make_float4(du2[0].x + du2[0].y, du2[1].x + du2[1].y, du2[2].x + du2[2].y, du2[3].x + du2[3].y);
         xc[(w * 3 + 2) * 64 + lane] = make_float4(dd2[0].x + dd2[0].y, dd2[1].x + dd2[1].y, dd2[2].x + dd2[2].y, dd2[3].x + dd2[3].y);
         MMU_LDS_BARRIER();
-        const int arr = w == 0 ? 1 : (w == 1 ? 2 : 0);
-        float tot[4] = {0.f, 0.f, 0.f, 0.f};
+        const int arr = w == 0 ? 1 : (w == 1 ? 2 : 0);   // rows of the exchange: 0 = y, 1 = q, 2 = sum_n A g a h_prev
+        float tot[4] = {0.f, 0.f, 0.f, 0.f}, totq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 o = xc[(q * 3 + arr) * 64 + lane];
             tot[0] += o.x; tot[1] += o.y; tot[2] += o.z; tot[3] += o.w;
+        }
+        if (w == 1) {  // d(delta) needs q as well
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o = xc[(q * 3 + 1) * 64 + lane];
+                totq[0] += o.x; totq[1] += o.y; totq[2] += o.z; totq[3] += o.w;
+            }
         }
         // partial sums of dA (this wave's 4 states), dD, dbias: row of chunk c0; zeros for chunk c0 + 1
         const unsigned prow = dcur * (unsigned)(N + 2) * 4u, prow1 = prow + (unsigned)p.dim * (N + 2) * 4u;
@@ -1379,14 +1388,14 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
         float ov[4];
         if (w == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ov[i] = fmaf(Dv, dy[i], tot[i]);
+            for (int i = 0; i < 4; ++i) ov[i] = fmaf(Dv, dy[i], dl[i] * tot[i]);   // du = delta q + D dy
             buf_store4<io_t>(r_o, voff, dcur * o_ds * ES, ov);
         } else if (w == 1) {
             float dbp = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float dsp = (p.softplus && vraw[i] <= 20.f) ? sigmoidf_(vraw[i]) : 1.f;  // bwd_kernel.cuh:439-453
-                ov[i] = tot[i] * dsp;
+                ov[i] = fmaf(uv[i], totq[i], tot[i]) * dsp;                          // ddelta' = u q + sum_n A g a h_prev
                 dbp += ov[i];
             }
             buf_store4<io_t>(r_o, voff, dcur * o_ds * ES, ov);

@@ -57,10 +57,16 @@ static_assert(ST_LDS == 160 * 1024, "the double-buffered B / C tile + exchange r
 // One state pair over this lane's 8 tokens (see fwd_pair8 in selective_scan.hip): exps and the lane's local
 // composition, the cross-lane scan with the carry folded into lane 0, then the true recurrence and y.
 // hc: state of the pair entering the tile; leaves holding the state at the end of the tile.
+#ifdef MMU_STREAM_STAMPS
+#define ST_T(i) do { asm volatile("" ::: "memory"); ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ST_T(i)
+#endif
 __device__ __forceinline__ void stream_pair(const v2f (&dl)[4], const v2f (&du)[4], float dlsum, v2f (&yp)[8],
                                             const v2f a2, v2f &hc, const float *tileB, const float *tileC, int pr,
-                                            int lane, float4 &rec) {
+                                            int lane, float4 &rec, unsigned long long *ts = nullptr) {
     v2f a[8], bb[8], Bv[8], Cv[8];
+    ST_T(0);
     pair8_read(tileB, pr, lane, Bv);  // lands behind the 16 exps
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -69,6 +75,7 @@ __device__ __forceinline__ void stream_pair(const v2f (&dl)[4], const v2f (&du)[
     }
     const v2f P = exp2_2(a2 * dlsum);
     __builtin_amdgcn_sched_barrier(0);
+    ST_T(1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         bb[2 * q] = mul_bcast<0>(du[q], Bv[2 * q]);
@@ -81,14 +88,23 @@ __device__ __forceinline__ void stream_pair(const v2f (&dl)[4], const v2f (&du)[
     S = lane == 0 ? S_in : S;
     float P0 = P.x, S0 = S.x, P1 = P.y, S1 = S.y;
     __builtin_amdgcn_sched_barrier(0);
+    ST_T(2);
     pair8_read(tileC, pr, lane, Cv);  // lands during the scan
     wave_scan_affine_x2(P0, S0, P1, S1);
     v2f h = v2f{wave_shift_up1(S0, hc.x), wave_shift_up1(S1, hc.y)};  // states entering this lane's tokens
+#ifdef MMU_STREAM_STAMPS
+    asm volatile("" : "+v"(h));
+#endif
+    ST_T(3);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         h = fma2(a[i], h, bb[i]);
         yp[i] = fma2(Cv[i], h, yp[i]);
     }
+#ifdef MMU_STREAM_STAMPS
+    asm volatile("" : "+v"(yp[7]), "+v"(h));
+#endif
+    ST_T(4);
     rec = make_float4(P0, S0, P1, S1);
     hc = v2f{wave_bcast_last(S0), wave_bcast_last(S1)};
     asm volatile("" : "+v"(hc));  // carried in VGPRs (see a2)
@@ -269,7 +285,15 @@ __global__ __launch_bounds__(512, 2) void scan_fwd_stream_kernel(ScanArgs p) {
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
             float4 rec;
+#ifdef MMU_STREAM_STAMPS
+            unsigned long long ts[5];
+            stream_pair(dl2, du2, dlsum, yp, a2[pr], hc[pr], tileB, tileC, 4 * hf + pr, lane, rec, ts);
+            if (pr == 2 && (blockIdx.x == 0 || blockIdx.x == 131) && k >= 16 && k < 24 && lane == 0)
+                for (int i = 0; i < 4; ++i)
+                    g_stream_stamps[(((blockIdx.x != 0) * 8 + w) * 8 + (k - 16)) * 16 + 12 + i] = ts[i + 1] - ts[i];
+#else
             stream_pair(dl2, du2, dlsum, yp, a2[pr], hc[pr], tileB, tileC, 4 * hf + pr, lane, rec);
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(
                 v4u{__float_as_uint(rec.x), __float_as_uint(rec.y), __float_as_uint(rec.z), __float_as_uint(rec.w)},
                 r_x, voff_x + 16u * pr, 0, 0);
