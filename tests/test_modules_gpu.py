@@ -856,41 +856,55 @@ def test_train_step_vs_oracle_side_step():
 
 
 def test_train_step_graph_replay_matches_eager():
-    """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) against the eager trajectory, compared on
-    POST-STEP WEIGHTS after 2 eager warm-up steps + 2 replays (a stale or accumulated gradient under replay moves
-    most elements of every tensor; the only legitimate differences are sign flips of rounding-noise gradients, where
-    the sampler's / conv1d's float atomics pick the order)."""
+    """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) against the eager step.  The learning rate is 0,
+    so the weights never move and every step's gradient is a function of the step's batch alone; what is compared
+    is AdamW's state after 2 eager warm-up steps + 2 replays -- the exponential averages of the gradients and of
+    their squares, i.e. every gradient the replayed backward produced.  A stale input buffer or a gradient that is
+    accumulated instead of overwritten under replay changes them by O(1); the float atomics of the sampler /
+    conv1d weight gradient (the only run-to-run difference of the kernels) by ~1 % at the far end of the backward.  (Comparing trained weights
+    instead is hopeless: the network amplifies 1e-7 of atomic-order noise ~6,000x per step -- the reference's own
+    response, fixture ``train_logits_sens`` -- and Adam turns every sign flip of a noise-level gradient into 2 lr.)"""
     from mm_unet_amd.loss import DICE_BCE_Loss
     from mm_unet_amd.train_step import TrainStep, make_optimizer
     gen = torch.Generator().manual_seed(3)
     xs = [torch.randn(2, 3, 64, 64, generator=gen).to(DEV) for _ in range(4)]
     ts = [(torch.rand(2, 1, 64, 64, generator=gen) > 0.88).float().to(DEV) for _ in range(4)]
-    lr = 1e-3
-    losses, weights = {}, {}
+    losses, state, w0 = {}, {}, None
     for mode in ("eager", "graph"):
-        # eval-mode normalisation (running statistics): with batch statistics of 2 images the network amplifies
-        # the float-atomic reordering noise of the sampler ~6,000x (the reference's own response, fixture
-        # ``train_logits_sens``) and no two runs of ANY implementation keep Adam's sign(g) -- see the test above
-        m = _mmnet().eval()
-        step = TrainStep(m, DICE_BCE_Loss(), make_optimizer(m, lr=lr, capturable=(mode == "graph")),
-                         use_graph=(mode == "graph"))
+        m = _mmnet().eval()           # (running statistics: the batch-statistics path amplifies the atomics' noise)
+        if w0 is None:
+            w0 = {k: v.detach().clone() for k, v in m.named_parameters()}
+        opt = make_optimizer(m, lr=0.0, capturable=(mode == "graph"))
+        step = TrainStep(m, DICE_BCE_Loss(), opt, use_graph=(mode == "graph"))
         losses[mode] = [float(step(x, t)) for x, t in zip(xs, ts)]
+        torch.cuda.synchronize()
         assert (mode == "graph") == (step._graph is not None)
-        weights[mode] = {k: v.detach().clone() for k, v in m.named_parameters()}
+        names = {id(p_): k for k, p_ in m.named_parameters()}
+        state[mode] = {names[id(p_)]: (st["exp_avg"].clone(), st["exp_avg_sq"].clone()) for p_, st in opt.state.items()}
+        for k, v in m.named_parameters():
+            assert torch.equal(v.detach(), w0[k]), f"{k} moved at lr = 0"
     assert all(np.isfinite(v) for v in losses["graph"])
-    assert abs(losses["eager"][0] - losses["graph"][0]) < 1e-3
-    moved = 0
-    for k, we in weights["eager"].items():
-        wg = weights["graph"][k]
-        d = (we - wg).abs()
-        assert float(d.max()) <= 2.2 * lr * len(xs), f"{k}: weights differ by {float(d.max()):.2e} after {len(xs)} steps"
-        frac = float((d > 5e-5).float().mean())
-        # (a stale input or an accumulated gradient under replay moves ~all elements of every tensor by O(lr);
-        # sign flips of noise-level gradients, which then feed back through the sampler, reach ~10 % of one tensor)
-        assert frac < 0.30 or we.numel() < 1000, f"{k}: {frac:.1%} of the elements moved apart under graph replay"
-        moved += int((d > 5e-5).sum())
-    total = sum(v.numel() for v in weights["eager"].values())
-    assert moved < 0.05 * total, f"{moved}/{total} weights differ between eager and graph-replayed training"
+    for a, b_ in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b_) < 1e-4 * max(1.0, abs(a)), (losses["eager"], losses["graph"])
+    assert state["eager"].keys() == state["graph"].keys() and len(state["eager"]) > 300
+    # Norm-wise comparison (measured run to run: up to ~5 % on single small-gradient tensors -- the eval-mode
+    # network answers a 1e-6 input perturbation with 2 % on the stem gradient, fixture ``eval_sens`` -- and 0.1 %
+    # over the whole gradient; a replay bug is O(100 %) everywhere)
+    num = den = num2 = den2 = 0.0
+    for k, (ea, ea2) in state["eager"].items():
+        ga, ga2 = state["graph"][k]
+        n_, d_ = float((ea - ga).double().pow(2).sum()), float(ea.double().pow(2).sum())
+        num, den = num + n_, den + d_
+        num2, den2 = num2 + float((ea2 - ga2).double().pow(2).sum()), den2 + float(ea2.double().pow(2).sum())
+    total = den ** 0.5
+    for k, (ea, _) in state["eager"].items():
+        ga = state["graph"][k][0]
+        nk = float(ea.double().norm())
+        if nk > 1e-2 * total:   # tensors that carry a visible share of the gradient
+            rel = float((ea - ga).double().norm()) / nk
+            assert rel < 0.2, f"{k}: exp_avg differs by {rel:.1%} between eager and graph replay"
+    assert (num / den) ** 0.5 < 0.02, f"gradient averages differ by {(num / den) ** 0.5:.2%} overall"
+    assert (num2 / den2) ** 0.5 < 0.05, f"squared-gradient averages differ by {(num2 / den2) ** 0.5:.2%} overall"
 
 
 def test_captured_optimizer_step_follows_the_learning_rate():
