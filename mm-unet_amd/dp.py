@@ -19,7 +19,14 @@ for this model and this fabric:
     pre-existing bucket views costs one ``add_`` launch per parameter per step (1,069 launches, 8 ms
     of GPU time and as much host time on MI355X, measured).
   * with a single rank nothing is copied or launched at all;
-  * per-replica BatchNorm statistics and per-replica loss, like DDP (no SyncBN in the reference).
+  * under HIP-graph replay (``static_grads=True``, what ``bench.py`` runs) the hooks are off: forward + backward
+    are one graph, and the exchange -- pack, all-reduce, unpack, three buckets -- runs after the replay, not
+    overlapped with the backward (38 MB over xGMI is < 1 % of a 52 ms step);
+  * per-replica BatchNorm batch statistics and per-replica loss, as under DDP (no SyncBN in the reference).
+    BUFFERS: DDP's default ``broadcast_buffers=True`` re-broadcasts rank 0's BatchNorm running statistics at
+    every forward, so under the reference every rank validates / checkpoints with rank 0's statistics.  Here
+    nothing is exchanged per step (18,968 floats that only matter in eval mode); call ``sync_buffers`` before
+    validation and before saving a checkpoint to get the same state.
 """
 import torch
 import torch.distributed as dist
@@ -29,6 +36,16 @@ def broadcast_module_state(module, src=0, group=None):
     """DDP construction semantics: parameters and buffers of rank ``src`` everywhere."""
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=group)
+
+
+def sync_buffers(module, src=0, group=None):
+    """Rank ``src``'s buffers (BatchNorm running statistics, ``num_batches_tracked``) everywhere: what DDP's
+    ``broadcast_buffers=True`` leaves every rank with.  Call before validation / checkpointing."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in module.buffers():
             dist.broadcast(t, src=src, group=group)
 
 

@@ -2,7 +2,9 @@
  (a) discovers the live-parameter set once and skips never-used parameters (MM-UNet has 6.76 M of them),
  (b) leaves in every p.grad the MEAN over ranks of the local gradients (== DDP semantics, train.py:52,252),
  (c) keeps replicas bit-identical after optimizer steps, with and without hook-driven overlap,
- (d) broadcast_module_state makes replicas equal at start.
+ (d) broadcast_module_state makes replicas equal at start,
+ (e) BatchNorm running statistics stay per replica during training; sync_buffers gives every rank rank 0's (DDP's
+     broadcast_buffers state) for validation / checkpoints.
 The model is a small pure-ATen network (the MM-UNet blocks themselves are GPU-only)."""
 import os
 import sys
@@ -36,7 +38,7 @@ def _worker(rank, world, port, overlap, bucket_bytes, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from mm_unet_amd.dp import GradAllReducer, broadcast_module_state
+        from mm_unet_amd.dp import GradAllReducer, broadcast_module_state, sync_buffers
         torch.manual_seed(100 + rank)            # different init per rank on purpose
         net = Net()
         broadcast_module_state(net)
@@ -74,6 +76,9 @@ def _worker(rank, world, port, overlap, bucket_bytes, q):
         out["payload"] = red.payload_bytes()
         out["n_buckets"] = len(red.buckets)
         out["w"] = torch.cat([p.detach().flatten() for p in net.parameters()]).numpy().copy()  # by value
+        out["bn_before"] = net.bn.running_mean.numpy().copy()   # per-replica statistics (different data per rank)
+        sync_buffers(net)                                        # what DDP's broadcast_buffers leaves behind
+        out["bn_after"] = net.bn.running_mean.numpy().copy()
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -97,3 +102,5 @@ def test_grad_allreduce_two_ranks_gloo(overlap, bucket_bytes):
     if bucket_bytes < 1024:
         assert res[0]["n_buckets"] > 1           # several buckets, launched from hooks as they fill
     assert (res[0]["w"] == res[1]["w"]).all(), "replicas diverged"
+    assert not (res[0]["bn_before"] == res[1]["bn_before"]).all()       # running statistics are per replica ...
+    assert (res[1]["bn_after"] == res[0]["bn_before"]).all() and (res[0]["bn_after"] == res[0]["bn_before"]).all()
