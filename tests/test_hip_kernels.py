@@ -252,6 +252,50 @@ def test_scan_fwd_stream_vs_oracle_and_chunk_path(case):
         close(r[4], og["dC"], RTOL, ATOL * max(1, d // 32), "dC (streamed states)")
 
 
+def test_scan_state_groups_dstate64_vs_golden_and_generic(monkeypatch):
+    """dstate = 64 (BASELINE config 5) as four dstate-16 launches on strided views (selective_scan_hip._fwd_groups /
+    _bwd_groups) against the reference fixture ``scan_c5_D8_L512_N64`` and against the single generic-dstate launch on a
+    larger case: outputs, every chunk state, every gradient."""
+    from mm_unet_amd import selective_scan_hip as ss
+    monkeypatch.setattr(ss, "GROUP_SPLIT_MIN_ELEMENTS", 1)
+    g = golden("scan_c5_D8_L512_N64")
+    u, delta, A, B, C = (_g(g, k) for k in ("u", "delta", "A", "B", "C"))
+    D, z, bias, dout = (_g(g, k) for k in ("D", "z", "delta_bias", "dout"))
+    sp = bool(g["softplus"])
+    assert ss.group_split(A.shape[1], u)
+    res = ss.fwd(u, delta, A, _bc4(B), _bc4(C), D, z, bias, sp)
+    close(res[2] if z is not None else res[0], g["out"], RTOL, ATOL, "out")
+    close(res[1][:, :, -1, 1::2], g["last_state"], RTOL, ATOL, "last_state")
+    r = ss.bwd(u, delta, A, _bc4(B), _bc4(C), D, z, bias, dout, res[1], res[0], None, sp, z is not None)
+    close(r[0], g["du"], RTOL * 2, ATOL * 2, "du")
+    close(r[1], g["ddelta"], RTOL * 5, ATOL * 10, "ddelta")
+    close(r[2], g["dA"], RTOLW, ATOLW * 5, "dA")
+    close(r[3].reshape(g["dB"].shape), g["dB"], RTOL, ATOL, "dB")
+    close(r[4].reshape(g["dC"].shape), g["dC"], RTOL, ATOL, "dC")
+    for i, k in ((5, "dD"), (6, "ddelta_bias"), (7, "dz")):
+        if k in g:
+            close(r[i], g[k], RTOLW, ATOLW, k)
+    # larger case, mamba layout, against the generic single launch (and the bf16 contract)
+    for dt, rt, at in ((torch.float32, RTOL, ATOL), (torch.bfloat16, 3e-2, 6e-2)):
+        c = _rand_case(2, 16, 2048, 64, seed=4)
+        mk = lambda t_: t_.to(dt).permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)  # noqa: E731
+        uu, dd, zz, go = mk(c["u"]), mk(c["delta"]), mk(c["z"]), mk(c["dout"])
+        AA, DD, bb = c["A"].to(DEV), c["D"].to(DEV), c["delta_bias"].to(DEV)
+        BB, CC = c["B"].to(dt).to(DEV), c["C"].to(dt).to(DEV)
+        a = ss.fwd(uu, dd, AA, BB, CC, DD, zz, bb, True)
+        ga = ss.bwd(uu, dd, AA, BB, CC, DD, zz, bb, go, a[1], a[0], None, True, True)
+        monkeypatch.setattr(ss, "GROUP_SPLIT", False)
+        b_ = ss.fwd(uu, dd, AA, BB, CC, DD, zz, bb, True)
+        gb = ss.bwd(uu, dd, AA, BB, CC, DD, zz, bb, go, b_[1], b_[0], None, True, True)
+        monkeypatch.setattr(ss, "GROUP_SPLIT", True)
+        close(a[0], b_[0], rt, at, f"out {dt}")
+        close(a[2], b_[2], rt, at, f"out_z {dt}")
+        close(a[1][..., 1::2], b_[1][..., 1::2], RTOL, ATOL, f"chunk states {dt}")
+        for i, nm in enumerate(["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z"]):
+            sc = max(1.0, float(gb[i].float().abs().max()))
+            close(ga[i], gb[i], rt * 3, at * 3 * (sc if nm in ("dA", "dD", "ddelta_bias") else 1.0), f"{nm} {dt}")
+
+
 def test_scan_bwd_reproducibility():
     """Every gradient of the dstate-16 backward (K4p / K4s: register dB/dC sums, no atomics anywhere) is
     bit-identical run to run; the reference uses global float atomics for dA/dB/dC/dD/dbias
