@@ -186,8 +186,8 @@ def _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_
 # state (BASELINE config 5: d_state = 64) is a SUM over groups of 16 states of independent recurrences:
 #     y = sum_g y_g + D u,   h of group g depends on A[:, 16g:16g+16], B[:, :, 16g:16g+16], C[:, :, 16g:16g+16] only,
 # so it runs as one dstate-16 call per group on strided VIEWS of A / B / C (no copies; dB / dC of a group are written
-# straight into their rows), the per-token sums (y, du, ddelta, ddelta_bias) are added up in float32, and the gate /
-# its gradient are applied once to the total -- instead of the generic-dstate kernels, whose backward adds dB / dC with
+# straight into their rows) and the per-token results -- all linear in the group's y, the gate included -- are added
+# up in float32, instead of the generic-dstate kernels, whose backward adds dB / dC with
 # LDS float atomics (137 of 212 GPU-ms per training step of config 5, profiles/r02_config5_before.txt).
 # Worth it only when the scan is large; small scans (MMConv's 6-channel blocks) keep the single generic launch.
 GROUP_SPLIT = True
@@ -195,8 +195,7 @@ GROUP_SPLIT_MIN_ELEMENTS = 1 << 22   # batch * dim * seqlen
 
 
 def group_split(dstate, u):
-    """True when fwd / bwd run this call as dstate // 16 launches of the dstate-16 kernels (then the backward wants
-    the un-gated ``out`` of the forward: callers that normally drop it should keep it)."""
+    """True when fwd / bwd run this call as dstate // 16 launches of the dstate-16 kernels."""
     return (GROUP_SPLIT and dstate > 16 and dstate % 16 == 0 and u.numel() >= GROUP_SPLIT_MIN_ELEMENTS
             and u.shape[-1] % 512 == 0)
 
@@ -207,11 +206,6 @@ def _groups(A, B, C):
         yield g, sl, A[:, sl], B[:, :, sl], C[:, :, sl]
 
 
-def _silu(z):
-    zf = z.float()
-    return zf * torch.sigmoid(zf)
-
-
 def _f32(*ts):
     """bf16 I/O: the group launches run on float32 copies -- a group's y can be two orders of magnitude larger than
     the sum over the groups, and rounding each partial to bf16 first costs the sum its last bits (seen: 1.0 absolute
@@ -219,88 +213,93 @@ def _f32(*ts):
     return [t if (t is None or t.dtype == torch.float32) else t.float() for t in ts]
 
 
-def _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
+def _acc(total, part):
+    return part if total is None else total.add_(part)
+
+
+def _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
+    """Everything the kernel computes per token is LINEAR in the group's y -- out = y, out_z = y silu(z) -- so every
+    group launch gets z (and group 0 gets D) and the outputs are simply added up."""
     io_dtype = u.dtype
-    u, delta, B, C = _f32(u, delta, B, C)
+    u, delta, z_, B, C = _f32(u, delta, z_, B, C)
     batch, dim, seqlen = u.shape
     dstate = A.shape[1]
     T = chunk_len(dstate, u.dtype)
     _check(T == chunk_len(16, u.dtype), "selective_scan: group split needs equal chunk lengths")
     n_chunks = (seqlen + T - 1) // T
     x = torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device, dtype=torch.float32)
-    y = None
+    out = out_z = None
     for g, sl, Ag, Bg, Cg in _groups(A, B, C):
-        out_g, x_g = _fwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, None, delta_bias_, delta_softplus)
-        x[..., 32 * g:32 * g + 32] = x_g
-        y = out_g if y is None else y.add_(out_g)
-    out = y.to(io_dtype)
-    if z_ is None:
-        return [out, x]
-    return [out, x, (y * _silu(z_)).to(io_dtype)]
+        r = _fwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, z_, delta_bias_, delta_softplus,
+                     want_out=want_out or z_ is None)
+        x[..., 32 * g:32 * g + 32] = r[1]
+        if r[0] is not None:
+            out = _acc(out, r[0])
+        if z_ is not None:
+            out_z = _acc(out_z, r[2])
+    out = out.to(io_dtype) if out is not None else None
+    return [out, x] if z_ is None else [out, x, out_z.to(io_dtype)]
 
 
-def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
+def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_softplus, recompute_out_z,
                 dB_out=None, dC_out=None):
+    """Likewise du, ddelta, dz (= dout * y * d silu / dz: linear in y), ddelta_bias and the recomputed out_z are sums
+    over the groups; dA, dB, dC of a group are its own rows (dB / dC written in place through strided views)."""
     io_dtype, bc_dtype = u.dtype, B.dtype
     batch, dim, seqlen = u.shape
     dstate, g_ = A.shape[1], B.shape[1]
-    if z_ is not None and out_ is None:     # the gate's gradient needs y: rebuild it (callers should pass `out`)
-        out_ = _fwd_groups(u, delta, A, B, C, D_, None, delta_bias_, delta_softplus)[0]
     if x_ is None:
         x_ = _fwd_groups(u, delta, A, B, C, D_, None, delta_bias_, delta_softplus)[1]
-    dy = dout.float() if z_ is None else dout.float() * _silu(z_)
-    u, delta, B, C = _f32(u, delta, B, C)
+    u, delta, z_, dout, B, C = _f32(u, delta, z_, dout, B, C)
     f32 = dict(device=u.device, dtype=torch.float32)
     dB = dB_out if dB_out is not None else torch.empty((batch, g_, dstate, seqlen), **f32)
     dC = dC_out if dC_out is not None else torch.empty((batch, g_, dstate, seqlen), **f32)
     dA = torch.empty((dim, dstate), **f32)
-    du = ddelta = dbias = dD = None
+    du = ddelta = dbias = dD = dz = out_z = None
     for g, sl, Ag, Bg, Cg in _groups(A, B, C):
-        r = _bwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, None, delta_bias_, dy,
-                     x_[..., 32 * g:32 * g + 32].contiguous(), None, None, delta_softplus, False,
+        r = _bwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, z_, delta_bias_, dout,
+                     x_[..., 32 * g:32 * g + 32].contiguous(), None, None, delta_softplus, recompute_out_z,
                      dB_out=dB[:, :, sl], dC_out=dC[:, :, sl])
         dA[:, sl] = r[2]
+        du, ddelta = _acc(du, r[0]), _acc(ddelta, r[1])
         if g == 0:
-            du, ddelta, dD = r[0], r[1], r[5]
-            dbias = r[6].clone() if r[6] is not None else None
-        else:
-            du.add_(r[0])
-            ddelta.add_(r[1])
-            if dbias is not None:
-                dbias.add_(r[6])
+            dD = r[5]
+        if r[6] is not None:
+            dbias = _acc(dbias, r[6])
+        if z_ is not None:
+            dz = _acc(dz, r[7])
+            if recompute_out_z:
+                out_z = _acc(out_z, r[8])
     result = [du.to(io_dtype), ddelta.to(io_dtype), dA, dB if dB.dtype == bc_dtype else dB.to(bc_dtype),
               dC if dC.dtype == bc_dtype else dC.to(bc_dtype), dD, dbias]
     if z_ is not None:
-        zf, yf = z_.float(), out_.float()
-        sg = torch.sigmoid(zf)
-        dz = (dout.float() * yf * sg * (1.0 + zf * (1.0 - sg))).to(io_dtype)
         if dz_ is not None:
             dz_.copy_(dz)
             dz = dz_
+        else:
+            dz = dz.to(io_dtype)
         result.append(dz)
         if recompute_out_z:
-            result.append((yf * zf * sg).to(io_dtype))
+            result.append(out_z.to(io_dtype))
     return result
 
 
 def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
     """selective_scan_cuda.fwd (selective_scan.cpp:226-336): ``[out, x]`` or ``[out, x, out_z]``; see ``_fwd_one``.
-    ``want_out=False`` (extension, only with ``z_``): ``None`` in place of the un-gated ``out`` -- except for state
-    groups (``group_split``), where ``out`` is what the backward needs and is always returned."""
+    ``want_out=False`` (extension, only with ``z_``): ``None`` in place of the un-gated ``out``."""
     if A.dim() == 2 and u.dim() == 3 and group_split(A.shape[1], u):
         _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
         _check(want_out or z_ is not None, "selective_scan_fwd: want_out=False needs z")
-        return _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus)
+        return _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out)
     return _fwd_one(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out)
 
 
 def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
         dB_out=None, dC_out=None):
-    """selective_scan_cuda.bwd (selective_scan.cpp:338-492); see ``_bwd_one``.  For state groups ``out_`` (the
-    un-gated forward output) is read when ``z_`` is given."""
+    """selective_scan_cuda.bwd (selective_scan.cpp:338-492); see ``_bwd_one``."""
     if A.dim() == 2 and u.dim() == 3 and group_split(A.shape[1], u):
         _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
-        return _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus,
-                           recompute_out_z, dB_out, dC_out)
+        return _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_softplus, recompute_out_z,
+                           dB_out, dC_out)
     return _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
                     dB_out, dC_out)

@@ -253,10 +253,9 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                                        C_proj_bias)
     if D is not None:
         D = D.contiguous()
-    # the un-gated `out` is not kept: this backward recomputes y from the states it rebuilds (except for state
-    # groups, d_state > 16, where the gate's gradient is applied outside the kernels and needs y: out_keep)
-    out_keep, scan_intermediates, out_z = selective_scan_hip.fwd(conv1d_out, delta, A, B, C, D, z, delta_bias,
-                                                                 delta_softplus, want_out=False)
+    # the un-gated `out` is not kept: this backward recomputes y from the states it rebuilds
+    _, scan_intermediates, out_z = selective_scan_hip.fwd(conv1d_out, delta, A, B, C, D, z, delta_bias,
+                                                          delta_softplus, want_out=False)
     ctx.delta_softplus = delta_softplus
     ctx.checkpoint_lvl = checkpoint_lvl
     ctx.with_out_proj = with_out_proj
@@ -267,7 +266,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dblT, x_proj_weight, delta_proj_weight,
                           out_proj_weight if with_out_proj else None, conv1d_out, delta, A,
                           None if ctx.is_variable_B else B, None if ctx.is_variable_C else C, D, delta_bias,
-                          scan_intermediates, out_keep)
+                          scan_intermediates)
     if not with_out_proj:
         return out_z
     # (B, L, E) = out_z^T W_out^T, computed tokens-last then viewed
@@ -280,7 +279,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
 
 def _inner_backward(ctx, dout):
     (xz, conv1d_weight, conv1d_bias, x_dblT, x_proj_weight, delta_proj_weight, out_proj_weight, conv1d_out, delta,
-     A, B, C, D, delta_bias, scan_intermediates, out_keep) = ctx.saved_tensors
+     A, B, C, D, delta_bias, scan_intermediates) = ctx.saved_tensors
     batch, _, L = xz.shape
     r = delta_proj_weight.shape[1]
     d_state = A.shape[-1]
@@ -309,7 +308,7 @@ def _inner_backward(ctx, dout):
     direct = dx_dblT.dtype == torch.float32
     dB_out = _rows_as_bnl(dx_dblT[r:r + d_state], batch, L) if (ctx.is_variable_B and direct) else None
     dC_out = _rows_as_bnl(dx_dblT[r + d_state:], batch, L) if (ctx.is_variable_C and direct) else None
-    res = selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, out_keep, dz,
+    res = selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz,
                                  ctx.delta_softplus, ctx.with_out_proj, dB_out=dB_out, dC_out=dC_out)
     dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz = res[:8]
     dout_proj_weight = dout_proj_bias = None
