@@ -14,7 +14,7 @@ def per_launch(d, counter):
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            if sys.argv[2] == "bwd" and "fwd" in n.split("(")[0]:
+            if sys.argv[2] == "bwd" and ("scan_fwd_stream" in n or "chunk_apply_fwd" in n):
                 continue   # (the backward script runs one forward to get the chunk states)
             if ("chunk_" in n or "scan_fwd_stream" in n or "reduce_partials" in n or "reduce_slices" in n) and r["Counter_Name"] == counter:
                 k = n.split("(anonymous namespace)::")[1].split("(")[0].split("<")[0]
