@@ -144,8 +144,13 @@ typedef struct {
     float *dweight;     /* [dim, width] contiguous float32, must be ZEROED by the caller (atomics) */
     float *dbias;       /* [dim] float32 zeroed, or NULL */
     int64_t x_bs, x_ds, dout_bs, dout_ds, dx_bs, dx_ds, w_ds, w_ws;
+    float *workspace;   /* mmu_causal_conv1d_bwd_workspace_floats(...) floats: dweight / dbias are then OVERWRITTEN with
+                         * sums formed in a fixed order (bit-reproducible, no zero-fill needed); NULL: dweight / dbias
+                         * must be zeroed by the caller and are accumulated with float atomics, as the reference does
+                         * (causal_conv1d_bwd.cu:256-268) */
 } mmu_conv1d_bwd_params;
 
+size_t mmu_causal_conv1d_bwd_workspace_floats(int batch, int dim, int seqlen);
 int mmu_causal_conv1d_bwd(const mmu_conv1d_bwd_params *p, void *stream);
 
 typedef struct {

@@ -53,6 +53,7 @@ class Conv1dBwdParams(ctypes.Structure):
         [(n, _i32) for n in ("batch", "dim", "seqlen", "width", "dtype", "silu")]
         + [(n, _vp) for n in ("x", "weight", "bias", "dout", "dx", "dweight", "dbias")]
         + [(n, _i64) for n in ("x_bs", "x_ds", "dout_bs", "dout_ds", "dx_bs", "dx_ds", "w_ds", "w_ws")]
+        + [("workspace", _vp)]
     )
 
 
@@ -130,7 +131,7 @@ class CoordsParams(ctypes.Structure):
 EXPORTS = (
     "mmu_abi_version", "mmu_last_error", "mmu_scan_chunk_len", "mmu_scan_bwd_workspace_bytes",
     "mmu_selective_scan_fwd", "mmu_selective_scan_bwd", "mmu_causal_conv1d_fwd", "mmu_causal_conv1d_bwd",
-    "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
+    "mmu_causal_conv1d_bwd_workspace_floats", "mmu_causal_conv1d_update", "mmu_morph_sample_fwd", "mmu_morph_sample_bwd", "mmu_zigzag_inproj_fwd",
     "mmu_zigzag_inproj_bwd", "mmu_coords_outproj_fwd", "mmu_coords_outproj_bwd", "mmu_bilinear_resize_fwd",
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
     "mmu_conv3x3_small_wgrad_workspace_floats",
@@ -178,6 +179,8 @@ def lib():
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
+    L.mmu_causal_conv1d_bwd_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_causal_conv1d_bwd_workspace_floats.argtypes = [ctypes.c_int] * 3
     L.mmu_conv3x3_small_fwd_splits.restype = ctypes.c_int
     L.mmu_conv3x3_small_fwd_splits.argtypes = [ctypes.c_int] * 4
     L.mmu_conv3x3_small_wgrad_workspace_floats.restype = ctypes.c_size_t

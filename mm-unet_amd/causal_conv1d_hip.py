@@ -68,8 +68,12 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
         dx = dx_
     else:
         dx = torch.empty_like(x)
-    dweight = torch.zeros((dim, width), device=x.device, dtype=torch.float32)
-    dbias = torch.zeros((dim,), device=x.device, dtype=torch.float32) if bias_ is not None else None
+    # weight-gradient sums through a workspace of per-block partials added in a fixed order: no float atomics,
+    # bit-reproducible, nothing to zero (the reference: atomicAdd into zeroed dweight / dbias)
+    dweight = torch.empty((dim, width), device=x.device, dtype=torch.float32)
+    dbias = torch.empty((dim,), device=x.device, dtype=torch.float32) if bias_ is not None else None
+    ws = torch.empty(_lib.lib().mmu_causal_conv1d_bwd_workspace_floats(batch, dim, seqlen), device=x.device,
+                     dtype=torch.float32)
     p = _lib.Conv1dBwdParams()
     p.batch, p.dim, p.seqlen, p.width = batch, dim, seqlen, width
     p.dtype, p.silu = _lib.dtype_code(x), int(bool(silu_activation))
@@ -79,6 +83,7 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
     p.dout_bs, p.dout_ds = dout.stride(0), dout.stride(1)
     p.dx_bs, p.dx_ds = dx.stride(0), dx.stride(1)
     p.w_ds, p.w_ws = w32.stride(0), w32.stride(1)
+    p.workspace = ws.data_ptr()
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().mmu_causal_conv1d_bwd(p, _lib.stream_of(x)))
     return [dx, dweight.to(weight.dtype), dbias.to(bias_.dtype) if bias_ is not None else None]

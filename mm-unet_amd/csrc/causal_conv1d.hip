@@ -26,7 +26,7 @@ struct ConvArgs {
     const void *x, *dout;
     const float *weight, *bias;
     void *out, *dx;
-    float *dweight, *dbias;
+    float *dweight, *dbias, *ws;   // ws: [batch][dim][gridDim.x][5] partials of (dW taps, db), or NULL -> float atomics
     long x_bs, x_ds, out_bs, out_ds, dout_bs, dout_ds, dx_bs, dx_ds, w_ds, w_ws;
 };
 
@@ -69,19 +69,23 @@ __global__ __launch_bounds__(CTHREADS) void conv1d_fwd_kernel(ConvArgs p) {
     store_k<io_t, CK>((io_t *)p.out + (long)b * p.out_bs + (long)d * p.out_ds + t, L - t, p.vec, o);
 }
 
+// A block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of one (batch, channel) row and keeps the five
+// weight-gradient sums (four taps + bias) in registers across its tiles: one block reduction per block, not per
+// 1,024 tokens.  With a workspace the block sums are plain stores and conv1d_wgrad_reduce_kernel adds them in a
+// fixed order (bit-reproducible, nothing to zero-fill); without one they are float atomics, as in the reference
+// (causal_conv1d_bwd.cu:256-268).
 template <typename io_t>
 __global__ __launch_bounds__(CTHREADS) void conv1d_bwd_kernel(ConvArgs p) {
     __shared__ float red[CTHREADS / 64][5];
     const int d = blockIdx.y, b = blockIdx.z;
-    const int t = blockIdx.x * CTILE + threadIdx.x * CK;
     const int L = p.seqlen;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float wr[4], bv;
     load_weights(p, d, wr, bv);
     float dwr[4] = {0.f, 0.f, 0.f, 0.f}, dbv = 0.f;
-    if (t < L) {
-        const io_t *xr = (const io_t *)p.x + (long)b * p.x_bs + (long)d * p.x_ds;
-        const io_t *gr = (const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds;
+    const io_t *xr = (const io_t *)p.x + (long)b * p.x_bs + (long)d * p.x_ds;
+    const io_t *gr = (const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds;
+    for (int t = blockIdx.x * CTILE + threadIdx.x * CK; t < L; t += gridDim.x * CTILE) {
         float cur[CK], prev[CK], next[CK], g0[CK], g1[CK];
         load_k<io_t, CK>(xr + t, L - t, p.vec, cur);
         load_k<io_t, CK>(xr + t + CK, L - t - CK, p.vec, next);
@@ -119,26 +123,47 @@ __global__ __launch_bounds__(CTHREADS) void conv1d_bwd_kernel(ConvArgs p) {
         }
         store_k<io_t, CK>((io_t *)p.dx + (long)b * p.dx_bs + (long)d * p.dx_ds + t, L - t, p.vec, dxv);
     }
-    // block reduction of the 5 weight-gradient partials, one atomic per block and tap
-    float v[5] = {dwr[0], dwr[1], dwr[2], dwr[3], dbv};
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const float s = wave_scan_add(v[k]);
-        if (lane == 63) red[w][k] = s;
-    }
+    // block reduction of the 5 weight-gradient partials
+    const float v4 = wave_sum4(dwr[0], dwr[1], dwr[2], dwr[3]);   // lanes 12..15: totals of taps 0..3
+    const float vb = wave_sum(dbv);
+    if (lane >= 12 && lane < 16) red[w][lane - 12] = v4;
+    if (lane == 0) red[w][4] = vb;
     __syncthreads();
     if (threadIdx.x < 5) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < CTHREADS / 64; ++i) s += red[i][threadIdx.x];
         const int m = threadIdx.x;
-        if (m < 4) {
+        if (p.ws) {
+            p.ws[((((long)b * p.dim + d) * gridDim.x) + blockIdx.x) * 5 + m] = s;
+        } else if (m < 4) {
             const int k = m - (4 - p.width);
             if (k >= 0) atomicAdd(&p.dweight[(long)d * p.width + k], s);
         } else if (p.dbias) {
             atomicAdd(&p.dbias[d], s);
         }
     }
+}
+
+// dW[d][k], db[d] = sum over (batch, block) of the partials, in a fixed order.  grid dim, block 64.
+__global__ __launch_bounds__(64) void conv1d_wgrad_reduce_kernel(const float *__restrict__ ws, int batch, int dim, int nblk,
+                                                                 int width, float *dweight, float *dbias) {
+    const int d = blockIdx.x, lane = threadIdx.x;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n = batch * nblk;           // partial rows of channel d: (b, block) pairs, strided over the lanes
+    for (int i = lane; i < n; i += 64) {
+        const int b = i / nblk, k = i - b * nblk;
+        const float *r = ws + ((((long)b * dim + d) * nblk) + k) * 5;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc[m] += r[m];
+    }
+    const float v4 = wave_sum4(acc[0], acc[1], acc[2], acc[3]);
+    const float vb = wave_sum(acc[4]);
+    if (lane >= 12 && lane < 16) {
+        const int k = (lane - 12) - (4 - width);
+        if (k >= 0) dweight[(long)d * width + k] = v4;
+    }
+    if (lane == 0 && dbias) dbias[d] = vb;
 }
 
 struct UpdArgs {
@@ -167,6 +192,14 @@ __global__ __launch_bounds__(64) void conv1d_update_kernel(UpdArgs p) {
 }
 
 inline bool al(const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; }
+// blocks per (batch, channel) row of the backward: enough blocks overall to fill the chip several times over,
+// few enough that a block keeps its weight-gradient sums in registers over many tiles
+inline int conv1d_bwd_blocks(int batch, int dim, int seqlen) {
+    const long tiles = ((long)seqlen + CTILE - 1) / CTILE, rows = (long)batch * dim;
+    long per_row = (4096 + rows - 1) / rows;
+    if (per_row < 1) per_row = 1;
+    return (int)(per_row < tiles ? per_row : tiles);
+}
 inline bool ml(long v) { return (v % CK) == 0; }
 
 }  // namespace
@@ -198,6 +231,10 @@ extern "C" int mmu_causal_conv1d_fwd(const mmu_conv1d_fwd_params *p, void *strea
     return 0;
 }
 
+extern "C" size_t mmu_causal_conv1d_bwd_workspace_floats(int batch, int dim, int seqlen) {
+    return (size_t)batch * dim * conv1d_bwd_blocks(batch, dim, seqlen) * 5;
+}
+
 extern "C" int mmu_causal_conv1d_bwd(const mmu_conv1d_bwd_params *p, void *stream) {
     CONV_CHECKS(p, "causal_conv1d_bwd");
     MMU_CHECK(p->seqlen > 0 && p->x && p->weight && p->dout && p->dx && p->dweight,
@@ -205,18 +242,23 @@ extern "C" int mmu_causal_conv1d_bwd(const mmu_conv1d_bwd_params *p, void *strea
     ConvArgs a = {};
     a.batch = p->batch; a.dim = p->dim; a.seqlen = p->seqlen; a.width = p->width; a.silu = p->silu;
     a.x = p->x; a.weight = p->weight; a.bias = p->bias; a.dout = p->dout; a.dx = p->dx;
-    a.dweight = p->dweight; a.dbias = p->dbias;
+    a.dweight = p->dweight; a.dbias = p->dbias; a.ws = p->workspace;
     a.x_bs = p->x_bs; a.x_ds = p->x_ds; a.dout_bs = p->dout_bs; a.dout_ds = p->dout_ds;
     a.dx_bs = p->dx_bs; a.dx_ds = p->dx_ds; a.w_ds = p->w_ds; a.w_ws = p->w_ws;
     const size_t g = (p->dtype == MMU_DTYPE_F32 ? 4 : 2) * CK;
     a.vec = al(p->x, g) && al(p->dout, g) && al(p->dx, g) && ml(p->x_bs) && ml(p->x_ds) && ml(p->dout_bs) &&
             ml(p->dout_ds) && ml(p->dx_bs) && ml(p->dx_ds);
-    dim3 grid((p->seqlen + CTILE - 1) / CTILE, p->dim, p->batch);
+    dim3 grid(conv1d_bwd_blocks(p->batch, p->dim, p->seqlen), p->dim, p->batch);
     if (p->dtype == MMU_DTYPE_F32)
         conv1d_bwd_kernel<float><<<grid, CTHREADS, 0, (hipStream_t)stream>>>(a);
     else
         conv1d_bwd_kernel<bf16_t><<<grid, CTHREADS, 0, (hipStream_t)stream>>>(a);
     MMU_HIP_LAUNCH_CHECK("causal_conv1d_bwd");
+    if (p->workspace) {
+        conv1d_wgrad_reduce_kernel<<<p->dim, 64, 0, (hipStream_t)stream>>>(p->workspace, p->batch, p->dim, (int)grid.x,
+                                                                         p->width, p->dweight, p->dbias);
+        MMU_HIP_LAUNCH_CHECK("causal_conv1d_bwd(reduce)");
+    }
     return 0;
 }
 

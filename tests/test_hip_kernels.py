@@ -535,6 +535,43 @@ def test_conv1d_vs_oracle_strided(shape):
     assert float(dxz[:, d:].abs().max()) == 0.0, "conv1d bwd wrote outside its dx view"
 
 
+def test_conv1d_bwd_weight_gradient_is_bit_reproducible_and_matches_atomic_path():
+    """dW / db are per-block partial sums added in a fixed order (workspace path): two calls give identical bits, at
+    a size where a block walks several tiles and a channel has several blocks.  The C-ABI's NULL-workspace path
+    (float atomics into zeroed buffers, the reference's scheme, causal_conv1d_bwd.cu:256-268) gives the same sums
+    to rounding."""
+    from mm_unet_amd import _lib
+    from mm_unet_amd import causal_conv1d_hip as cc
+    gen = torch.Generator().manual_seed(11)
+    for (b, d, l, width) in [(2, 24, 65536 + 37, 4), (1, 8, 5000, 3), (8, 768, 1024, 4)]:
+        x = torch.randn(b, d, l, generator=gen).to(DEV)
+        w = torch.randn(d, width, generator=gen).to(DEV)
+        bias = torch.randn(d, generator=gen).to(DEV)
+        dout = torch.randn(b, d, l, generator=gen).to(DEV)
+        dx1, dw1, db1 = cc.causal_conv1d_bwd(x, w, bias, dout, None, True)
+        dx2, dw2, db2 = cc.causal_conv1d_bwd(x, w, bias, dout, None, True)
+        assert torch.equal(dw1, dw2) and torch.equal(db1, db2) and torch.equal(dx1, dx2)
+        # the atomics path of the ABI
+        dwa = torch.zeros(d, width, device=DEV)
+        dba = torch.zeros(d, device=DEV)
+        dxa = torch.empty_like(x)
+        p = _lib.Conv1dBwdParams()
+        p.batch, p.dim, p.seqlen, p.width = b, d, l, width
+        p.dtype, p.silu = _lib.dtype_code(x), 1
+        p.x, p.weight, p.bias = x.data_ptr(), w.data_ptr(), bias.data_ptr()
+        p.dout, p.dx, p.dweight, p.dbias = dout.data_ptr(), dxa.data_ptr(), dwa.data_ptr(), dba.data_ptr()
+        p.x_bs, p.x_ds = x.stride(0), x.stride(1)
+        p.dout_bs, p.dout_ds = dout.stride(0), dout.stride(1)
+        p.dx_bs, p.dx_ds = dxa.stride(0), dxa.stride(1)
+        p.w_ds, p.w_ws = w.stride(0), w.stride(1)
+        p.workspace = None
+        _lib.check(_lib.lib().mmu_causal_conv1d_bwd(p, _lib.stream_of(x)))
+        assert torch.equal(dxa, dx1)
+        scale = float(dw1.abs().max())
+        close(dwa, dw1, 1e-4, 1e-4 * scale, "dweight atomics vs ordered")
+        close(dba, db1, 1e-4, 1e-4 * float(db1.abs().max()), "dbias atomics vs ordered")
+
+
 def test_conv1d_update_matches_reference_semantics():
     """causal_conv1d_update_ref (causal_conv1d_interface.py:83-104): roll, append, dot, silu."""
     from mm_unet_amd import causal_conv1d_hip as cc
