@@ -397,5 +397,29 @@ __device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v
     return r;
 }
 
+// wave_sum4 with the four rows joined by the gfx950 row-swap instructions instead of two ds_bpermute round trips
+// (v_permlane16_swap: odd rows of the first operand <-> even rows of the second; v_permlane32_swap: upper half of
+// the first <-> lower half of the second; with both operands = r the sum of the two results is r + its partner
+// row / half in every lane).  Pure VALU: no LDS latency in the dependency chain.
+__device__ __forceinline__ float wave_sum4_swap(float v0, float v1, float v2, float v3) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float x01 = b0 ? v1 : v0, y01 = b0 ? v0 : v1;
+    const float x23 = b0 ? v3 : v2, y23 = b0 ? v2 : v3;
+    const float r01 = x01 + dpp_mov<0xB1, 0xf>(0.f, y01);
+    const float r23 = x23 + dpp_mov<0xB1, 0xf>(0.f, y23);
+    const float x = b1 ? r23 : r01, y = b1 ? r01 : r23;
+    float r = x + dpp_mov<0x4E, 0xf>(0.f, y);
+    r += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, r);
+    r += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, r);
+    float a = r, b = r;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    r = a + b;
+    a = r;
+    b = r;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // sum over the 64 lanes, result valid in every lane
 __device__ __forceinline__ float wave_sum(float v) { return wave_bcast_last(wave_scan_add(v)); }

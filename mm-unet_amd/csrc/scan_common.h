@@ -94,3 +94,9 @@ int set_lds(F kernel, size_t bytes) {
 // streaming forward (selective_scan_stream.hip): returns 1 if it took the call, 0 if the shape is not its,
 // < 0 on error
 int mmu_scan_fwd_stream(const ScanArgs &a, int dtype, hipStream_t st);
+
+// backward apply on 512-token tiles, one state pair per wave (selective_scan_bwd_w8.hip): same return convention;
+// its dA / dD / dbias partials have their own layout and reduction
+int mmu_scan_bwd_apply_w8(const ScanArgs &a, int dtype, hipStream_t st);
+int mmu_scan_bwd_reduce_w8(const float *part8, float *part2, int batch, int dim, int seqlen, float *dA, float *dD,
+                           float *dbias, hipStream_t st);

@@ -1607,7 +1607,7 @@ int launch_fwd(const ScanArgs &a, hipStream_t st) {
 }
 
 template <typename io_t, int K>
-int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st) {
+int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st, bool *w8_layout) {
     const int N = a.dstate, T = 64 * K;
     const int dpg = a.dim / a.ngroups;
     dim3 grid(a.n_chunks, a.batch, a.ngroups);
@@ -1636,8 +1636,17 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st) {
                        mult(a.dC_gs, 4) && mult(a.dC_ns, 4);
     const bool ptrs16 = al16(a.u) && al16(a.delta) && al16(a.dout) && al16(a.z) && al16(a.du) && al16(a.ddelta) &&
                         al16(a.dz) && al16(a.out_z) && al16(a.B) && al16(a.C) && al16(a.dB) && al16(a.dC);
-    if (K == 2 && N == 16 && a.seqlen % 256 == 0 && rows4 && ptrs16 && span * 4 < (1L << 31) &&
-        (long)a.dim * a.n_chunks * 2 * N * 4 < (1L << 31) && (long)a.n_chunks * a.dim * (N + 2) * 4 < (1L << 31)) {
+    const bool fast = K == 2 && N == 16 && a.seqlen % 256 == 0 && rows4 && ptrs16 && span * 4 < (1L << 31) &&
+                      (long)a.dim * a.n_chunks * 2 * N * 4 < (1L << 31) && (long)a.n_chunks * a.dim * (N + 2) * 4 < (1L << 31);
+    if (fast) {   // 512-token tiles, one state pair per wave (selective_scan_bwd_w8.hip), when the launch fills the chip
+        const int r = mmu_scan_bwd_apply_w8(a, sizeof(io_t) == 4 ? MMU_DTYPE_F32 : MMU_DTYPE_BF16, st);
+        if (r < 0) return r;
+        if (r == 1) {
+            *w8_layout = true;
+            return 0;
+        }
+    }
+    if (fast) {
         // fast form: full aligned 256-token tiles, packed state pairs, buffer addressing
         const size_t lds = sizeof(float) * (4 * 512 * 4 + 4 * 32 + 2 * 4 * 3 * 64 * 4);
         dim3 gridp(a.seqlen / 256, a.batch, a.ngroups);
@@ -1772,18 +1781,24 @@ extern "C" int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream
                mult(p->B_ns, K) && mult(p->C_bs, K) && mult(p->C_gs, K) && mult(p->C_ns, K);
     hipStream_t st = (hipStream_t)stream;
     const bool have_x = p->x != nullptr;
+    bool w8_layout = false;
     int r;
     if (p->dtype == MMU_DTYPE_F32) {
-        r = K == 4 ? launch_bwd<float, 4>(a, have_x, p->workspace, st)
-                   : (K == 2 ? launch_bwd<float, 2>(a, have_x, p->workspace, st)
-                             : launch_bwd<float, 1>(a, have_x, p->workspace, st));
+        r = K == 4 ? launch_bwd<float, 4>(a, have_x, p->workspace, st, &w8_layout)
+                   : (K == 2 ? launch_bwd<float, 2>(a, have_x, p->workspace, st, &w8_layout)
+                             : launch_bwd<float, 1>(a, have_x, p->workspace, st, &w8_layout));
     } else {
-        r = K == 4 ? launch_bwd<bf16_t, 4>(a, have_x, p->workspace, st)
-                   : (K == 2 ? launch_bwd<bf16_t, 2>(a, have_x, p->workspace, st)
-                             : launch_bwd<bf16_t, 1>(a, have_x, p->workspace, st));
+        r = K == 4 ? launch_bwd<bf16_t, 4>(a, have_x, p->workspace, st, &w8_layout)
+                   : (K == 2 ? launch_bwd<bf16_t, 2>(a, have_x, p->workspace, st, &w8_layout)
+                             : launch_bwd<bf16_t, 1>(a, have_x, p->workspace, st, &w8_layout));
     }
     if (r) return r;
     const size_t xs = (size_t)p->batch * p->dim * p->n_chunks * 2 * p->dstate;
+    if (w8_layout) {
+        const size_t parts = (size_t)p->batch * p->n_chunks * p->dim * (p->dstate + 2);
+        return mmu_scan_bwd_reduce_w8(p->workspace + xs, p->workspace + xs + parts + (have_x ? 0 : xs), p->batch, p->dim,
+                                      p->seqlen, p->dA, p->dD, p->ddelta_bias, st);
+    }
     {
         const int BC = p->batch * p->n_chunks;
         const int n_slices = (BC + 511) / 512;

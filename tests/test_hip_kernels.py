@@ -252,6 +252,84 @@ def test_scan_fwd_stream_vs_oracle_and_chunk_path(case):
         close(r[4], og["dC"], RTOL, ATOL * max(1, d // 32), "dC (streamed states)")
 
 
+@pytest.mark.parametrize("case", [
+    # (batch, dim, L, groups, dtype, has_z, recompute_out_z, D and bias given)
+    (2, 8, 1024, 1, torch.float32, True, True, True),     # two tiles: carry-in from the left / right neighbour
+    (1, 6, 512, 1, torch.float32, True, False, True),     # one tile: no carries at all
+    (2, 12, 1536, 2, torch.float32, True, True, True),    # two groups, three tiles (a middle tile with both carries)
+    (2, 4, 1024, 1, torch.float32, False, False, False),  # no z, no D, no bias
+    (1, 1, 2048, 1, torch.float32, True, False, True),    # a single channel: the pipeline prologue is the whole loop
+    (2, 8, 1024, 1, torch.bfloat16, True, True, True),
+])
+def test_scan_bwd_w8_vs_oracle_and_p4(case):
+    """chunk_apply_bwd_w8_kernel (selective_scan_bwd_w8.hip: 512-token tiles, one state pair per wave; forced with
+    MMU_SCAN_BWD_W8=1, by default taken once the launch has a tile per CU) against the CPU oracle and against the
+    256-token-tile kernel it replaces (MMU_SCAN_BWD_W8=0) on the same inputs and chunk states."""
+    import oracle
+    from mm_unet_amd import selective_scan_hip as ss
+    b, d, l, g, dt, has_z, want_oz, has_db = case
+    n = 16
+    gen = torch.Generator().manual_seed(31)
+    c = _rand_case(b, d, l, n, seed=31)
+    c["B"] = torch.randn(b, g, n, l, generator=gen)
+    c["C"] = torch.randn(b, g, n, l, generator=gen)
+    if dt == torch.bfloat16:
+        c = {k: (v.bfloat16().float() if k in ("u", "delta", "z", "B", "C", "dout") else v) for k, v in c.items()}
+
+    def put(t):
+        return t.to(dt).permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)
+
+    u, delta, dout = put(c["u"]), put(c["delta"]), put(c["dout"])
+    z = put(c["z"]) if has_z else None
+    A = c["A"].to(DEV)
+    D = c["D"].to(DEV) if has_db else None
+    bias = c["delta_bias"].to(DEV) if has_db else None
+    B, C = c["B"].to(dt).to(DEV), c["C"].to(dt).to(DEV)
+    res = ss.fwd(u, delta, A, B, C, D, z, bias, True)
+    got = {}
+    for mode in ("1", "0"):
+        os.environ["MMU_SCAN_BWD_W8"] = mode
+        try:
+            got[mode] = ss.bwd(u, delta, A, B, C, D, z, bias, dout, res[1], None, None, True, want_oz)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["MMU_SCAN_BWD_W8"]
+    dpg = d // g
+    og = {}
+    for gi in range(g):
+        sl = slice(gi * dpg, (gi + 1) * dpg)
+        o = oracle.selective_scan_bwd(c["u"][:, sl], c["delta"][:, sl], c["A"][sl], c["B"][:, gi:gi + 1],
+                                      c["C"][:, gi:gi + 1], c["D"][sl] if has_db else None,
+                                      c["z"][:, sl] if has_z else None, c["delta_bias"][sl] if has_db else None,
+                                      c["dout"][:, sl], True)
+        for k, v in o.items():
+            if v is not None:
+                og.setdefault(k, []).append(v)
+    cat = {k: torch.cat(v, dim=1 if k in ("du", "ddelta", "dz", "dB", "dC") else 0) for k, v in og.items()}
+    f32 = dt == torch.float32
+    rt, at = (RTOL, ATOL) if f32 else (3e-2, 6e-2)
+    names = ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z"]
+    w8, p4 = got["1"], got["0"]
+    close(w8[0], cat["du"], rt * 2, at * 2, "du vs oracle")
+    close(w8[1], cat["ddelta"], rt * 5, at * 10, "ddelta vs oracle")
+    close(w8[2], cat["dA"], RTOLW if f32 else 3e-2, (ATOLW * 5 if f32 else 0.5) * max(1, l // 1024), "dA vs oracle")
+    close(w8[3], cat["dB"], rt, at, "dB vs oracle")
+    close(w8[4], cat["dC"], rt, at, "dC vs oracle")
+    if has_db:
+        close(w8[5], cat["dD"], RTOLW if f32 else 3e-2, (ATOLW if f32 else 0.5) * max(1, l // 1024), "dD vs oracle")
+        close(w8[6], cat["ddelta_bias"], RTOLW if f32 else 3e-2, (ATOLW if f32 else 0.5) * max(1, l // 1024), "dbias vs oracle")
+    if has_z:
+        close(w8[7], cat["dz"], RTOLW if f32 else 3e-2, ATOLW if f32 else 6e-2, "dz vs oracle")
+    # the two kernels share every input and all the math: fp32 summation order is the only difference
+    assert len(w8) == len(p4)
+    for i, nm in enumerate(names[:len(w8)]):
+        if w8[i] is None or p4[i] is None:
+            assert w8[i] is None and p4[i] is None, nm
+            continue
+        scale = float(p4[i].float().abs().max()) + 1e-6
+        close(w8[i], p4[i], 0.0, (2e-5 if f32 else 2e-2) * scale, f"{nm} vs the 256-token-tile kernel")
+
+
 def test_scan_state_groups_dstate64_vs_golden_and_generic(monkeypatch):
     """dstate = 64 (BASELINE config 5) as four dstate-16 launches on strided views (selective_scan_hip._fwd_groups /
     _bwd_groups) against the reference fixture ``scan_c5_D8_L512_N64`` and against the single generic-dstate launch on a
