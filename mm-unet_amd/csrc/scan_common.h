@@ -20,6 +20,10 @@ struct ScanArgs {
     long dout_bs, dout_ds, du_bs, du_ds, ddelta_bs, ddelta_ds, dz_bs, dz_ds;
     long A_ds, A_ns, B_bs, B_gs, B_ns, C_bs, C_gs, C_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
+    // backward apply with the channels of a group cut into d_splits ranges (grid.z = ngroups * d_splits): range s
+    // writes its dB / dC sums at dB + s * dBC_ss, dC + s * dBC_ss; sum_splits_kernel adds the ranges afterwards
+    int d_splits;
+    long dBC_ss;
 };
 
 namespace {

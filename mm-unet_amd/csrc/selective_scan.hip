@@ -1138,7 +1138,8 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
     constexpr int N = 16, TT = 256;
     constexpr unsigned ES = sizeof(io_t);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tile = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int g = blockIdx.z / p.d_splits, sp = blockIdx.z - g * p.d_splits;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n0 = w * 4;
     const int t0 = tile * TT;
@@ -1166,8 +1167,8 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
         }
     }
 
-    const int dpg = p.dim / p.ngroups;
-    const int dbeg = g * dpg, dend = dbeg + dpg;
+    const int dpg = p.dim / p.ngroups, cps = (dpg + p.d_splits - 1) / p.d_splits;   // host: no range is empty
+    const int dbeg = g * dpg + sp * cps, dend = min(dbeg + cps, (g + 1) * dpg);
     const rsrc_t r_delta = make_rsrc((const io_t *)p.delta + (long)b * p.delta_bs + t0);
     const rsrc_t r_u = make_rsrc((const io_t *)p.u + (long)b * p.u_bs + t0);
     const rsrc_t r_go = make_rsrc((const io_t *)p.dout + (long)b * p.dout_bs + t0);
@@ -1430,8 +1431,8 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
         }
     }
     // this wave's 4 rows of dB / dC
-    float *dBg = p.dB + (long)b * p.dB_bs + (long)g * p.dB_gs + t0 + lane * 4;
-    float *dCg = p.dC + (long)b * p.dC_bs + (long)g * p.dC_gs + t0 + lane * 4;
+    float *dBg = p.dB + sp * p.dBC_ss + (long)b * p.dB_bs + (long)g * p.dB_gs + t0 + lane * 4;
+    float *dCg = p.dC + sp * p.dBC_ss + (long)b * p.dC_bs + (long)g * p.dC_gs + t0 + lane * 4;
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
         const int n = n0 + 2 * pi;
@@ -1606,6 +1607,44 @@ int launch_fwd(const ScanArgs &a, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Channel-range splits of the fast backward apply kernels.  A launch with few tiles (L = 4,096, batch 8: 128
+// workgroups of the 256-token kernel on 256 CUs) leaves every workgroup a serial walk over all channels of its
+// group; cutting the channels into S ranges (grid.z = S) gives S times the workgroups.  Each range sums dB / dC
+// over its own channels into its own [B][N][L] slab of the workspace; sum_splits_kernel adds the slabs in a fixed
+// order.  Only for ngroups == 1 (MM-UNet's case: the workspace query does not know the group count).
+// ---------------------------------------------------------------------------
+inline int bwd_d_splits(int batch, int dim, int seqlen, int dstate, int ngroups) {
+    if (dstate != 16 || ngroups != 1 || seqlen % 256 != 0 || dim < 16) return 1;
+    const long wgs = (long)(seqlen / 256) * batch;   // workgroups of the 256-token kernel
+    const long want = 2L * mmu_cu_count();
+    if (wgs >= want) return 1;
+    long S = (want + wgs - 1) / wgs;
+    if (S > 8) S = 8;
+    if (S > dim / 8) S = dim / 8;                    // at least 8 channels per range
+    if (S < 2) return 1;
+    const int cps = (int)((dim + S - 1) / S);
+    return (dim + cps - 1) / cps;                    // no empty range
+}
+
+// out[b][n][t] (strides bs, ns) = sum over s of part[s][b][n][t];  L % 4 == 0.  grid ceil(B*N*L/4 / 256), block 256
+__global__ __launch_bounds__(256) void sum_splits_kernel(const float *__restrict__ part, int S, long ss, int B, int N, int L,
+                                                         float *__restrict__ out, long bs, long ns) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total4 = (long)B * N * L / 4;
+    if (i4 >= total4) return;
+    const long i = i4 * 4;
+    const int t = (int)(i % L);
+    const long r = i / L;
+    const int n = (int)(r % N), b = (int)(r / N);
+    float4 acc = *reinterpret_cast<const float4 *>(part + i);
+    for (int s1 = 1; s1 < S; ++s1) {
+        const float4 v = *reinterpret_cast<const float4 *>(part + s1 * ss + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + b * bs + n * ns + t) = acc;
+}
+
 template <typename io_t, int K>
 int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st, bool *w8_layout) {
     const int N = a.dstate, T = 64 * K;
@@ -1638,23 +1677,49 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st, bool *w8_layo
                         al16(a.dz) && al16(a.out_z) && al16(a.B) && al16(a.C) && al16(a.dB) && al16(a.dC);
     const bool fast = K == 2 && N == 16 && a.seqlen % 256 == 0 && rows4 && ptrs16 && span * 4 < (1L << 31) &&
                       (long)a.dim * a.n_chunks * 2 * N * 4 < (1L << 31) && (long)a.n_chunks * a.dim * (N + 2) * 4 < (1L << 31);
+    // few tiles: the channels are cut into ranges, each with its own dB / dC slab behind the other workspace regions
+    float *const dB_out = a.dB, *const dC_out = a.dC;
+    const long dB_bs = a.dB_bs, dB_ns = a.dB_ns, dC_bs = a.dC_bs, dC_ns = a.dC_ns;
+    const int S = fast ? bwd_d_splits(a.batch, a.dim, a.seqlen, N, a.ngroups) : 1;
+    if (S > 1) {
+        const size_t parts = (size_t)a.batch * a.n_chunks * a.dim * (N + 2);
+        const size_t slices = ((size_t)a.batch * a.n_chunks + 511) / 512 * a.dim * (N + 2);
+        float *slab = ws + xs + parts + (have_x ? 0 : xs) + slices;
+        a.d_splits = S;
+        a.dBC_ss = (long)a.batch * N * a.seqlen;
+        a.dB = slab;
+        a.dC = slab + (size_t)S * a.dBC_ss;
+        a.dB_bs = a.dC_bs = (long)N * a.seqlen;
+        a.dB_gs = a.dC_gs = 0;
+        a.dB_ns = a.dC_ns = a.seqlen;
+    }
+    const auto join_splits = [&]() -> int {
+        if (S == 1) return 0;
+        const long total4 = (long)a.batch * N * a.seqlen / 4;
+        const unsigned blocks = (unsigned)((total4 + 255) / 256);
+        sum_splits_kernel<<<blocks, 256, 0, st>>>(a.dB, S, a.dBC_ss, a.batch, N, a.seqlen, dB_out, dB_bs, dB_ns);
+        sum_splits_kernel<<<blocks, 256, 0, st>>>(a.dC, S, a.dBC_ss, a.batch, N, a.seqlen, dC_out, dC_bs, dC_ns);
+        MMU_HIP_LAUNCH_CHECK("sum_splits");
+        return 0;
+    };
     if (fast) {   // 512-token tiles, one state pair per wave (selective_scan_bwd_w8.hip), when the launch fills the chip
         const int r = mmu_scan_bwd_apply_w8(a, sizeof(io_t) == 4 ? MMU_DTYPE_F32 : MMU_DTYPE_BF16, st);
         if (r < 0) return r;
         if (r == 1) {
             *w8_layout = true;
-            return 0;
+            return join_splits();
         }
     }
     if (fast) {
         // fast form: full aligned 256-token tiles, packed state pairs, buffer addressing
         const size_t lds = sizeof(float) * (4 * 512 * 4 + 4 * 32 + 2 * 4 * 3 * 64 * 4);
-        dim3 gridp(a.seqlen / 256, a.batch, a.ngroups);
+        dim3 gridp(a.seqlen / 256, a.batch, a.ngroups * a.d_splits);
         MMU_BOOL(a.z != nullptr, HAS_Z, {
             if (int r = set_lds(chunk_apply_bwd_p4_kernel<io_t, HAS_Z>, lds)) return r;
             chunk_apply_bwd_p4_kernel<io_t, HAS_Z><<<gridp, 256, lds, st>>>(a);
         });
         MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd_p4");
+        if (int r = join_splits()) return r;
     } else if (K == 2 && N == 16) {
         size_t lds = sizeof(float) * ((size_t)2 * N * T + (size_t)2 * 4 * 3 * 2 * 64);
         MMU_BOOL(full, FULL, {
@@ -1689,7 +1754,9 @@ extern "C" size_t mmu_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, i
     const size_t xs = (size_t)batch * dim * nc * 2 * dstate;
     const size_t parts = (size_t)batch * nc * dim * (dstate + 2);
     const size_t slices = ((size_t)batch * nc + 511) / 512 * dim * (dstate + 2);
-    return sizeof(float) * (xs + parts + (have_x ? 0 : xs) + slices);
+    const int S = bwd_d_splits(batch, dim, seqlen, dstate, 1);   // dB / dC slabs of the channel ranges (ngroups == 1)
+    const size_t slabs = S > 1 ? (size_t)2 * S * batch * dstate * seqlen : 0;
+    return sizeof(float) * (xs + parts + (have_x ? 0 : xs) + slices + slabs);
 }
 
 #define SCAN_COMMON_CHECKS(p)                                                                                       \
@@ -1715,6 +1782,7 @@ extern "C" int mmu_selective_scan_fwd(const mmu_scan_fwd_params *p, void *stream
     const int K = items_per_lane(p->dstate);
     const size_t es = p->dtype == MMU_DTYPE_F32 ? 4 : 2;
     ScanArgs a = {};
+    a.d_splits = 1;
     a.batch = p->batch; a.dim = p->dim; a.seqlen = p->seqlen; a.dstate = p->dstate; a.ngroups = p->ngroups;
     a.n_chunks = p->n_chunks; a.softplus = p->delta_softplus;
     a.u = p->u; a.delta = p->delta; a.z = p->z; a.B = p->B; a.C = p->C; a.A = p->A; a.D = p->D;
@@ -1754,6 +1822,7 @@ extern "C" int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream
     const int K = items_per_lane(p->dstate);
     const size_t es = p->dtype == MMU_DTYPE_F32 ? 4 : 2;
     ScanArgs a = {};
+    a.d_splits = 1;
     a.batch = p->batch; a.dim = p->dim; a.seqlen = p->seqlen; a.dstate = p->dstate; a.ngroups = p->ngroups;
     a.n_chunks = p->n_chunks; a.softplus = p->delta_softplus;
     a.u = p->u; a.delta = p->delta; a.z = p->z; a.B = p->B; a.C = p->C; a.A = p->A; a.D = p->D;

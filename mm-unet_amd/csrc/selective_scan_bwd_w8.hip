@@ -55,19 +55,20 @@ __device__ __forceinline__ float ld1(const io_t *p) { return to_f32(*p); }
 template <typename io_t>
 __device__ __forceinline__ void st1(io_t *p, float v) { *p = from_f32<io_t>(v); }
 
-template <typename io_t, bool HAS_Z>
+template <typename io_t, bool HAS_Z, bool HAS_OZ>
 __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) {
     constexpr int N = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tile = blockIdx.x, b = blockIdx.y, g = blockIdx.z;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int g = blockIdx.z / p.d_splits, sp = blockIdx.z - g * p.d_splits;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n0 = 2 * w;
     const int t0 = tile * W8_TT, c0 = tile * 4, n_tiles = gridDim.x;
     float *xch = smem;                                   // [2][8][XS]
     float *prep = smem + 2 * 8 * W8_XS;                  // [2][3][AS]
     float *slots = prep + 2 * 3 * W8_AS + w * 16;        // [8][2][8]: A2 pair | h0 pair | g0 pair | bias | D
-    const int dpg = p.dim / p.ngroups;
-    const int dbeg = g * dpg, dend = dbeg + dpg;
+    const int dpg = p.dim / p.ngroups, cps = (dpg + p.d_splits - 1) / p.d_splits;   // host: no range is empty
+    const int dbeg = g * dpg + sp * cps, dend = min(dbeg + cps, (g + 1) * dpg);
     const unsigned T = w * 64 + lane;                    // the token this lane prepares and finishes
     const int posT = ((T >> 2) & 1) * W8_SUB + (T >> 3) * 4 + (T & 3);
     const int posL = lane * 4;                           // this lane's 8 tokens: float4 at posL and posL + SUB
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
     io_t *o_du = (io_t *)p.du + (long)b * p.du_bs + (long)dbeg * p.du_ds + t0 + T;
     io_t *o_dd = (io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)dbeg * p.ddelta_ds + t0 + T;
     io_t *o_dz = HAS_Z ? (io_t *)p.dz + (long)b * p.dz_bs + (long)dbeg * p.dz_ds + t0 + T : nullptr;
-    io_t *o_oz = (HAS_Z && p.out_z) ? (io_t *)p.out_z + (long)b * p.out_z_bs + (long)dbeg * p.out_z_ds + t0 + T : nullptr;
+    io_t *o_oz = HAS_OZ ? (io_t *)p.out_z + (long)b * p.out_z_bs + (long)dbeg * p.out_z_ds + t0 + T : nullptr;
     float *part8 = p.part + (((long)b * n_tiles + tile) * p.dim + dbeg) * 32 + w * 4 + ((lane - 12) & 3);
     const bool hasH = c0 > 0, hasG = c0 + 4 < p.n_chunks;
 
@@ -149,12 +150,13 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
         gp += gstride;
     };
     // what the finishing step of a channel needs of its token
-    struct Tok { float dl, u, dy, dsp, F, G; };
+    struct Tok { float dl, u, dy, dsp, F, G, D; };
     auto prepare = [&](int par, const Raw &r, Tok &k) {   // a channel's loads -> prep[par], slots[par], k
         const float r_dl = r.dl, r_u = r.u, r_go = r.go, r_z = r.z;
         const float gvs = r.gv * gscale;
         if (lane < 8) slots[par * 8 + lane] = gvs;
         const float bias = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gvs), 6));
+        k.D = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gvs), 7));
         const float vraw = r_dl + bias;
         k.dl = p.softplus ? softplus_thr(vraw) : vraw;
         k.dsp = (p.softplus && vraw <= 20.f) ? sigmoidf_(vraw) : 1.f;   // bwd_kernel.cuh:439-453
@@ -199,16 +201,62 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
 #ifdef MMU_W8_STAMPS
     int ch = 0;
 #endif
-    // one channel; `par` is a compile-time constant (the loop below is unrolled by two: no parity arithmetic, no
-    // copy of the prepared token from `nxt` to `cur`)
-    auto channel = [&](auto PAR, const Tok &cur, Tok &nxt, Raw &raw) {
+    // Finishing token T of a channel: meeting the eight state pairs (sums of q / dd / y over the waves), du, ddelta,
+    // dz, out_z, and this wave's share of the dA / dD / dbias partials.  It runs at the top of the NEXT channel's
+    // call, right after the barrier that completed the exchange rows.  (Measured and dropped: running it inside
+    // that channel's main phase to hide its LDS / reduction latencies, and alternating s_setprio by phase to keep
+    // the two waves of a SIMD in step -- both within noise of this form, 1.27-1.31 ms for the headline backward.)
+    struct Fin { v2f qd[8]; float y[8]; };
+    auto finish_issue = [&](auto PAR, Fin &f) {
         constexpr int par = decltype(PAR)::value;
+        const float *xc = xch + par * (8 * W8_XS);
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) {
+            f.qd[wv] = *reinterpret_cast<const v2f *>(xc + wv * W8_XS + posT2);
+            if constexpr (HAS_Z) f.y[wv] = xc[wv * W8_XS + 4 * W8_SUB2 + posT];
+        }
+    };
+    auto finish_done = [&](const Fin &f, const Tok &k, v2f dA) {
+        v2f QD = (f.qd[0] + f.qd[1]) + (f.qd[2] + f.qd[3]);
+        QD += (f.qd[4] + f.qd[5]) + (f.qd[6] + f.qd[7]);
+        const float Q = QD.x, DDs = QD.y;
+        const float du = fmaf(k.D, k.dy, k.dl * Q);
+        const float ddel = fmaf(k.u, Q, DDs) * k.dsp;
+        st1(o_du, du);
+        st1(o_dd, ddel);
+        if constexpr (HAS_Z) {
+            const float Y = ((f.y[0] + f.y[1]) + (f.y[2] + f.y[3])) + ((f.y[4] + f.y[5]) + (f.y[6] + f.y[7]));
+            const float yt = fmaf(k.D, k.u, Y);
+            st1(o_dz, yt * k.F);
+            if constexpr (HAS_OZ) st1(o_oz, yt * k.G);
+        }
+        const float v = wave_sum4_swap(dA.x, dA.y, k.dy * k.u, ddel);   // lanes 12..15: the four wave totals
+        if (lane >= 12 && lane < 16) *part8 = v;
+        o_du += p.du_ds;
+        o_dd += p.ddelta_ds;
+        if constexpr (HAS_Z) {
+            o_dz += p.dz_ds;
+            if constexpr (HAS_OZ) o_oz += p.out_z_ds;
+        }
+        part8 += 32;
+    };
+
+    // one channel; `par` is a compile-time constant (the loop below is unrolled by two: no parity arithmetic, no
+    // copies of the prepared tokens).  FIN: the previous channel (token `prv`, dA sums `dA_prv`) is finished inside.
+    v2f dA_prv = v2f{0.f, 0.f};
+    auto channel = [&](auto PAR, auto FIN, Tok &prv_nxt, Raw &raw) {
+        constexpr int par = decltype(PAR)::value;
+        constexpr bool fin = decltype(FIN)::value;
+        if constexpr (fin) {
+            Fin fbuf;
+            finish_issue(std::integral_constant<int, par ^ 1>{}, fbuf);
+            finish_done(fbuf, prv_nxt, dA_prv);
+        }
         W8_STAMP(0);
         // ---- this channel's scalars and prepared per-token values ------------------------------------
         const float4 sA = *reinterpret_cast<const float4 *>(slots + par * 8);
         const float4 sB = *reinterpret_cast<const float4 *>(slots + par * 8 + 4);
         const v2f a2 = v2f{sA.x, sA.y}, h0 = v2f{sA.z, sA.w}, g0 = v2f{sB.x, sB.y};
-        const float Dv = sB.w;
         v2f dl2[4], dlu2[4], dy2[4];
         {
             const float *pr = prep + par * (3 * W8_AS) + posL;
@@ -309,59 +357,44 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
                         make_float4(yv[4 * j], yv[4 * j + 1], yv[4 * j + 2], yv[4 * j + 3]);
             }
         }
-        // ---- the next channel's tokens (loads issued a channel ago), then the loads of the one after --------
+        dA_prv = dAp;
+        // ---- the next channel's tokens (loads issued two channels ago), then the loads of the one after it ----
         W8_STAMP(2);
-        prepare(par ^ 1, raw, nxt);
+        prepare(par ^ 1, raw, prv_nxt);
         W8_STAMP(3);
         next_fetch(raw);
         W8_STAMP(4);
         MMU_LDS_BARRIER();
         W8_STAMP(5);
-        // ---- finish token T of this channel: meet the eight state pairs -------------------------------------
-        {
-            const float *xc = xch + par * (8 * W8_XS);
-            v2f QD = v2f{0.f, 0.f};
-            float Y = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 8; ++wv) {
-                QD += *reinterpret_cast<const v2f *>(xc + wv * W8_XS + posT2);
-                if constexpr (HAS_Z) Y += xc[wv * W8_XS + 4 * W8_SUB2 + posT];
-            }
-            W8_STAMP(6);
-            const float Q = QD.x, DDs = QD.y;
-            const float du = fmaf(Dv, cur.dy, cur.dl * Q);
-            const float ddel = fmaf(cur.u, Q, DDs) * cur.dsp;
-            st1(o_du, du);
-            st1(o_dd, ddel);
-            if constexpr (HAS_Z) {
-                const float yt = fmaf(Dv, cur.u, Y);
-                st1(o_dz, yt * cur.F);
-                if (o_oz) st1(o_oz, yt * cur.G);
-            }
-            W8_STAMP(7);
-            const float v = wave_sum4_swap(dAp.x, dAp.y, cur.dy * cur.u, ddel);   // lanes 12..15: the four wave totals
-            if (lane >= 12 && lane < 16) *part8 = v;
-        }
-        o_du += p.du_ds;
-        o_dd += p.ddelta_ds;
-        if constexpr (HAS_Z) {
-            o_dz += p.dz_ds;
-            if (o_oz) o_oz += p.out_z_ds;
-        }
-        part8 += 32;
 #ifdef MMU_W8_STAMPS
         ++ch;
 #endif
     };
-    Tok tok0 = cur, tok1;
-    for (int d = dbeg; d < dend; d += 2) {
-        channel(std::integral_constant<int, 0>{}, tok0, tok1, raw1);
-        if (d + 1 >= dend) break;
-        channel(std::integral_constant<int, 1>{}, tok1, tok0, raw0);
+    // tokE / tokO: prepared tokens of the even / odd channels (counted from dbeg).  A channel call finishes the
+    // previous channel from the token of the OTHER parity and then overwrites it with the next channel's.
+    Tok tokE = cur, tokO = cur;
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    constexpr std::true_type FIN{};
+    channel(P0, std::false_type{}, tokO, raw1);             // dbeg: nothing to finish yet
+    int d = dbeg + 1;
+    for (; d + 1 < dend; d += 2) {
+        channel(P1, FIN, tokE, raw0);                       // d odd: finishes d - 1 (tokE), prepares d + 1 into tokE
+        channel(P0, FIN, tokO, raw1);
+    }
+    if (d < dend) {                                         // an odd channel is left
+        channel(P1, FIN, tokE, raw0);
+        Fin fb;
+        finish_issue(P1, fb);
+        finish_done(fb, tokO, dA_prv);
+    } else {
+        Fin fb;
+        finish_issue(P0, fb);
+        finish_done(fb, tokE, dA_prv);
     }
     // this wave's two rows of dB / dC
-    float *dBg = p.dB + (long)b * p.dB_bs + (long)g * p.dB_gs + (long)n0 * p.dB_ns + t0 + lane * 8;
-    float *dCg = p.dC + (long)b * p.dC_bs + (long)g * p.dC_gs + (long)n0 * p.dC_ns + t0 + lane * 8;
+    float *dBg = p.dB + sp * p.dBC_ss + (long)b * p.dB_bs + (long)g * p.dB_gs + (long)n0 * p.dB_ns + t0 + lane * 8;
+    float *dCg = p.dC + sp * p.dBC_ss + (long)b * p.dC_bs + (long)g * p.dC_gs + (long)n0 * p.dC_ns + t0 + lane * 8;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         *reinterpret_cast<float4 *>(dBg + 4 * j) = make_float4(accB[4 * j].x, accB[4 * j + 1].x, accB[4 * j + 2].x, accB[4 * j + 3].x);
@@ -427,7 +460,7 @@ __global__ __launch_bounds__(64) void reduce_slices_w8_kernel(const float *__res
     w8_emit(t32, d, dA, dD, dbias);
 }
 
-unsigned long long g_lds_done[2][2];
+unsigned long long g_lds_done[2][3];
 
 }  // namespace
 
@@ -444,20 +477,24 @@ int mmu_scan_bwd_apply_w8(const ScanArgs &a, int dtype, hipStream_t st) {
     const char *e = getenv("MMU_SCAN_BWD_W8");
     if (e && e[0] == '0') return 0;
     if (a.dstate != 16 || a.seqlen % W8_TT != 0) return 0;
-    const long wgs = (long)(a.seqlen / W8_TT) * a.batch * a.ngroups;
+    const long wgs = (long)(a.seqlen / W8_TT) * a.batch * a.ngroups * a.d_splits;
     if (!(e && e[0] == '1') && wgs < mmu_cu_count()) return 0;   // too few tiles to give every CU one: p4's are half the size
     const size_t lds = sizeof(float) * (2 * 8 * W8_XS + 2 * 3 * W8_AS + 8 * 16);
-    dim3 grid(a.seqlen / W8_TT, a.batch, a.ngroups);
+    dim3 grid(a.seqlen / W8_TT, a.batch, a.ngroups * a.d_splits);
     const bool f32 = dtype == MMU_DTYPE_F32;
     hipError_t err = hipSuccess;
     MMU_BOOL(a.z != nullptr, HAS_Z, {
-        if (f32) {
-            err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<float, HAS_Z>, (int)lds, g_lds_done[0][HAS_Z]);
-            if (err == hipSuccess) chunk_apply_bwd_w8_kernel<float, HAS_Z><<<grid, 512, lds, st>>>(a);
-        } else {
-            err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z>, (int)lds, g_lds_done[1][HAS_Z]);
-            if (err == hipSuccess) chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z><<<grid, 512, lds, st>>>(a);
-        }
+        MMU_BOOL(a.z != nullptr && a.out_z != nullptr, HAS_OZ, {
+            if constexpr (HAS_Z || !HAS_OZ) {
+                if (f32) {
+                    err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<float, HAS_Z, HAS_OZ>, (int)lds, g_lds_done[0][HAS_Z + HAS_OZ]);
+                    if (err == hipSuccess) chunk_apply_bwd_w8_kernel<float, HAS_Z, HAS_OZ><<<grid, 512, lds, st>>>(a);
+                } else {
+                    err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z, HAS_OZ>, (int)lds, g_lds_done[1][HAS_Z + HAS_OZ]);
+                    if (err == hipSuccess) chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z, HAS_OZ><<<grid, 512, lds, st>>>(a);
+                }
+            }
+        });
     });
     if (err != hipSuccess) return mmu_fail("chunk_apply_bwd_w8: hipFuncSetAttribute: %s", hipGetErrorString(err));
     MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd_w8");

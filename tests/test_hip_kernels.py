@@ -260,6 +260,7 @@ def test_scan_fwd_stream_vs_oracle_and_chunk_path(case):
     (2, 4, 1024, 1, torch.float32, False, False, False),  # no z, no D, no bias
     (1, 1, 2048, 1, torch.float32, True, False, True),    # a single channel: the pipeline prologue is the whole loop
     (2, 8, 1024, 1, torch.bfloat16, True, True, True),
+    (2, 40, 1024, 1, torch.float32, True, False, True),   # few tiles, >= 16 channels: channel ranges (d_splits = 5)
 ])
 def test_scan_bwd_w8_vs_oracle_and_p4(case):
     """chunk_apply_bwd_w8_kernel (selective_scan_bwd_w8.hip: 512-token tiles, one state pair per wave; forced with

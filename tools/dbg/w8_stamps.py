@@ -23,12 +23,12 @@ buf = (ctypes.c_ulonglong * (2 * 8 * 8 * 8))()
 fn = _lib.lib().mmu_debug_w8_stamps
 assert fn(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(2, 8, 8, 8).astype(np.int64)
-names = ["main", "xch wr", "prepare", "fetch", "barrier wait", "xch rd+sum", "finish+stores"]
+names = ["main (+finish of the previous channel)", "xch wr", "prepare", "fetch", "barrier wait"]
 for blk in range(2):
     print(f"block sel {blk}: ticks (10 ns) per phase, averaged over channels 16..23")
     for w in range(8):
-        dt = np.diff(t[blk, w], axis=1).mean(axis=0)
-        nxt = (t[blk, w, 1:, 0] - t[blk, w, :-1, 7]).mean()  # wave sum + partial store + pointer adds
+        dt = np.diff(t[blk, w, :, :6], axis=1).mean(axis=0)
+        nxt = (t[blk, w, 1:, 0] - t[blk, w, :-1, 5]).mean()  # wave sum + partial store + pointer adds
         per = (t[blk, w, 1:, 0] - t[blk, w, :-1, 0]).mean()
         print(f"  wave {w}: " + " ".join(f"{nm}={v:.0f}" for nm, v in zip(names, dt)) + f" | wave_sum+tail={nxt:.0f} channel={per:.0f}")
     print("  barrier arrival spread (ticks, max-min over waves): " + " ".join(str(int(t[blk, :, c, 4].max() - t[blk, :, c, 4].min())) for c in range(8)))
