@@ -128,10 +128,12 @@ def scan_rooflines(dev, iters=20):
             "VALU issue, not HBM: one v_exp_f32 + ~5.6 VALU instructions per (d, n, t) element group against a budget "
             "of ~6.5 issue slots at 70 % of HBM (DESIGN.md 4.1)", _traffic("scan_fwd_traffic.json") if tag == "" else None)
         leg("roofline_bwd" + tag,
-            "mmu_selective_scan_bwd = chunk_reduce8<bwd> + chunk_carry_par + chunk_apply_bwd_p4 + reduce_partials",
+            "mmu_selective_scan_bwd = chunk_reduce8<bwd> + chunk_carry_par + chunk_apply_bwd_w8 (512-token tiles, one "
+            "state pair per wave) + reduce_partials_w8",
             shape, s_ * b * l * (8 * d + 2 * n) + 4 * b * l * 2 * n, ms_b,
-            "VALU issue: ~29 VALU instructions per (d, n, t) element group (recompute + adjoint scan + 8 gradient "
-            "streams), DESIGN.md 4.2", _traffic("scan_bwd_traffic.json") if tag == "" else None)
+            "VALU issue: ~15 packed fp32 + 2 exp + 6.6 DPP instructions per (d, state pair, t) in the apply kernel "
+            "(recompute + adjoint scan + 8 gradient streams) at ~2.5 ns per packed instruction and SIMD, DESIGN.md 4.2",
+            _traffic("scan_bwd_traffic.json") if tag == "" else None)
         if tag == "":
             w = torch.randn(d, 4, device=dev)
             cb = torch.randn(d, device=dev)
