@@ -16,10 +16,12 @@ from mm_unet_amd.train_step import TrainStep, make_optimizer  # noqa: E402
 pats = sys.argv[1:] or ["aten::fill_", "aten::zero_", "aten::add_", "aten::copy_", "aten::add", "aten::mul", "aten::sum", "aten::contiguous", "aten::clone"]
 dev = "cuda:0"
 torch.manual_seed(0)
+BF16 = os.environ.get("BF16") == "1"        # BASELINE config 3: bf16 autocast, batch 16
+BATCH = int(os.environ.get("BATCH", "16" if BF16 else "8"))
 m = MM_Net(num_classes=1).to(dev).train()
-step = TrainStep(m, DICE_BCE_Loss(), make_optimizer(m), use_graph=False)
-x = torch.randn(8, 3, 512, 512, device=dev)
-t = (torch.rand(8, 1, 512, 512, device=dev) > 0.88).float()
+step = TrainStep(m, DICE_BCE_Loss(), make_optimizer(m), use_graph=False, amp_dtype=torch.bfloat16 if BF16 else None)
+x = torch.randn(BATCH, 3, 512, 512, device=dev)
+t = (torch.rand(BATCH, 1, 512, 512, device=dev) > 0.88).float()
 for _ in range(2):
     step(x, t)
 torch.cuda.synchronize()
