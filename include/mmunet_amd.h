@@ -172,7 +172,8 @@ int mmu_causal_conv1d_update(const mmu_conv1d_update_params *p, void *stream);
  * F.grid_sample(bilinear, zeros, align_corners=True) and their autograd
  * (src/UM_Net/MMUNet.py:196-242,259-263).  The column of tap k at pixel (h, w) is the integer
  * w + k - K/2, only the row coordinate y is learned, so the gather is a 2-tap vertical lerp.
- * All tensors contiguous float32.
+ * All tensors contiguous; input / dinput in in_dtype (float32, or bfloat16 activations under autocast), the
+ * coordinates, samples and their gradients float32 (grid_sample is on autocast's float32 list).
  *   fwd: out[b,c,h*K+k,w] from input[b,c,:,:] and y[b,k,h,w] (pixels, unclamped)
  *   bwd: dinput (written in full: gathered, far outliers added with float atomics) and dy (clamp mask applied)
  * out_layout MMU_MORPH_TOKENS_LAST stores the samples as [channels, taps, batch, height, width], i.e. the
@@ -183,12 +184,13 @@ int mmu_causal_conv1d_update(const mmu_conv1d_update_params *p, void *stream);
 typedef struct {
     int32_t batch, channels, height, width, taps;
     int32_t out_layout;  /* MMU_MORPH_BCHW or MMU_MORPH_TOKENS_LAST (layout of out and dout) */
-    const float *input;  /* [batch, channels, height, width] */
+    const void *input;   /* [batch, channels, height, width], in_dtype */
     const float *y;      /* [batch, taps, height, width] */
     float *out;          /* fwd: [batch, channels, height*taps, width] */
     const float *dout;   /* bwd: same shape as out */
-    float *dinput;       /* bwd: [batch, channels, height, width] */
+    void *dinput;        /* bwd: [batch, channels, height, width], in_dtype */
     float *dy;           /* bwd: [batch, taps, height, width] */
+    int32_t in_dtype;    /* MMU_DTYPE_F32 (0, the default of a zeroed struct) or MMU_DTYPE_BF16 */
 } mmu_morph_params;
 
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
@@ -210,21 +212,23 @@ int mmu_bilinear_resize_bwd(const mmu_resize_params *p, void *stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution with few output channels (a9: MMConv.offset_conv) ------------ */
 /* nn.Conv2d(Cin, CO, 3, padding=1) for CO in {1, 2, 6, 8} (src/UM_Net/MMUNet.py:46,250: Cin -> 2K = 6), contiguous
- * float32 NCHW.  weight_t is the weight transposed to [Cin][3][3][CO] (a channel's CO*9 weights contiguous).
+ * NCHW; input / dinput in in_dtype (float32, or bfloat16 activations under autocast), everything else float32.
+ * weight_t is the weight transposed to [Cin][3][3][CO] (a channel's CO*9 weights contiguous).
  *   fwd : out[b,co,h,w] = bias[co] + sum_{ci,ky,kx} W[co][ci][ky][kx] * in[b,ci,h+ky-1,w+kx-1]
  *   bwd : dinput (if non-NULL), dweight [CO][Cin][3][3] and dbias [CO] (if non-NULL; zeroed inside, float atomics) */
 typedef struct {
     int32_t batch, in_channels, out_channels, height, width;
-    const float *input;     /* [batch, in_channels, height, width] */
+    const void *input;      /* [batch, in_channels, height, width], in_dtype */
     const float *weight_t;  /* [in_channels, 3, 3, out_channels] */
     const float *bias;      /* [out_channels] or NULL */
     float *out;             /* fwd: [batch, out_channels, height, width] */
     const float *dout;      /* bwd: same shape as out */
-    float *dinput;          /* bwd, optional */
+    void *dinput;           /* bwd, optional, in_dtype */
     float *dweight;         /* bwd, optional: [out_channels, in_channels, 3, 3] */
     float *dbias;           /* bwd, optional (only with dweight) */
     float *workspace;       /* fwd: mmu_conv3x3_small_fwd_splits() x (elements of out) floats when splits > 1;
                              * bwd: mmu_conv3x3_small_wgrad_workspace_floats() floats or NULL */
+    int32_t in_dtype;       /* MMU_DTYPE_F32 (0, the default of a zeroed struct) or MMU_DTYPE_BF16 */
 } mmu_conv3x3s_params;
 
 /* small images have too few pixels to fill the chip: the forward then slices the input channels and sums the
@@ -256,7 +260,9 @@ int mmu_tri_combine(const mmu_tri_params *p, void *stream);
 
 /* ---- GroupNorm [-> BatchNorm2d] [-> ReLU | tanh] as one normalisation (a9/a11 blocks) ------------------ */
 /* nn.GroupNorm(groups, C) optionally followed by nn.BatchNorm2d(C) (training or eval statistics) and an
- * activation (src/UM_Net/MMUNet.py:250,265 + :344-349,357-359,424-430,436-452), contiguous float32 NCHW.
+ * activation (src/UM_Net/MMUNet.py:250,265 + :344-349,357-359,424-430,436-452), contiguous NCHW.  Two element
+ * types (MMU_DTYPE_*): x_dtype for input / dinput (what the producer -- a GEMM or a convolution -- emits), act_dtype
+ * for out, residual, dout, act_out, dresidual (bf16 under autocast); statistics and parameters are float32.
  * Both normalisations are affine in x per (batch, channel) once the statistics are known, and the statistics
  * follow from the per-(batch, channel) moments of x: two passes forward, two backward.
  * Buffers the caller owns: s1, s2, scale, shift [batch*channels]; mu, rstd [batch*groups]; bn_mean, bn_rstd
@@ -269,23 +275,24 @@ typedef struct {
     int32_t has_gn;           /* 0: BatchNorm2d [-> act] alone (then groups == channels, has_bn == 1) */
     int32_t dinput_channel_major;  /* bwd: write dinput as [channels][batch][hw] (for a tokens-last consumer) */
     float gn_eps, bn_eps, momentum;
-    const float *input;       /* [batch, channels, hw] */
+    const void *input;        /* [batch, channels, hw], x_dtype */
     const float *gn_weight;   /* [channels] or NULL */
     const float *gn_bias;     /* [channels] or NULL */
     const float *bn_weight;   /* [channels] or NULL */
     const float *bn_bias;     /* [channels] or NULL */
     const float *pre_bias;    /* [channels] or NULL: normalise input + pre_bias[c] (the bias of the conv before) */
-    const float *residual;    /* fwd, or NULL: out = relu(norm(input) + residual)  (ResidualBlock, MMUNet.py:455-467) */
+    const void *residual;     /* fwd, or NULL: out = relu(norm(input) + residual)  (ResidualBlock, MMUNet.py:455-467); act_dtype */
     float *running_mean;      /* [channels]: updated in training mode (may be NULL), used in eval mode */
     float *running_var;
-    float *out;               /* fwd */
+    void *out;                /* fwd, act_dtype */
     float *s1, *s2, *mu, *rstd, *bn_mean, *bn_rstd, *scale, *shift;   /* saved statistics */
-    const float *dout;        /* bwd */
-    const float *act_out;     /* bwd, residual mode: the forward output (its sign is the ReLU mask) */
-    float *dinput;            /* bwd */
-    float *dresidual;         /* bwd, residual mode: gradient of the residual input */
+    const void *dout;         /* bwd, act_dtype */
+    const void *act_out;      /* bwd, residual mode: the forward output (its sign is the ReLU mask), act_dtype */
+    void *dinput;             /* bwd, x_dtype */
+    void *dresidual;          /* bwd, residual mode: gradient of the residual input, act_dtype */
     float *dgn_weight, *dgn_bias, *dbn_weight, *dbn_bias, *dpre_bias; /* bwd, each optional */
     float *workspace;         /* bwd */
+    int32_t x_dtype, act_dtype;   /* MMU_DTYPE_F32 (0, the default of a zeroed struct) or MMU_DTYPE_BF16 */
 } mmu_norm_params;
 
 size_t mmu_norm_fused_workspace_floats(int batch, int channels, int groups);

@@ -67,7 +67,8 @@ class Conv1dUpdateParams(ctypes.Structure):
 
 class MorphParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "channels", "height", "width", "taps", "out_layout")]
-                + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")])
+                + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")]
+                + [("in_dtype", _i32)])
 
 
 class ResizeParams(ctypes.Structure):
@@ -78,7 +79,8 @@ class ResizeParams(ctypes.Structure):
 class Conv3x3sParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "in_channels", "out_channels", "height", "width")]
                 + [(n, _vp) for n in ("input", "weight_t", "bias", "out", "dout", "dinput", "dweight", "dbias",
-                                      "workspace")])
+                                      "workspace")]
+                + [("in_dtype", _i32)])
 
 
 class TriParams(ctypes.Structure):
@@ -93,7 +95,8 @@ class NormParams(ctypes.Structure):
                                       "running_mean",
                                       "running_var", "out", "s1", "s2", "mu", "rstd", "bn_mean", "bn_rstd", "scale",
                                       "shift", "dout", "act_out", "dinput", "dresidual", "dgn_weight", "dgn_bias", "dbn_weight", "dbn_bias",
-                                      "dpre_bias", "workspace")])
+                                      "dpre_bias", "workspace")]
+                + [("x_dtype", _i32), ("act_dtype", _i32)])
 
 
 class Conv3x3MfmaParams(ctypes.Structure):

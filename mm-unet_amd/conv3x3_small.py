@@ -2,8 +2,10 @@
 
 MMConv's ``offset_conv`` (Cin -> 2K = 6 channels, src/UM_Net/MMUNet.py:46,250) runs 44 times per MM-UNet
 forward.  Six output channels leave a matrix core nothing to do; MIOpen's Winograd / implicit-GEMM kernels
-take 60 us forward and 140 us backward for [8, 64, 128, 128] (5.3 ms per training step in total).  float32,
-contiguous NCHW; anything else is the caller's ``F.conv2d``.
+take 60 us forward and 140 us backward for [8, 64, 128, 128] (5.3 ms per training step in total).  Contiguous
+NCHW; the input (and its gradient) float32 or bfloat16 -- bf16 activations under autocast are read as they are, the
+arithmetic, the weights and the 6-channel output are float32 (more exact than autocast's bf16 convolution, and
+the output feeds a GroupNorm that autocast runs in float32 anyway); anything else is the caller's ``F.conv2d``.
 """
 import torch
 
@@ -14,8 +16,8 @@ WEIGHT_GRAD_NATIVE = True    # False: weight / bias gradient from ATen (MIOpen);
 
 
 def supported(x, weight):
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
-            and weight.shape[2:] == (3, 3) and weight.shape[0] in SUPPORTED_CO and not torch.is_autocast_enabled())
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32 and x.dim() == 4
+            and weight.shape[2:] == (3, 3) and weight.shape[0] in SUPPORTED_CO)
 
 
 class Conv3x3SmallFn(torch.autograd.Function):
@@ -24,7 +26,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
         _lib.require_gpu(x, weight)
         if not supported(x, weight) or weight.shape[1] != x.shape[1] or \
                 (bias is not None and (bias.dtype != torch.float32 or bias.numel() != weight.shape[0])):
-            raise RuntimeError("conv3x3_small: float32 NCHW input, [CO, Cin, 3, 3] float32 weight with CO in "
+            raise RuntimeError("conv3x3_small: float32 / bfloat16 NCHW input, [CO, Cin, 3, 3] float32 weight with CO in "
                                f"{SUPPORTED_CO} and a float32 bias of CO elements required")
         x = x.contiguous()
         weight = weight.contiguous()
@@ -36,6 +38,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
         p = _lib.Conv3x3sParams()
         p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
         p.input, p.weight_t, p.bias, p.out = x.data_ptr(), wt.data_ptr(), _lib.ptr(bias), out.data_ptr()
+        p.in_dtype = _lib.dtype_code(x)
         splits = _lib.lib().mmu_conv3x3_small_fwd_splits(B, Cin, H, W)
         ws = torch.empty((splits,) + tuple(out.shape), device=x.device, dtype=torch.float32) if splits > 1 else None
         p.workspace = _lib.ptr(ws)
@@ -59,6 +62,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
             p = _lib.Conv3x3sParams()
             p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
             p.input, p.weight_t, p.dout, p.dinput = x.data_ptr(), wt.data_ptr(), g.data_ptr(), dx.data_ptr()
+            p.in_dtype = _lib.dtype_code(x)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
         if need_w or need_b:
@@ -69,6 +73,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
                 p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
                 p.input, p.weight_t, p.dout = x.data_ptr(), wt.data_ptr(), g.data_ptr()
                 p.dweight, p.dbias = dw.data_ptr(), _lib.ptr(db)
+                p.in_dtype = _lib.dtype_code(x)
                 nws = _lib.lib().mmu_conv3x3_small_wgrad_workspace_floats(B, Cin, CO, H, W)
                 ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
                 p.workspace = _lib.ptr(ws)
@@ -79,7 +84,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
                 # transposes take 50-110 us where the row-walking kernel needs a fraction of that)
                 w = wt.permute(3, 0, 1, 2)
                 _, dw, db = torch.ops.aten.convolution_backward(
-                    g, x, w, [CO] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                    g, x.float(), w, [CO] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                     [False, bool(need_w), bool(need_b)])
         return dx, dw, db
 

@@ -23,8 +23,8 @@ namespace {
 
 // fwd.  grid (ceil(B*H*ceil(W/4) / 256), splits): split s handles input channels [s*cps, (s+1)*cps) and
 // writes its partial sums to part[s] ([B][CO][H][W]); with one split `part` is the output itself.
-template <int CO>
-__global__ __launch_bounds__(256) void conv3x3s_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+template <int CO, typename in_t>
+__global__ __launch_bounds__(256) void conv3x3s_fwd_kernel(const in_t *__restrict__ x, const float *__restrict__ wt,
                                                            const float *__restrict__ bias, float *__restrict__ part,
                                                            int B, int Cin, int H, int W, int cps) {
     const int wq = (W + 3) / 4;
@@ -59,20 +59,21 @@ __global__ __launch_bounds__(256) void conv3x3s_fwd_kernel(const float *__restri
         coff[j] = ww < 0 ? 0 : (ww > W - 1 ? W - 1 : ww);
     }
     const bool vec = (W & 3) == 0;  // then columns w0..w0+3 are in range and 16-byte aligned
-    const float *xp = x + ((long)b * Cin + c_lo) * HW;
+    const in_t *xp = x + ((long)b * Cin + c_lo) * HW;
     for (int ci = c_lo; ci < c_hi; ++ci, xp += HW) {
         float v[3][6];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const float *rp = xp + roff[dy];
+            const in_t *rp = xp + roff[dy];
             if (vec) {
-                const float4 c = *reinterpret_cast<const float4 *>(rp + w0);
-                v[dy][1] = c.x * rm[dy]; v[dy][2] = c.y * rm[dy]; v[dy][3] = c.z * rm[dy]; v[dy][4] = c.w * rm[dy];
-                v[dy][0] = rp[coff[0]] * (rm[dy] * cm[0]);
-                v[dy][5] = rp[coff[5]] * (rm[dy] * cm[5]);
+                float c[4];
+                load_k<in_t, 4, true>(rp + w0, 4, true, c);
+                v[dy][1] = c[0] * rm[dy]; v[dy][2] = c[1] * rm[dy]; v[dy][3] = c[2] * rm[dy]; v[dy][4] = c[3] * rm[dy];
+                v[dy][0] = to_f32(rp[coff[0]]) * (rm[dy] * cm[0]);
+                v[dy][5] = to_f32(rp[coff[5]]) * (rm[dy] * cm[5]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) v[dy][j] = rp[coff[j]] * (rm[dy] * cm[j]);
+                for (int j = 0; j < 6; ++j) v[dy][j] = to_f32(rp[coff[j]]) * (rm[dy] * cm[j]);
             }
         }
         const float *wc = wt + (long)ci * 9 * CO;  // wave-uniform: scalar loads
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void conv3x3s_sum_splits_kernel(const float *_
 
 // dx[b,ci,y,x] = sum_co sum_{ky,kx} W[co][ci][ky][kx] * g[b,co,y-ky+1,x-kx+1]
 // grid (ceil(B*H*ceil(W/2) / 256), channel slices): every slice re-reads the (small) dout neighbourhood
-template <int CO>
+template <int CO, typename in_t>
 __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__restrict__ g, const float *__restrict__ wt,
-                                                                float *__restrict__ dx, int B, int Cin, int H, int W,
+                                                                in_t *__restrict__ dx, int B, int Cin, int H, int W,
                                                                 int cps) {
     const int wq = (W + 1) / 2;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__r
             for (int co = 0; co < CO; ++co) gv[co][dy][j] = gp[co * HW + off] * m;
         }
     }
-    float *dp = dx + ((long)b * Cin + c_lo) * HW + (long)h * W + w0;
+    in_t *dp = dx + ((long)b * Cin + c_lo) * HW + (long)h * W + w0;
     const bool two = (W & 1) == 0;
     for (int ci = c_lo; ci < c_hi; ++ci, dp += HW) {
         const float *wc = wt + (long)ci * 9 * CO;
@@ -159,10 +160,11 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__r
                     a1 = fmaf(wv, gv[co][2 - ky][3 - kx], a1);
                 }
         if (two) {
-            *reinterpret_cast<float2 *>(dp) = make_float2(a0, a1);
+            const float a01[2] = {a0, a1};
+            store_k<in_t, 2, true>(dp, 2, true, a01);
         } else {
-            dp[0] = a0;
-            if (w0 + 1 < W) dp[1] = a1;
+            dp[0] = from_f32<in_t>(a0);
+            if (w0 + 1 < W) dp[1] = from_f32<in_t>(a1);
         }
     }
 }
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__r
 // grid (chunks of 64*gpl groups over B*H*ceil(W/4), ceil(Cin / 4)); block 256 = 4 waves = 4 input channels;
 // lane = group of 4 consecutive pixels of a row (the 3 x 6 input neighbourhood is shared by the 4 pixels:
 // 9 + 6 load instructions per 216 FMAs), CO*9 register accumulators, wave reduction + one atomic per weight.
-template <int CO>
-__global__ __launch_bounds__(256) void conv3x3s_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ g,
+template <int CO, typename in_t>
+__global__ __launch_bounds__(256) void conv3x3s_bwd_weight_kernel(const in_t *__restrict__ x, const float *__restrict__ g,
                                                                   float *__restrict__ dW, float *__restrict__ dbias,
                                                                   int B, int Cin, int H, int W, int gpl) {
     const int lane = threadIdx.x & 63;
@@ -198,23 +200,24 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_weight_kernel(const float *_
         const long r = gidx / wq;
         const int h = (int)(r % H), b = (int)(r / H);
         const int w0 = q * 4;
-        const float *xp = x + ((long)b * Cin + ci) * HW;
+        const in_t *xp = x + ((long)b * Cin + ci) * HW;
         float xv[3][6];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int hh = h + dy - 1;
             const float rmask = (hh >= 0 && hh < H) ? 1.f : 0.f;
-            const float *rp = xp + (hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh)) * W;
+            const in_t *rp = xp + (hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh)) * W;
             if (vec) {
-                const float4 c = *reinterpret_cast<const float4 *>(rp + w0);
-                xv[dy][1] = c.x * rmask; xv[dy][2] = c.y * rmask; xv[dy][3] = c.z * rmask; xv[dy][4] = c.w * rmask;
-                xv[dy][0] = rp[w0 > 0 ? w0 - 1 : 0] * (w0 > 0 ? rmask : 0.f);
-                xv[dy][5] = rp[w0 + 4 < W ? w0 + 4 : W - 1] * (w0 + 4 < W ? rmask : 0.f);
+                float c[4];
+                load_k<in_t, 4, true>(rp + w0, 4, true, c);
+                xv[dy][1] = c[0] * rmask; xv[dy][2] = c[1] * rmask; xv[dy][3] = c[2] * rmask; xv[dy][4] = c[3] * rmask;
+                xv[dy][0] = to_f32(rp[w0 > 0 ? w0 - 1 : 0]) * (w0 > 0 ? rmask : 0.f);
+                xv[dy][5] = to_f32(rp[w0 + 4 < W ? w0 + 4 : W - 1]) * (w0 + 4 < W ? rmask : 0.f);
             } else {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const int ww = w0 + j - 1;
-                    xv[dy][j] = rp[ww < 0 ? 0 : (ww > W - 1 ? W - 1 : ww)] * ((ww >= 0 && ww < W) ? rmask : 0.f);
+                    xv[dy][j] = to_f32(rp[ww < 0 ? 0 : (ww > W - 1 ? W - 1 : ww)]) * ((ww >= 0 && ww < W) ? rmask : 0.f);
                 }
             }
         }
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_weight_kernel(const float *_
 // No integer division anywhere (the first version spent its time in 64-bit div/mod).  Each wave writes its
 // CO*10 partial sums (wave_sum4 batches) to part[block][ci][*]; a second kernel adds the blocks in fixed
 // order: deterministic, no atomics, no zero-fill.
-template <int CO>
-__global__ __launch_bounds__(256) void conv3x3s_wgrad_rows_kernel(const float *__restrict__ x, const float *__restrict__ g,
+template <int CO, typename in_t>
+__global__ __launch_bounds__(256) void conv3x3s_wgrad_rows_kernel(const in_t *__restrict__ x, const float *__restrict__ g,
                                                                   float *__restrict__ part, int Cin, int H, int W,
                                                                   int lwq, int rs) {
     constexpr int NV = CO * 10, NV4 = (NV + 3) & ~3;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void conv3x3s_wgrad_rows_kernel(const float *_
     const int wq = 1 << lwq, q = lane & (wq - 1), st = lane >> lwq, S = 64 >> lwq;
     const int h0 = (blockIdx.x * S + st) * rs;
     const long HW = (long)H * W;
-    const float *xp = x + ((long)b * Cin + ci) * HW + 4 * q;
+    const in_t *xp = x + ((long)b * Cin + ci) * HW + 4 * q;
     const float *gp = g + (long)b * CO * HW + 4 * q;
     const float lm = q > 0 ? 1.f : 0.f, rm = q < wq - 1 ? 1.f : 0.f;
     float v[NV];
@@ -285,8 +288,9 @@ __global__ __launch_bounds__(256) void conv3x3s_wgrad_rows_kernel(const float *_
     auto load_row = [&](int hh, float(&r)[6]) {
         const float m = (hh >= 0 && hh < H) ? 1.f : 0.f;
         const int hc = hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh);
-        const float4 c = *reinterpret_cast<const float4 *>(xp + (long)hc * W);
-        r[1] = c.x * m; r[2] = c.y * m; r[3] = c.z * m; r[4] = c.w * m;
+        float c[4];
+        load_k<in_t, 4, true>(xp + (long)hc * W, 4, true, c);
+        r[1] = c[0] * m; r[2] = c[1] * m; r[3] = c[2] * m; r[4] = c[3] * m;
         r[0] = __shfl_up(r[4], 1) * lm;
         r[5] = __shfl_down(r[1], 1) * rm;
     };
@@ -386,12 +390,21 @@ int check(const mmu_conv3x3s_params *p, const char *name) {
     return 0;
 }
 
-#define CO_DISPATCH(co, ...)                                          \
+#define CO_DISPATCH_T(co, ...)                                        \
     switch (co) {                                                     \
         case 1: { constexpr int CO = 1; __VA_ARGS__ } break;          \
         case 2: { constexpr int CO = 2; __VA_ARGS__ } break;          \
         case 6: { constexpr int CO = 6; __VA_ARGS__ } break;          \
         default: { constexpr int CO = 8; __VA_ARGS__ } break;         \
+    }
+// CO = out_channels, in_t = element type of input / dinput (p->in_dtype)
+#define CO_DISPATCH(co, ...)                                          \
+    if (p->in_dtype == MMU_DTYPE_BF16) {                              \
+        using in_t = bf16_t;                                          \
+        CO_DISPATCH_T(co, __VA_ARGS__)                                \
+    } else {                                                          \
+        using in_t = float;                                           \
+        CO_DISPATCH_T(co, __VA_ARGS__)                                \
     }
 
 }  // namespace
@@ -411,8 +424,8 @@ extern "C" int mmu_conv3x3_small_fwd(const mmu_conv3x3s_params *p, void *stream)
     hipStream_t st = (hipStream_t)stream;
     float *part = splits == 1 ? p->out : p->workspace;
     dim3 grid((unsigned)((total + 255) / 256), splits);
-    CO_DISPATCH(p->out_channels, conv3x3s_fwd_kernel<CO><<<grid, 256, 0, st>>>(
-                                     p->input, p->weight_t, p->bias, part, p->batch, p->in_channels, p->height,
+    CO_DISPATCH(p->out_channels, conv3x3s_fwd_kernel<CO, in_t><<<grid, 256, 0, st>>>(
+                                     (const in_t *)p->input, p->weight_t, p->bias, part, p->batch, p->in_channels, p->height,
                                      p->width, cps);)
     MMU_HIP_LAUNCH_CHECK("conv3x3_small_fwd");
     if (splits > 1) {
@@ -439,8 +452,8 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
         const int splits = channel_splits(total, p->in_channels);
         const int cps = (p->in_channels + splits - 1) / splits;
         dim3 grid((unsigned)((total + 255) / 256), splits);
-        CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO><<<grid, 256, 0, st>>>(
-                                         p->dout, p->weight_t, p->dinput, p->batch, p->in_channels, p->height,
+        CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO, in_t><<<grid, 256, 0, st>>>(
+                                         p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
                                          p->width, cps);)
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(data)");
     }
@@ -449,9 +462,10 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
         MMU_CHECK(p->input, "conv3x3_small_bwd: input is required for dweight");
         MMU_CHECK(((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->dout & 15) == 0,
                   "conv3x3_small_bwd: input and dout must be 16-byte aligned");
+
         dim3 grid(nrb, (p->in_channels + 3) / 4, p->batch);
         CO_DISPATCH(p->out_channels, {
-            conv3x3s_wgrad_rows_kernel<CO><<<grid, 256, 0, st>>>(p->input, p->dout, p->workspace, p->in_channels,
+            conv3x3s_wgrad_rows_kernel<CO, in_t><<<grid, 256, 0, st>>>((const in_t *)p->input, p->dout, p->workspace, p->in_channels,
                                                                  p->height, p->width, lwq, rs);
             MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight rows)");
             constexpr int NV4 = (CO * 10 + 3) & ~3;
@@ -461,8 +475,8 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight sum)");
     } else if (p->dweight) {
         MMU_CHECK(p->input, "conv3x3_small_bwd: input is required for dweight");
-        hipError_t e = hipMemsetAsync(p->dweight, 0, sizeof(float) * (size_t)p->out_channels * p->in_channels * 9, st);
-        if (e == hipSuccess && p->dbias) e = hipMemsetAsync(p->dbias, 0, sizeof(float) * p->out_channels, st);
+        hipError_t e = mmu_zero_async(p->dweight, (size_t)p->out_channels * p->in_channels * 9, st);
+        if (e == hipSuccess && p->dbias) e = mmu_zero_async(p->dbias, p->out_channels, st);
         if (e != hipSuccess) return mmu_fail("conv3x3_small_bwd: memset: %s", hipGetErrorString(e));
         const long NG = (long)p->batch * p->height * ((p->width + 3) / 4);
         // groups per lane: ~4096 waves in total (the 54-value wave reduction + atomics at the end of a wave
@@ -470,8 +484,8 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
         long gpl_ = NG * p->in_channels / 64 / 4096;
         const int gpl = gpl_ < 2 ? 2 : (gpl_ > 32 ? 32 : (int)gpl_);
         dim3 grid((unsigned)((NG + 64L * gpl - 1) / (64L * gpl)), (p->in_channels + 3) / 4);
-        CO_DISPATCH(p->out_channels, conv3x3s_bwd_weight_kernel<CO><<<grid, 256, 0, st>>>(
-                                         p->input, p->dout, p->dweight, p->dbias, p->batch, p->in_channels,
+        CO_DISPATCH(p->out_channels, conv3x3s_bwd_weight_kernel<CO, in_t><<<grid, 256, 0, st>>>(
+                                         (const in_t *)p->input, p->dout, p->dweight, p->dbias, p->batch, p->in_channels,
                                          p->height, p->width, gpl);)
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight)");
     }

@@ -50,6 +50,20 @@ inline hipError_t mmu_set_lds_once(F kernel, int bytes, unsigned long long &done
     return e;
 }
 
+// Zero-fill of an accumulation target as a KERNEL, not hipMemsetAsync: under stream capture a memset becomes a memset
+// node, and on this ROCm the replays of a graph did not reliably clear the buffer before the kernel that accumulates
+// into it (seen as garbage / NaN gradients from the second replay on, at the small sizes where the atomic paths
+// run; tools/dbg/replay_diff.py).  A kernel node keeps the stream order.
+__global__ __launch_bounds__(256) static void mmu_zero_kernel(float *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+inline hipError_t mmu_zero_async(float *p, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    mmu_zero_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p, n);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // I/O element types
 // ---------------------------------------------------------------------------
@@ -263,10 +277,6 @@ __device__ __forceinline__ void wave_scan_affine_shfl(float &P, float &S) {
     }
 }
 
-#ifndef MMU_SCAN_USE_SHFL
-#define MMU_SCAN_USE_SHFL 0
-#endif
-
 // Hand-scheduled form of wave_scan_affine_dpp: each scan step is ONE v_fmac_f32_dpp
 // (S += dpp(S) * P) and ONE v_mul_f32_dpp (P *= dpp(P)); lanes whose DPP source does not exist
 // are not written (bound_ctrl off), rows masked out by row_mask are not written -- which is
@@ -282,10 +292,6 @@ __device__ __forceinline__ void wave_scan_affine_shfl(float &P, float &S) {
     "v_mul_f32_dpp %2, %2, %2 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"
 
 __device__ __forceinline__ void wave_scan_affine_x2(float &P0, float &S0, float &P1, float &S1) {
-#if MMU_SCAN_USE_SHFL
-    wave_scan_affine_shfl(P0, S0);
-    wave_scan_affine_shfl(P1, S1);
-#else
     asm volatile("s_nop 1\n\t"
                  MMU_SCAN2_STEP("row_shr:1", "0xf")
                  MMU_SCAN2_STEP("row_shr:2", "0xf")
@@ -295,7 +301,6 @@ __device__ __forceinline__ void wave_scan_affine_x2(float &P0, float &S0, float 
                  MMU_SCAN2_STEP("row_bcast:31", "0xc")
                  "s_nop 1"
                  : "+v"(P0), "+v"(S0), "+v"(P1), "+v"(S1));
-#endif
 }
 
 #define MMU_SCAN1_STEP(ctrl, mask)                                                         \
@@ -304,9 +309,6 @@ __device__ __forceinline__ void wave_scan_affine_x2(float &P0, float &S0, float 
     "s_nop 1\n\t"
 
 __device__ __forceinline__ void wave_scan_affine(float &P, float &S) {
-#if MMU_SCAN_USE_SHFL
-    wave_scan_affine_shfl(P, S);
-#else
     asm volatile("s_nop 1\n\t"
                  MMU_SCAN1_STEP("row_shr:1", "0xf")
                  MMU_SCAN1_STEP("row_shr:2", "0xf")
@@ -315,17 +317,11 @@ __device__ __forceinline__ void wave_scan_affine(float &P, float &S) {
                  MMU_SCAN1_STEP("row_bcast:15", "0xa")
                  MMU_SCAN1_STEP("row_bcast:31", "0xc")
                  : "+v"(P), "+v"(S));
-#endif
 }
 
 // value of lane (l-1); lane 0 gets `fill`
 __device__ __forceinline__ float wave_shift_up1(float v, float fill) {
-#if MMU_SCAN_USE_SHFL
-    const float r = __shfl_up(v, 1, 64);
-    return (threadIdx.x & 63) == 0 ? fill : r;
-#else
     return dpp_mov<MMU_DPP_WAVE_SHR1, 0xf>(fill, v);
-#endif
 }
 
 // lane l <-> lane 63-l
@@ -336,15 +332,6 @@ __device__ __forceinline__ float wave_reverse(float v) {
 
 // inclusive prefix sum over lanes
 __device__ __forceinline__ float wave_scan_add(float v) {
-#if MMU_SCAN_USE_SHFL
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
-    return v;
-#else
     v += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, v);
     v += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, v);
     v += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, v);
@@ -352,7 +339,6 @@ __device__ __forceinline__ float wave_scan_add(float v) {
     v += dpp_mov<MMU_DPP_ROW_BCAST15, 0xa>(0.f, v);
     v += dpp_mov<MMU_DPP_ROW_BCAST31, 0xc>(0.f, v);
     return v;
-#endif
 }
 
 // inclusive prefix / suffix sums within each 16-lane DPP row (4 steps, no cross-row traffic)

@@ -306,7 +306,7 @@ extern "C" int mmu_zigzag_inproj_bwd(const mmu_coords_params *p, void *stream) {
               "zigzag_inproj_bwd: offset, in_proj_weight, dxz, doffset, din_proj_weight required");
     CoordArgs a = to_args(p);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(a.dwin, 0, sizeof(float) * 4 * p->taps * p->taps, st) != hipSuccess)
+    if (mmu_zero_async(a.dwin, (size_t)4 * p->taps * p->taps, st) != hipSuccess)
         return mmu_fail("zigzag_inproj_bwd: memset failed");
     DISPATCH_K(zigzag_inproj_bwd_kernel, reduce_blocks((long)a.B * a.H * a.W), st, a);
     MMU_HIP_LAUNCH_CHECK("zigzag_inproj_bwd");
@@ -330,8 +330,8 @@ extern "C" int mmu_coords_outproj_bwd(const mmu_coords_params *p, void *stream) 
               "coords_outproj_bwd: out_proj_weight, altho, out_z, dy, doffset, dout_z, dout_proj_weight, daltho required");
     CoordArgs a = to_args(p);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(a.dwout, 0, sizeof(float) * 2 * p->taps * p->taps, st) != hipSuccess ||
-        hipMemsetAsync(a.daltho, 0, sizeof(float), st) != hipSuccess)
+    if (mmu_zero_async(a.dwout, (size_t)2 * p->taps * p->taps, st) != hipSuccess ||
+        mmu_zero_async(a.daltho, 1, st) != hipSuccess)
         return mmu_fail("coords_outproj_bwd: memset failed");
     DISPATCH_K(coords_outproj_bwd_kernel, reduce_blocks((long)a.B * a.H * a.W), st, a);
     MMU_HIP_LAUNCH_CHECK("coords_outproj_bwd");

@@ -30,13 +30,30 @@ struct MorphArgs {
     int B, C, H, W, K, cs;  // cs = channel slices (grid.z = B * cs)
     int reach;              // gather window in rows (< 0: scatter everything, din pre-zeroed)
     long so_b, so_c, so_h, so_k;  // element strides of out / dout (unit stride along w)
-    const float *in;        // [B, C, H, W]
+    const void *in;         // [B, C, H, W], in_t (float or bf16_t: activations under autocast)
     const float *y;         // [B, K, H, W]  row coordinate in pixels (unclamped)
     float *out;             // [B, C, H*K, W] or [C, K, B, H, W] (so_* strides)
     const float *dout;      // same layout as out
-    float *din;             // [B, C, H, W]  zero-initialised by the caller (atomics)
+    void *din;              // [B, C, H, W], in_t
     float *dy;              // [B, K, H, W]  zero-initialised when cs > 1
 };
+
+// += on an element of d input (the rare far-outlier contributions): float atomics, or for bf16 a CAS loop on the
+// 32-bit word that holds the element
+__device__ __forceinline__ void din_add(float *p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void din_add(bf16_t *p, float v) {
+    unsigned *word = reinterpret_cast<unsigned *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+    const bool hi = (reinterpret_cast<uintptr_t>(p) & 2) != 0;
+    unsigned old = *word, assumed;
+    do {
+        assumed = old;
+        bf16_t cur;
+        cur.bits = (uint16_t)(hi ? assumed >> 16 : assumed & 0xffffu);
+        const unsigned nb = from_f32<bf16_t>(to_f32(cur) + v).bits;
+        const unsigned repl = hi ? ((assumed & 0x0000ffffu) | (nb << 16)) : ((assumed & 0xffff0000u) | nb);
+        old = atomicCAS(word, assumed, repl);
+    } while (old != assumed);
+}
 
 __device__ __forceinline__ bool decode(const MorphArgs &p, int &b, int &k, int &h, int &w, int &c0, int &c1) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,6 +71,7 @@ __device__ __forceinline__ bool decode(const MorphArgs &p, int &b, int &k, int &
     return c0 < c1;
 }
 
+template <typename in_t>
 __global__ __launch_bounds__(256) void morph_sample_fwd_kernel(MorphArgs p) {
     int b, k, h, w, c0, c1;
     if (!decode(p, b, k, h, w, c0, c1)) return;
@@ -65,19 +83,20 @@ __global__ __launch_bounds__(256) void morph_sample_fwd_kernel(MorphArgs p) {
     const bool has1 = y0 + 1 <= p.H - 1;
     int col = w + k - p.K / 2;
     col = col < 0 ? 0 : (col > p.W - 1 ? p.W - 1 : col);
-    const float *src = p.in + ((long)b * p.C + c0) * HW + (long)y0 * p.W + col;
+    const in_t *src = static_cast<const in_t *>(p.in) + ((long)b * p.C + c0) * HW + (long)y0 * p.W + col;
     float *dst = p.out + b * p.so_b + c0 * p.so_c + h * p.so_h + k * p.so_k + w;
     const long ostride = p.so_c;
 #pragma unroll 4
     for (int c = c0; c < c1; ++c) {
-        const float v0 = src[0];
-        const float v1 = has1 ? src[p.W] : 0.f;
+        const float v0 = to_f32(src[0]);
+        const float v1 = has1 ? to_f32(src[p.W]) : 0.f;
         *dst = fmaf(wy, v1 - v0, v0);
         src += HW;
         dst += ostride;
     }
 }
 
+template <typename in_t>
 __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
     int b, k, h, w, c0, c1;
     if (!decode(p, b, k, h, w, c0, c1)) return;
@@ -91,8 +110,8 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
     int col = w + k - p.K / 2;
     col = col < 0 ? 0 : (col > p.W - 1 ? p.W - 1 : col);
     const long ioff = ((long)b * p.C + c0) * HW + (long)y0 * p.W + col;
-    const float *src = p.in + ioff;
-    float *gin = p.din + ioff;
+    const in_t *src = static_cast<const in_t *>(p.in) + ioff;
+    in_t *gin = static_cast<in_t *>(p.din) + ioff;
     const float *g = p.dout + b * p.so_b + c0 * p.so_c + h * p.so_h + k * p.so_k + w;
     const long ostride = p.so_c;
     // targets the gather kernel does not see (further than `reach` rows from the source row h)
@@ -102,8 +121,8 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
     if (!far0 && !far1) {
 #pragma unroll 4
         for (int c = c0; c < c1; ++c) {
-            const float v0 = src[0];
-            const float v1 = has1 ? src[p.W] : 0.f;
+            const float v0 = to_f32(src[0]);
+            const float v1 = has1 ? to_f32(src[p.W]) : 0.f;
             acc = fmaf(*g, v1 - v0, acc);
             src += HW;
             g += ostride;
@@ -111,11 +130,11 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
     } else {
         for (int c = c0; c < c1; ++c) {
             const float gv = *g;
-            const float v0 = src[0];
-            const float v1 = has1 ? src[p.W] : 0.f;
+            const float v0 = to_f32(src[0]);
+            const float v1 = has1 ? to_f32(src[p.W]) : 0.f;
             acc = fmaf(gv, v1 - v0, acc);
-            if (far0) atomicAdd(gin, gv * (1.f - wy));
-            if (far1) atomicAdd(gin + p.W, gv * wy);
+            if (far0) din_add(gin, gv * (1.f - wy));
+            if (far1) din_add(gin + p.W, gv * wy);
             src += HW;
             gin += HW;
             g += ostride;
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
 }
 
 // d input as a gather (see the header).  grid (ceil(H*W / 256), 1, B * ceil(C / CS)); thread = (yy, col).
-template <int CS>
+template <int CS, typename in_t>
 __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const int HW = p.H * p.W;
@@ -173,10 +192,10 @@ __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
             }
         }
     }
-    float *dst = p.din + ((long)b * p.C + c0) * HW + pos;
+    in_t *dst = static_cast<in_t *>(p.din) + ((long)b * p.C + c0) * HW + pos;
 #pragma unroll
     for (int c = 0; c < CS; ++c)
-        if (c < nc) dst[(long)c * HW] = acc[c];
+        if (c < nc) dst[(long)c * HW] = from_f32<in_t>(acc[c]);
 }
 
 int channel_slices(int B, int C, int positions) {
@@ -204,6 +223,8 @@ int check(const mmu_morph_params *p, const char *name) {
               "%s: tensor too large for 32-bit positions", name);
     MMU_CHECK(p->out_layout == MMU_MORPH_BCHW || p->out_layout == MMU_MORPH_TOKENS_LAST, "%s: unknown out_layout %d",
               name, p->out_layout);
+    MMU_CHECK(p->in_dtype == MMU_DTYPE_F32 || p->in_dtype == MMU_DTYPE_BF16, "%s: unsupported in_dtype %d", name,
+              p->in_dtype);
     return 0;
 }
 
@@ -219,7 +240,10 @@ extern "C" int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream) {
     const int positions = a.K * a.H * a.W;
     a.cs = channel_slices(a.B, a.C, positions);
     dim3 grid((positions + 255) / 256, 1, a.B * a.cs);
-    morph_sample_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    if (p->in_dtype == MMU_DTYPE_BF16)
+        morph_sample_fwd_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else
+        morph_sample_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     MMU_HIP_LAUNCH_CHECK("morph_sample_fwd");
     return 0;
 }
@@ -239,15 +263,21 @@ extern "C" int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream) {
     {
         constexpr int CS = 16;
         dim3 gg((a.H * a.W + 255) / 256, 1, a.B * ((a.C + CS - 1) / CS));
-        morph_gather_din_kernel<CS><<<gg, 256, 0, st>>>(a);
+        if (p->in_dtype == MMU_DTYPE_BF16)
+            morph_gather_din_kernel<CS, bf16_t><<<gg, 256, 0, st>>>(a);
+        else
+            morph_gather_din_kernel<CS, float><<<gg, 256, 0, st>>>(a);
         MMU_HIP_LAUNCH_CHECK("morph_gather_din");
     }
     if (a.cs > 1) {
-        hipError_t e = hipMemsetAsync(a.dy, 0, sizeof(float) * (size_t)a.B * positions, st);
+        hipError_t e = mmu_zero_async(a.dy, (size_t)a.B * positions, st);
         if (e != hipSuccess) return mmu_fail("morph_sample_bwd: memset: %s", hipGetErrorString(e));
     }
     dim3 grid((positions + 255) / 256, 1, a.B * a.cs);
-    morph_sample_bwd_kernel<<<grid, 256, 0, st>>>(a);
+    if (p->in_dtype == MMU_DTYPE_BF16)
+        morph_sample_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
+    else
+        morph_sample_bwd_kernel<float><<<grid, 256, 0, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("morph_sample_bwd");
     return 0;
 }

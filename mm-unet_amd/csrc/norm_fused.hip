@@ -13,6 +13,7 @@
 // t1 = sum_hw g2, t2 = sum_hw g2 x  (g2 = dout * act'(y2)) per (batch, channel) -- one pass for those and one
 // for  dx = c0_bc g2 + c1_bc x + c2_bc  (derivation in norm_fused.py).  The per-(b, c) algebra runs in a
 // single small workgroup in double precision.
+#include <type_traits>
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
 
@@ -52,33 +53,26 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 
 // moments per (b, c): grid (B*C), block 256.  BWD: t1 = sum g2, t2 = sum g2 x with g2 = dout * act'(A x + D)
 // act_out (BWD, residual mode): the forward output relu(A x + D + residual); its sign is the ReLU mask
-template <bool BWD>
-__global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict__ x, const float *__restrict__ dout,
+template <bool BWD, typename xin_t, typename act_t>
+__global__ __launch_bounds__(256) void nf_moments_kernel(const xin_t *__restrict__ x, const act_t *__restrict__ dout,
                                                          const float *__restrict__ A, const float *__restrict__ D,
                                                          float *__restrict__ m1, float *__restrict__ m2, int HW,
-                                                         int act, const float *__restrict__ act_out) {
+                                                         int act, const act_t *__restrict__ act_out) {
     __shared__ float red[8];
     const long base = (long)blockIdx.x * HW;
     const float Av = BWD ? A[blockIdx.x] : 0.f, Dv = BWD ? D[blockIdx.x] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     if ((HW & 3) == 0) {
-        const float4 *xp = reinterpret_cast<const float4 *>(x + base);
-        const float4 *gp = BWD ? reinterpret_cast<const float4 *>(dout + base) : nullptr;
-        const float4 *op = (BWD && act_out) ? reinterpret_cast<const float4 *>(act_out + base) : nullptr;
         for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
-            const float4 v = xp[i];
-            const float xv[4] = {v.x, v.y, v.z, v.w};
+            float xv[4];
+            load_k<xin_t, 4, true>(x + base + 4 * i, 4, true, xv);
             if (BWD) {
-                const float4 g = gp[i];
-                const float gv[4] = {g.x, g.y, g.z, g.w};
-                float ov[4] = {0.f, 0.f, 0.f, 0.f};
-                if (op) {
-                    const float4 o = op[i];
-                    ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
-                }
+                float gv[4], ov[4] = {0.f, 0.f, 0.f, 0.f};
+                load_k<act_t, 4, true>(dout + base + 4 * i, 4, true, gv);
+                if (act_out) load_k<act_t, 4, true>(act_out + base + 4 * i, 4, true, ov);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float g2 = gv[j] * (op ? (ov[j] > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv[j], Dv), act));
+                    const float g2 = gv[j] * (act_out ? (ov[j] > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv[j], Dv), act));
                     s1 += g2;
                     s2 = fmaf(g2, xv[j], s2);
                 }
@@ -92,10 +86,10 @@ __global__ __launch_bounds__(256) void nf_moments_kernel(const float *__restrict
         }
     } else {
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const float xv = x[base + i];
+            const float xv = to_f32(x[base + i]);
             if (BWD) {
-                const float g2 = dout[base + i] * (act_out ? (act_out[base + i] > 0.f ? 1.f : 0.f)
-                                                           : act_grad(fmaf(Av, xv, Dv), act));
+                const float g2 = to_f32(dout[base + i]) * (act_out ? (to_f32(act_out[base + i]) > 0.f ? 1.f : 0.f)
+                                                                   : act_grad(fmaf(Av, xv, Dv), act));
                 s1 += g2;
                 s2 = fmaf(g2, xv, s2);
             } else {
@@ -327,14 +321,17 @@ __global__ __launch_bounds__(1024) void nf_finalize_bwd_kernel(FinArgs p) {
 }
 
 // out = act(A x + D)  |  dx = c0 * dout * act'(A x + D) + c1 x + c2 ;  grid (ceil(HW/1024), B*C), block 256
-template <bool BWD>
-__global__ __launch_bounds__(256) void nf_apply_kernel(const float *__restrict__ x, const float *__restrict__ dout,
+// xin_t: element type of x and of dx; act_t: of out, the residual, dout, the saved forward output, d residual
+template <bool BWD, typename xin_t, typename act_t>
+__global__ __launch_bounds__(256) void nf_apply_kernel(const xin_t *__restrict__ x, const act_t *__restrict__ dout,
                                                        const float *__restrict__ A, const float *__restrict__ D,
                                                        const float *__restrict__ c0, const float *__restrict__ c1,
-                                                       const float *__restrict__ c2, float *__restrict__ out, int HW,
-                                                       int act, int out_cb_batch, const float *__restrict__ res,
-                                                       float *__restrict__ dres) {
+                                                       const float *__restrict__ c2, void *__restrict__ out_, int HW,
+                                                       int act, int out_cb_batch, const act_t *__restrict__ res,
+                                                       act_t *__restrict__ dres) {
     // res: FWD = residual added before the activation; BWD = the forward output (ReLU mask).  dres: BWD only.
+    using out_t = typename std::conditional<BWD, xin_t, act_t>::type;
+    out_t *__restrict__ out = static_cast<out_t *>(out_);
     const int bc = blockIdx.y;
     const float Av = A[bc], Dv = D[bc];
     const float k0 = BWD ? c0[bc] : 0.f, k1 = BWD ? c1[bc] : 0.f, k2 = BWD ? c2[bc] : 0.f;
@@ -348,48 +345,64 @@ __global__ __launch_bounds__(256) void nf_apply_kernel(const float *__restrict__
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= HW) return;
     if ((HW & 3) == 0) {
-        const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-        float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (res) {
-            const float4 r4 = *reinterpret_cast<const float4 *>(res + base + i);
-            rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
-        }
+        float xv[4], o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+        load_k<xin_t, 4, true>(x + base + i, 4, true, xv);
+        if (res) load_k<act_t, 4, true>(res + base + i, 4, true, rv);
         if (BWD) {
-            const float4 g = *reinterpret_cast<const float4 *>(dout + base + i);
-            const float gv[4] = {g.x, g.y, g.z, g.w};
-            float g2[4];
+            float gv[4], g2[4];
+            load_k<act_t, 4, true>(dout + base + i, 4, true, gv);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 g2[j] = gv[j] * (res ? (rv[j] > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv[j], Dv), act));
                 o[j] = fmaf(k0, g2[j], fmaf(k1, xv[j], k2));
             }
-            if (dres) *reinterpret_cast<float4 *>(dres + base + i) = make_float4(g2[0], g2[1], g2[2], g2[3]);
+            if (dres) store_k<act_t, 4, true>(dres + base + i, 4, true, g2);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xv[j], Dv) + rv[j], act);
         }
-        *reinterpret_cast<float4 *>(out + obase + i) = make_float4(o[0], o[1], o[2], o[3]);
+        store_k<out_t, 4, true>(out + obase + i, 4, true, o);
     } else {
         for (int j = 0; j < 4 && i + j < HW; ++j) {
-            const float xv = x[base + i + j];
-            const float rr = res ? res[base + i + j] : 0.f;
+            const float xv = to_f32(x[base + i + j]);
+            const float rr = res ? to_f32(res[base + i + j]) : 0.f;
             if (BWD) {
-                const float g2 = dout[base + i + j] * (res ? (rr > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv, Dv), act));
-                out[obase + i + j] = fmaf(k0, g2, fmaf(k1, xv, k2));
-                if (dres) dres[base + i + j] = g2;
+                const float g2 = to_f32(dout[base + i + j]) * (res ? (rr > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv, Dv), act));
+                out[obase + i + j] = from_f32<out_t>(fmaf(k0, g2, fmaf(k1, xv, k2)));
+                if (dres) dres[base + i + j] = from_f32<act_t>(g2);
             } else {
-                out[obase + i + j] = act_fwd(fmaf(Av, xv, Dv) + rr, act);
+                out[obase + i + j] = from_f32<out_t>(act_fwd(fmaf(Av, xv, Dv) + rr, act));
             }
         }
     }
 }
+
+// runtime dtype codes -> the two element types
+#define NF_TYPES(xd, ad, ...)                                   \
+    do {                                                        \
+        if ((xd) == MMU_DTYPE_F32 && (ad) == MMU_DTYPE_F32) {   \
+            using xin_t = float; using act_t = float;           \
+            __VA_ARGS__                                         \
+        } else if ((xd) == MMU_DTYPE_F32) {                     \
+            using xin_t = float; using act_t = bf16_t;          \
+            __VA_ARGS__                                         \
+        } else if ((ad) == MMU_DTYPE_F32) {                     \
+            using xin_t = bf16_t; using act_t = float;          \
+            __VA_ARGS__                                         \
+        } else {                                                \
+            using xin_t = bf16_t; using act_t = bf16_t;         \
+            __VA_ARGS__                                         \
+        }                                                       \
+    } while (0)
 
 int fill(const mmu_norm_params *p, FinArgs &a, const char *name) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
     MMU_CHECK(p->batch > 0 && p->channels > 0 && p->hw > 0 && p->groups > 0 && p->channels % p->groups == 0,
               "%s: need batch, channels, hw > 0 and channels divisible by groups", name);
     MMU_CHECK(p->act >= 0 && p->act <= 2, "%s: unknown activation %d", name, p->act);
+    MMU_CHECK((p->x_dtype == MMU_DTYPE_F32 || p->x_dtype == MMU_DTYPE_BF16) &&
+                  (p->act_dtype == MMU_DTYPE_F32 || p->act_dtype == MMU_DTYPE_BF16),
+              "%s: unsupported element type (%d, %d)", name, p->x_dtype, p->act_dtype);
     MMU_CHECK((long)p->batch * p->channels < 65536, "%s: batch * channels must be < 65536", name);
     a = FinArgs{};
     a.B = p->batch; a.C = p->channels; a.G = p->groups; a.HW = p->hw; a.has_bn = p->has_bn; a.training = p->training;
@@ -417,11 +430,15 @@ extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int BC = a.B * a.C;
     MMU_CHECK(!p->residual || p->act == ACT_RELU, "norm_fused_fwd: a residual input needs act = ReLU");
-    nf_moments_kernel<false><<<BC, 256, 0, st>>>(p->input, nullptr, nullptr, nullptr, p->s1, p->s2, a.HW, 0, nullptr);
-    nf_finalize_fwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
-    nf_apply_kernel<false><<<grid, 256, 0, st>>>(p->input, nullptr, a.A, a.D, nullptr, nullptr, nullptr, p->out, a.HW,
-                                                  p->act, 0, p->residual, nullptr);
+    NF_TYPES(p->x_dtype, p->act_dtype, {
+        nf_moments_kernel<false, xin_t, act_t><<<BC, 256, 0, st>>>((const xin_t *)p->input, nullptr, nullptr, nullptr, p->s1,
+                                                                  p->s2, a.HW, 0, nullptr);
+        nf_finalize_fwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
+        nf_apply_kernel<false, xin_t, act_t><<<grid, 256, 0, st>>>((const xin_t *)p->input, nullptr, a.A, a.D, nullptr,
+                                                                  nullptr, nullptr, p->out, a.HW, p->act, 0,
+                                                                  (const act_t *)p->residual, nullptr);
+    });
     MMU_HIP_LAUNCH_CHECK("norm_fused_fwd");
     return 0;
 }
@@ -444,11 +461,16 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     a.dpre_bias = p->pre_bias ? p->dpre_bias : nullptr;
     MMU_CHECK((p->act_out == nullptr) == (p->dresidual == nullptr) && (!p->act_out || p->act == ACT_RELU),
               "norm_fused_bwd: act_out and dresidual go together (residual mode, ReLU only)");
-    nf_moments_kernel<true><<<BC, 256, 0, st>>>(p->input, p->dout, a.A, a.D, t1, t2, a.HW, p->act, p->act_out);
-    nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
     dim3 grid((a.HW + 1023) / 1024, BC);
-    nf_apply_kernel<true><<<grid, 256, 0, st>>>(p->input, p->dout, a.A, a.D, a.c0, a.c1, a.c2, p->dinput, a.HW, p->act,
-                                                 p->dinput_channel_major ? a.B : 0, p->act_out, p->dresidual);
+    NF_TYPES(p->x_dtype, p->act_dtype, {
+        nf_moments_kernel<true, xin_t, act_t><<<BC, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
+                                                                 t1, t2, a.HW, p->act, (const act_t *)p->act_out);
+        nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
+        nf_apply_kernel<true, xin_t, act_t><<<grid, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
+                                                                 a.c0, a.c1, a.c2, p->dinput, a.HW, p->act,
+                                                                 p->dinput_channel_major ? a.B : 0,
+                                                                 (const act_t *)p->act_out, (act_t *)p->dresidual);
+    });
     MMU_HIP_LAUNCH_CHECK("norm_fused_bwd");
     return 0;
 }

@@ -161,7 +161,9 @@ class MMConv(nn.Module):
         bias, bias or None): the fused normalisation folds the bias into its statistics."""
         raw = self._offset_conv(input)
         if norm_fused.supported(raw, self.gn_offset):
-            offset = norm_fused.gn_bn_act(raw, self.gn_offset, None, "tanh")   # GroupNorm -> tanh in 2 passes
+            # GroupNorm -> tanh in 2 passes; float32 also under autocast (coordinates: the reference's group_norm and
+            # tanh run in float32 there)
+            offset = norm_fused.gn_bn_act(raw, self.gn_offset, None, "tanh", out_dtype=torch.float32)
         else:
             offset = self.tanh(self.gn_offset(raw))
         # Fused HIP sampler (morph_sample): the tap columns are the integers w + k - K//2, so only the

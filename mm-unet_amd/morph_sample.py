@@ -10,8 +10,9 @@ coordinate map alone:
     yc = clamp(y[b, k, h, w], 0, H-1),  col = clamp(w + k - K//2, 0, W-1)
 
 Gradients: d input (a gather over the reachable sources; float atomics only for far outliers) and d y
-(zero where y was clamped, like torch.clamp).  float32 only -- ``F.grid_sample`` is on autocast's fp32
-list, so the reference computes this step in fp32 under autocast as well.
+(zero where y was clamped, like torch.clamp).  The input (and its gradient) may be bfloat16 -- activations under
+autocast are read as they are; coordinates, interpolation and the samples are float32 (``F.grid_sample`` is on
+autocast's fp32 list, so the reference computes this step in fp32 under autocast as well).
 
 ``tokens_last=True`` returns the samples as the ``(C*K, B*H*W)`` matrix ``[c][k][b][h][w]``: the K x 1 /
 stride K x 1 ``dsc_conv_x`` that consumes them (MMUNet.py:262) is then ``weight.view(Cout, Cin*K) @ samples``
@@ -30,7 +31,7 @@ class MorphSampleFn(torch.autograd.Function):
             raise RuntimeError("morph_sample: input must be (B, C, H, W) and y (B, K, H, W)")
         if y.shape[1] % 2 != 1:
             raise RuntimeError("morph_sample: the number of taps K must be odd")
-        x = input.float().contiguous()
+        x = (input if input.dtype in (torch.float32, torch.bfloat16) else input.float()).contiguous()
         yy = y.float().contiguous()
         B, C, H, W = x.shape
         K = yy.shape[1]
@@ -40,6 +41,7 @@ class MorphSampleFn(torch.autograd.Function):
         p.batch, p.channels, p.height, p.width, p.taps = B, C, H, W, K
         p.out_layout = int(tokens_last)
         p.input, p.y, p.out = x.data_ptr(), yy.data_ptr(), out.data_ptr()
+        p.in_dtype = _lib.dtype_code(x)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_morph_sample_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, yy)
@@ -59,6 +61,7 @@ class MorphSampleFn(torch.autograd.Function):
         p.out_layout = int(ctx.tokens_last)
         p.input, p.y, p.dout = x.data_ptr(), yy.data_ptr(), g.data_ptr()
         p.dinput, p.dy = dinput.data_ptr(), dy.data_ptr()
+        p.in_dtype = _lib.dtype_code(x)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_morph_sample_bwd(p, _lib.stream_of(x)))
         return dinput.to(ctx.in_dtype), dy.to(ctx.y_dtype), None

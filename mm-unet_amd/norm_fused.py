@@ -17,7 +17,11 @@ one apply pass writes act(A x + D).  Backward, with g2 = dout * act'(y2), t1 = s
                            dx = r [gamma_g g1 - M1 - xhat M2]  =  c0 g2 + c1 x + c2    (per-(b, c) constants)
 
 so the backward is one pass for (t1, t2) and one for dx.  As separate ATen / MIOpen ops the chain makes 8
-passes over the activation forward and 13 backward.  float32 NCHW contiguous.
+passes over the activation forward and 13 backward.  NCHW contiguous; the input is float32 or bfloat16 (what its
+producer emits: the tokens-last GEMM float32, a library convolution under autocast bfloat16), the output is
+bfloat16 under bf16 autocast (and for a bfloat16 input) and float32 otherwise; statistics, parameters and all
+arithmetic are float32 (group_norm / batch_norm are on autocast's float32 list: the reference computes them in
+float32 there as well and rounds the result once).
 """
 import torch
 import torch.nn as nn
@@ -25,17 +29,30 @@ import torch.nn as nn
 from . import _lib
 
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+_IO = (torch.float32, torch.bfloat16)
+
+
+def _out_dtype(x):
+    """bfloat16 under bf16 autocast or for a bfloat16 input, float32 otherwise."""
+    if x.dtype == torch.bfloat16:
+        return torch.bfloat16
+    if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+        return torch.bfloat16
+    return torch.float32
 
 
 class GnBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gn_w, gn_b, bn_w, bn_b, pre_bias, run_mean, run_var, groups, gn_eps, has_bn, training, bn_eps,
-                momentum, act, grad_cb=False, residual=None):
+                momentum, act, grad_cb=False, residual=None, out_dtype=None):
         _lib.require_gpu(x)
+        if x.dtype not in _IO:
+            raise RuntimeError("gn_bn_act: float32 or bfloat16 input required")
         x = x.contiguous()
         B, C, H, W = x.shape
         dev, f32 = x.device, torch.float32
-        out = torch.empty_like(x)
+        act_dtype = out_dtype if out_dtype is not None else _out_dtype(x)
+        out = torch.empty(x.shape, device=dev, dtype=act_dtype)
         stats = torch.empty(4 * B * C + 2 * B * groups + 2 * C, device=dev, dtype=f32)
         s1, s2, scale, shift = (stats[i * B * C:(i + 1) * B * C] for i in range(4))
         mu = stats[4 * B * C:4 * B * C + B * groups]
@@ -47,6 +64,7 @@ class GnBnActFn(torch.autograd.Function):
         p.has_bn, p.training, p.act, p.has_gn = int(has_bn), int(training), act, int(gn_eps >= 0)
         p.gn_eps, p.bn_eps, p.momentum = max(gn_eps, 0.0), bn_eps, momentum
         p.input, p.out = x.data_ptr(), out.data_ptr()
+        p.x_dtype, p.act_dtype = _lib.dtype_code(x), _lib.dtype_code(out)
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
         p.pre_bias = _lib.ptr(pre_bias)
         ctx.res_dtype = None
@@ -54,21 +72,22 @@ class GnBnActFn(torch.autograd.Function):
             if residual.shape != x.shape or residual.device != x.device:
                 raise RuntimeError("gn_bn_act: residual must have the shape / device of the input")
             ctx.res_dtype = residual.dtype
-            residual = residual.float().contiguous()     # (bf16 under autocast: the sum is fp32 there as well)
+            residual = residual.to(act_dtype).contiguous()   # (read in the output's type; the sum itself is fp32)
             p.residual = residual.data_ptr()
         for name, t in (("gn weight", gn_w), ("gn bias", gn_b), ("bn weight", bn_w), ("bn bias", bn_b),
                         ("pre_bias", pre_bias), ("running_mean", run_mean), ("running_var", run_var)):
             if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C
                                   or t.device != dev):
                 raise RuntimeError(f"gn_bn_act: {name} must be a contiguous float32 vector of {C} elements on {dev}")
-        if x.dtype != torch.float32 or C % groups != 0:
-            raise RuntimeError("gn_bn_act: float32 input with channels divisible by groups required")
+        if C % groups != 0:
+            raise RuntimeError("gn_bn_act: channels must be divisible by groups")
         p.running_mean, p.running_var = _lib.ptr(run_mean), _lib.ptr(run_var)
         p.s1, p.s2, p.mu, p.rstd = s1.data_ptr(), s2.data_ptr(), mu.data_ptr(), rstd.data_ptr()
         p.bn_mean, p.bn_rstd, p.scale, p.shift = bn_mean.data_ptr(), bn_rstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mmu_norm_fused_fwd(p, _lib.stream_of(x)))
         ctx.has_res = residual is not None
+        ctx.act_dtype = act_dtype
         ctx.save_for_backward(x, gn_w, gn_b, bn_w, bn_b, pre_bias, stats, out if ctx.has_res else None)
         ctx.cfg = (groups, gn_eps, has_bn, training, bn_eps, momentum, act)
         ctx.grad_cb = bool(grad_cb)
@@ -80,11 +99,12 @@ class GnBnActFn(torch.autograd.Function):
         groups, gn_eps, has_bn, training, bn_eps, momentum, act = ctx.cfg
         B, C, H, W = x.shape
         dev, f32 = x.device, torch.float32
-        g = dout.float().contiguous()
+        act_dtype = ctx.act_dtype
+        g = dout.to(act_dtype).contiguous()
         if g.shape != x.shape:
             raise RuntimeError("gn_bn_act backward: gradient shape mismatch")
         if ctx.grad_cb:   # the producer of x is a tokens-last GEMM: hand it its gradient as [C][B][HW] (no copy there)
-            dx = torch.empty((C, B, H, W), device=dev, dtype=f32).permute(1, 0, 2, 3)
+            dx = torch.empty((C, B, H, W), device=dev, dtype=x.dtype).permute(1, 0, 2, 3)
         else:
             dx = torch.empty_like(x)
         L = _lib.lib()
@@ -100,10 +120,11 @@ class GnBnActFn(torch.autograd.Function):
         p.has_bn, p.training, p.act, p.has_gn = int(has_bn), int(training), act, int(gn_eps >= 0)
         p.gn_eps, p.bn_eps, p.momentum = max(gn_eps, 0.0), bn_eps, momentum
         p.input, p.dout, p.dinput = x.data_ptr(), g.data_ptr(), dx.data_ptr()
+        p.x_dtype, p.act_dtype = _lib.dtype_code(x), _lib.dtype_code(g)
         p.dinput_channel_major = int(ctx.grad_cb)
         dres = None
         if ctx.has_res:
-            dres = torch.empty_like(x)
+            dres = torch.empty(x.shape, device=dev, dtype=act_dtype)
             p.act_out, p.dresidual = out_saved.data_ptr(), dres.data_ptr()
         p.gn_weight, p.gn_bias, p.bn_weight, p.bn_bias = (_lib.ptr(t) for t in (gn_w, gn_b, bn_w, bn_b))
         p.pre_bias = _lib.ptr(pre_bias)
@@ -123,12 +144,11 @@ class GnBnActFn(torch.autograd.Function):
         return (dx, dgw if gn_w is not None else None, dgb if gn_b is not None else None,
                 dbw if (has_bn and bn_w is not None) else None, dbb if (has_bn and bn_b is not None) else None,
                 dpb if pre_bias is not None else None, None, None, None, None, None, None, None, None, None, None,
-                dres if dres is None else dres.to(ctx.res_dtype))
+                dres if dres is None else dres.to(ctx.res_dtype), None)
 
 
 def supported(x, gn, bn=None):
-    # (fp32 activations also under autocast: group_norm / batch_norm are on autocast's fp32 list anyway)
-    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and \
+    ok = x.is_cuda and x.dtype in _IO and x.dim() == 4 and \
         x.shape[0] * x.shape[1] < 65536 and isinstance(gn, nn.GroupNorm)
     if bn is not None:
         ok = ok and isinstance(bn, nn.BatchNorm2d) and (bn.track_running_stats or bn.training) and \
@@ -137,12 +157,12 @@ def supported(x, gn, bn=None):
 
 
 def bn_act_supported(x, bn):
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and \
+    return x.is_cuda and x.dtype in _IO and x.dim() == 4 and \
         x.shape[0] * x.shape[1] < 65536 and isinstance(bn, nn.BatchNorm2d) and bn.affine and \
         (bn.track_running_stats or bn.training) and bn.momentum is not None
 
 
-def bn_act(x, bn, act=None, residual=None, pre_bias=None):
+def bn_act(x, bn, act=None, residual=None, pre_bias=None, out_dtype=None):
     """``act(bn(x + pre_bias[None, :, None, None]))`` for an ``nn.BatchNorm2d`` (training or eval statistics): the
     same two-pass kernels with the GroupNorm stage switched off -- BatchNorm and ReLU read and write the
     activation once each way together instead of once each.  ``pre_bias``: the bias of the convolution that
@@ -152,17 +172,18 @@ def bn_act(x, bn, act=None, residual=None, pre_bias=None):
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return GnBnActFn.apply(x, None, None, bn.weight, bn.bias, pre_bias, bn.running_mean, bn.running_var, x.shape[1],
-                           -1.0, True, training, bn.eps, bn.momentum, ACT[act], False, residual)
+                           -1.0, True, training, bn.eps, bn.momentum, ACT[act], False, residual, out_dtype)
 
 
-def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False, residual=None):
+def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False, residual=None, out_dtype=None):
     """``act(bn(gn(x + pre_bias[None, :, None, None])))`` with ``gn`` an ``nn.GroupNorm``, ``bn`` an optional
     ``nn.BatchNorm2d`` (its running statistics are updated in training mode exactly as the module would),
     ``act`` in {None, "relu", "tanh"}; ``pre_bias`` (the bias of the convolution that produced ``x``) is folded
     into the statistics instead of being added to the activation.  ``grad_channel_major``: return d x laid out
     [C][B][HW] (what a tokens-last GEMM producer of ``x`` wants; saves it a transposing copy).  ``residual``
     (needs ``act="relu"``): ``relu(bn(gn(x)) + residual)`` -- the tail of a ResidualBlock (MMUNet.py:455-467) in
-    the same two passes; its gradient ``dout * (out > 0)`` is written by the backward apply pass."""
+    the same two passes; its gradient ``dout * (out > 0)`` is written by the backward apply pass.  ``out_dtype``:
+    float32 / bfloat16 (default: bfloat16 under bf16 autocast or for a bfloat16 input, else float32)."""
     if residual is not None and act != "relu":
         raise ValueError("gn_bn_act: a residual input needs act='relu'")
     has_bn = bn is not None
@@ -172,4 +193,4 @@ def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False,
     return GnBnActFn.apply(x, gn.weight, gn.bias, bn.weight if has_bn else None, bn.bias if has_bn else None,
                            pre_bias, bn.running_mean if has_bn else None, bn.running_var if has_bn else None, gn.num_groups,
                            gn.eps, has_bn, training, bn.eps if has_bn else 0.0, bn.momentum if has_bn else 0.0, ACT[act],
-                           grad_channel_major, residual)
+                           grad_channel_major, residual, out_dtype)

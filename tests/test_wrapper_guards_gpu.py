@@ -39,7 +39,10 @@ def test_norm_fused_guards():
     x = _rnd(2, 8, 6, 10)
     ref = norm_fused.gn_bn_act(x, gn, bn, "relu")
     assert _same_or_raises(lambda: norm_fused.gn_bn_act(x.bfloat16(), gn, bn, "relu"), ref, 2e-2) in ("raised", "converted")
-    assert not norm_fused.supported(x.bfloat16(), gn, bn)          # what mmunet.run_fused consults first
+    assert norm_fused.supported(x.bfloat16(), gn, bn)              # bf16 activations are read natively (round 2)
+    assert not norm_fused.supported(x.half(), gn, bn)              # what mmunet.run_fused consults first
+    with pytest.raises(RuntimeError):
+        norm_fused.gn_bn_act(x.half(), gn, bn, "relu")
     xc = x.to(memory_format=torch.channels_last)
     assert _same_or_raises(lambda: norm_fused.gn_bn_act(xc, gn, bn, "relu"), ref, 1e-6) == "converted"
     with pytest.raises(RuntimeError):                               # 6 channels into 8-channel norms
@@ -174,3 +177,67 @@ def test_conv1d_and_scan_extension_guards():
     out, xs = ss.fwd(u, delta, A, B, C, None, None, None, False)
     with pytest.raises(RuntimeError):
         ss.bwd(u, delta, A, B, C, None, None, None, _rnd(1, 4, 32), xs, out, None, False, False)  # dout length
+
+
+def test_bf16_activations_are_read_and_written_natively():
+    """Round 2: bf16 as an I/O type of the fused MorphMamba chain.  The kernels read bf16
+    activations as they are and compute in float32, so on bf16-representable inputs they must agree with the
+    float32 call to rounding of the OUTPUT only; gradients come back in the input's type."""
+    from mm_unet_amd import norm_fused
+    from mm_unet_amd.conv3x3_small import conv3x3_small
+    from mm_unet_amd.morph_sample import morph_sample
+
+    def pair(*shape, seed=0):
+        a = _rnd(*shape, seed=seed).bfloat16()
+        return a, a.float()
+
+    # conv3x3_small: bf16 input, float32 weights / output
+    xb, xf = pair(2, 16, 8, 12)
+    w, b = _rnd(6, 16, 3, 3, seed=1), _rnd(6, seed=2)
+    xb.requires_grad_(); xf.requires_grad_()
+    wb, wf = w.clone().requires_grad_(), w.clone().requires_grad_()
+    ob, of = conv3x3_small(xb, wb, b), conv3x3_small(xf, wf, b)
+    assert ob.dtype == torch.float32 and torch.allclose(ob, of, atol=1e-5)
+    g = _rnd(*of.shape, seed=3)
+    ob.backward(g); of.backward(g)
+    assert xb.grad.dtype == torch.bfloat16
+    assert torch.allclose(xb.grad.float(), xf.grad, atol=2e-2 * float(xf.grad.abs().max()))
+    assert torch.allclose(wb.grad, wf.grad, atol=1e-4 * float(wf.grad.abs().max()))
+    # morph_sample: bf16 input, float32 coordinates / samples
+    xb, xf = pair(2, 5, 8, 12, seed=4)
+    y = 3.5 + _rnd(2, 3, 8, 12, seed=5)
+    xb.requires_grad_(); xf.requires_grad_()
+    yb, yf = y.clone().requires_grad_(), y.clone().requires_grad_()
+    for tl in (False, True):
+        sb, sf = morph_sample(xb, yb, tokens_last=tl), morph_sample(xf, yf, tokens_last=tl)
+        assert sb.dtype == torch.float32 and torch.allclose(sb, sf, atol=1e-6)
+        g = _rnd(*sf.shape, seed=6)
+        for t_ in (xb, xf, yb, yf):
+            t_.grad = None
+        sb.backward(g); sf.backward(g)
+        assert xb.grad.dtype == torch.bfloat16
+        assert torch.allclose(xb.grad.float(), xf.grad, atol=2e-2 * float(xf.grad.abs().max()))
+        assert torch.allclose(yb.grad, yf.grad, atol=1e-5 * float(yf.grad.abs().max()) + 1e-6)
+    # gn_bn_act: float32 in -> bf16 out under autocast; bf16 in -> bf16 out; residual in either type
+    gn, bn = torch.nn.GroupNorm(2, 8).to(DEV), torch.nn.BatchNorm2d(8).to(DEV).train()
+    x32 = _rnd(2, 8, 6, 12, seed=7).requires_grad_()
+    res = _rnd(2, 8, 6, 12, seed=8)
+    ref = norm_fused.gn_bn_act(x32, gn, bn, "relu", residual=res)
+    gref = _rnd(*ref.shape, seed=9)
+    ref.backward(gref)
+    gx_ref, x32.grad = x32.grad.clone(), None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = norm_fused.gn_bn_act(x32, gn, bn, "relu", residual=res.bfloat16())
+        off = norm_fused.gn_bn_act(x32, gn, None, "tanh", out_dtype=torch.float32)
+    assert out.dtype == torch.bfloat16 and off.dtype == torch.float32
+    assert torch.allclose(out.float(), ref, atol=2e-2)
+    out.backward(gref.bfloat16())
+    assert x32.grad.dtype == torch.float32
+    assert torch.allclose(x32.grad, gx_ref, atol=3e-2 * float(gx_ref.abs().max()))
+    xb16 = x32.detach().bfloat16().requires_grad_()
+    ob16 = norm_fused.gn_bn_act(xb16, gn, bn, "relu")
+    assert ob16.dtype == torch.bfloat16
+    ref16 = norm_fused.gn_bn_act(xb16.detach().float(), gn, bn, "relu")
+    assert torch.allclose(ob16.float(), ref16, atol=2e-2)
+    ob16.backward(gref.bfloat16())
+    assert xb16.grad.dtype == torch.bfloat16 and torch.isfinite(xb16.grad.float()).all()
