@@ -36,7 +36,7 @@ def _out_dtype(x):
     """bfloat16 under bf16 autocast or for a bfloat16 input, float32 otherwise."""
     if x.dtype == torch.bfloat16:
         return torch.bfloat16
-    if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         return torch.bfloat16
     return torch.float32
 
