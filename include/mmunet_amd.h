@@ -201,10 +201,12 @@ int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
  * (src/UM_Net/MMUNet.py:362,384,571-575).  Backward is a gather (no atomics, dinput written in full). */
 typedef struct {
     int32_t planes, in_h, in_w, out_h, out_w;
-    const float *input;  /* fwd: [planes, in_h, in_w] */
-    float *out;          /* fwd: [planes, out_h, out_w] */
-    const float *dout;   /* bwd: [planes, out_h, out_w] */
-    float *dinput;       /* bwd: [planes, in_h, in_w] */
+    const void *input;   /* fwd: [planes, in_h, in_w] */
+    void *out;           /* fwd: [planes, out_h, out_w] */
+    const void *dout;    /* bwd: [planes, out_h, out_w] */
+    void *dinput;        /* bwd: [planes, in_h, in_w] */
+    int32_t dtype;       /* element type of all four: MMU_DTYPE_F32 (0, the default of a zeroed struct) or
+                          * MMU_DTYPE_BF16; the interpolation itself is float32 */
 } mmu_resize_params;
 
 int mmu_bilinear_resize_fwd(const mmu_resize_params *p, void *stream);

@@ -73,7 +73,8 @@ class MorphParams(ctypes.Structure):
 
 class ResizeParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("planes", "in_h", "in_w", "out_h", "out_w")]
-                + [(n, _vp) for n in ("input", "out", "dout", "dinput")])
+                + [(n, _vp) for n in ("input", "out", "dout", "dinput")]
+                + [("dtype", _i32)])
 
 
 class Conv3x3sParams(ctypes.Structure):

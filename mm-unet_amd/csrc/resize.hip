@@ -17,10 +17,10 @@ namespace {
 struct ResizeArgs {
     int planes, H, W, OH, OW;
     float ry, rx;  // (H-1)/(OH-1), (W-1)/(OW-1)
-    const float *in;
-    float *out;
-    const float *dout;
-    float *din;
+    const void *in;     // io_t (float or bf16_t), all four
+    void *out;
+    const void *dout;
+    void *din;
 };
 
 __device__ __forceinline__ void tap(int o, float r, int n, int &i0, int &i1, float &w) {
@@ -31,6 +31,7 @@ __device__ __forceinline__ void tap(int o, float r, int n, int &i0, int &i1, flo
     w = s - (float)i0;
 }
 
+template <typename io_t>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs p) {
     const int xq = (p.OW + 3) / 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs p) {
     int y0, y1;
     float wy;
     tap(oy, p.ry, p.H, y0, y1, wy);
-    const float *r0 = p.in + (plane * p.H + y0) * p.W, *r1 = p.in + (plane * p.H + y1) * p.W;
+    const io_t *in = static_cast<const io_t *>(p.in);
+    const io_t *r0 = in + (plane * p.H + y0) * p.W, *r1 = in + (plane * p.H + y1) * p.W;
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -51,17 +53,18 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs p) {
         int x0, x1;
         float wx;
         tap(ox < p.OW ? ox : p.OW - 1, p.rx, p.W, x0, x1, wx);
-        const float a = fmaf(wx, r0[x1] - r0[x0], r0[x0]);
-        const float b = fmaf(wx, r1[x1] - r1[x0], r1[x0]);
+        const float a0 = to_f32(r0[x0]), b0 = to_f32(r1[x0]);
+        const float a = fmaf(wx, to_f32(r0[x1]) - a0, a0);
+        const float b = fmaf(wx, to_f32(r1[x1]) - b0, b0);
         v[j] = fmaf(wy, b - a, a);
     }
-    float *dst = p.out + (plane * p.OH + oy) * p.OW + q * 4;
+    io_t *dst = static_cast<io_t *>(p.out) + (plane * p.OH + oy) * p.OW + q * 4;
     if ((p.OW & 3) == 0) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        store_k<io_t, 4, true>(dst, 4, true, v);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (q * 4 + j < p.OW) dst[j] = v[j];
+            if (q * 4 + j < p.OW) dst[j] = from_f32<io_t>(v[j]);
     }
 }
 
@@ -81,6 +84,7 @@ __device__ __forceinline__ void src_range(int i, float r, int n_out, int &lo, in
     hi = hi > n_out - 1 ? n_out - 1 : hi;
 }
 
+template <typename io_t>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.planes * p.H * p.W;
@@ -114,13 +118,13 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
         tap(oy, p.ry, p.H, y0, y1, wy);
         const float cy = (y0 == y ? 1.f - wy : 0.f) + (y1 == y ? wy : 0.f);
         if (cy == 0.f) continue;
-        const float *g = p.dout + (plane * p.OH + oy) * p.OW;
+        const io_t *g = static_cast<const io_t *>(p.dout) + (plane * p.OH + oy) * p.OW;
         float row = 0.f;
         if (nx <= XC) {
 #pragma unroll
             for (int j = 0; j < XC; ++j) {
                 const int ox = xlo + j <= xhi ? xlo + j : xhi;
-                row = fmaf(cxs[j], g[ox], row);
+                row = fmaf(cxs[j], to_f32(g[ox]), row);
             }
         } else {
             for (int ox = xlo; ox <= xhi; ++ox) {
@@ -128,18 +132,19 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
                 float wx;
                 tap(ox, p.rx, p.W, x0, x1, wx);
                 const float cx = (x0 == x ? 1.f - wx : 0.f) + (x1 == x ? wx : 0.f);
-                row = fmaf(cx, g[ox], row);
+                row = fmaf(cx, to_f32(g[ox]), row);
             }
         }
         acc = fmaf(cy, row, acc);
     }
-    p.din[idx] = acc;
+    static_cast<io_t *>(p.din)[idx] = from_f32<io_t>(acc);
 }
 
 int fill(const mmu_resize_params *p, ResizeArgs &a, const char *name) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
     MMU_CHECK(p->planes > 0 && p->in_h > 0 && p->in_w > 0 && p->out_h > 0 && p->out_w > 0, "%s: empty tensor", name);
     a.planes = p->planes; a.H = p->in_h; a.W = p->in_w; a.OH = p->out_h; a.OW = p->out_w;
+    MMU_CHECK(p->dtype == MMU_DTYPE_F32 || p->dtype == MMU_DTYPE_BF16, "%s: unsupported dtype %d", name, p->dtype);
     a.ry = a.OH > 1 ? (float)(a.H - 1) / (float)(a.OH - 1) : 0.f;
     a.rx = a.OW > 1 ? (float)(a.W - 1) / (float)(a.OW - 1) : 0.f;
     return 0;
@@ -153,7 +158,10 @@ extern "C" int mmu_bilinear_resize_fwd(const mmu_resize_params *p, void *stream)
     MMU_CHECK(p->input && p->out, "bilinear_resize_fwd: input and out are required");
     a.in = p->input; a.out = p->out;
     const long total = (long)a.planes * a.OH * ((a.OW + 3) / 4);
-    resize_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+    if (p->dtype == MMU_DTYPE_BF16)
+        resize_fwd_kernel<bf16_t><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+    else
+        resize_fwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
     MMU_HIP_LAUNCH_CHECK("bilinear_resize_fwd");
     return 0;
 }
@@ -164,7 +172,10 @@ extern "C" int mmu_bilinear_resize_bwd(const mmu_resize_params *p, void *stream)
     MMU_CHECK(p->dout && p->dinput, "bilinear_resize_bwd: dout and dinput are required");
     a.dout = p->dout; a.din = p->dinput;
     const long total = (long)a.planes * a.H * a.W;
-    resize_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+    if (p->dtype == MMU_DTYPE_BF16)
+        resize_bwd_kernel<bf16_t><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+    else
+        resize_bwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
     MMU_HIP_LAUNCH_CHECK("bilinear_resize_bwd");
     return 0;
 }

@@ -3,8 +3,8 @@
 MM-UNet uses exactly this form everywhere it resizes (src/UM_Net/MMUNet.py:362 RCG edge map, :384
 DecoderBlock x2, :571-575 side outputs to the input size).  ATen's kernel takes 443 us for
 [8, 64, 128, 128] -> 256 x 256 on MI355X and its backward uses float atomics; here the forward is a plain
-streaming kernel and the backward a gather (bit-reproducible).  float32; other dtypes are computed in fp32
-and cast back (``upsample_bilinear2d`` accumulates in fp32 as well).
+streaming kernel and the backward a gather (bit-reproducible).  float32 or bfloat16 I/O (read and written as they
+are, interpolated in float32 as ``upsample_bilinear2d`` does); other dtypes are computed in fp32 and cast back.
 """
 import torch
 
@@ -17,25 +17,27 @@ class BilinearResizeFn(torch.autograd.Function):
         _lib.require_gpu(x)
         if x.dim() != 4:
             raise RuntimeError("bilinear_resize: input must be (B, C, H, W)")
-        xf = x.float().contiguous()
+        xf = (x if x.dtype in (torch.float32, torch.bfloat16) else x.float()).contiguous()
         B, C, H, W = xf.shape
-        out = torch.empty((B, C, out_h, out_w), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, C, out_h, out_w), device=x.device, dtype=xf.dtype)
         p = _lib.ResizeParams()
         p.planes, p.in_h, p.in_w, p.out_h, p.out_w = B * C, H, W, out_h, out_w
         p.input, p.out = xf.data_ptr(), out.data_ptr()
+        p.dtype = _lib.dtype_code(xf)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_bilinear_resize_fwd(p, _lib.stream_of(xf)))
-        ctx.shape, ctx.dtype = (B, C, H, W), x.dtype
+        ctx.shape, ctx.dtype, ctx.io_dtype = (B, C, H, W), x.dtype, xf.dtype
         return out.to(x.dtype)
 
     @staticmethod
     def backward(ctx, dout):
         B, C, H, W = ctx.shape
-        g = dout.float().contiguous()
-        dx = torch.empty((B, C, H, W), device=g.device, dtype=torch.float32)
+        g = dout.to(ctx.io_dtype).contiguous()
+        dx = torch.empty((B, C, H, W), device=g.device, dtype=ctx.io_dtype)
         p = _lib.ResizeParams()
         p.planes, p.in_h, p.in_w, p.out_h, p.out_w = B * C, H, W, g.shape[2], g.shape[3]
         p.dout, p.dinput = g.data_ptr(), dx.data_ptr()
+        p.dtype = _lib.dtype_code(g)
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().mmu_bilinear_resize_bwd(p, _lib.stream_of(g)))
         return dx.to(ctx.dtype), None, None

@@ -218,6 +218,16 @@ def test_bf16_activations_are_read_and_written_natively():
         assert xb.grad.dtype == torch.bfloat16
         assert torch.allclose(xb.grad.float(), xf.grad, atol=2e-2 * float(xf.grad.abs().max()))
         assert torch.allclose(yb.grad, yf.grad, atol=1e-5 * float(yf.grad.abs().max()) + 1e-6)
+    # bilinear_resize: bf16 in -> bf16 out, interpolated in float32
+    from mm_unet_amd.resize import bilinear_resize
+    xb, xf = pair(2, 3, 9, 14, seed=10)
+    xb.requires_grad_(); xf.requires_grad_()
+    rb, rf = bilinear_resize(xb, size=(18, 28)), bilinear_resize(xf, size=(18, 28))
+    assert rb.dtype == torch.bfloat16 and torch.allclose(rb.float(), rf, atol=1e-2 * float(rf.abs().max()))
+    g = _rnd(*rf.shape, seed=11).bfloat16()
+    rb.backward(g); rf.backward(g.float())
+    assert xb.grad.dtype == torch.bfloat16
+    assert torch.allclose(xb.grad.float(), xf.grad, atol=1e-2 * float(xf.grad.abs().max()))
     # gn_bn_act: float32 in -> bf16 out under autocast; bf16 in -> bf16 out; residual in either type
     gn, bn = torch.nn.GroupNorm(2, 8).to(DEV), torch.nn.BatchNorm2d(8).to(DEV).train()
     x32 = _rnd(2, 8, 6, 12, seed=7).requires_grad_()
