@@ -31,7 +31,10 @@ print(f'steady steps: {n_steps}; GPU-busy ms/step {sub.dur.sum()/1e6/n_steps:.1f
 for name, r in g.head(top).iterrows():
     print(f"{r['sum']/1e6/n_steps:8.2f} ms/step  calls/step {r['count']/n_steps:6.0f}  avg {r['sum']/r['count']/1e3:9.1f} us  {name}")
 cat = lambda pat: sub[sub.s.str.contains(pat)].dur.sum() / 1e6 / n_steps
-print(f"GEMM {cat('^GEMM'):.1f} | conv(MIOpen/ck/igemm) {cat('igemm|miopen|Conv|conv|ck::|_ZN2ck'):.1f} | "
-      f"elementwise/copy/fill/transpose {cat('elementwise|copy|Fill|transpose|SubTensor'):.1f} | "
-      f"scan {cat('chunk_|reduce_partials|reduce_slices'):.1f} | conv1d {cat('conv1d_'):.1f} | morph {cat('morph_'):.1f} | "
-      f"norm {cat('BatchNorm|Rowwise|GroupNorm|ComputeInternal|batch_norm'):.1f}")
+# (own kernels by family; library convolutions = MIOpen / ck / igemm only: the own conv kernels have their own buckets)
+print(f"GEMM(rocBLAS) {cat('^GEMM'):.1f} | conv(MIOpen/ck/igemm) {cat('igemm|miopen|Sp3Asm|naive_conv|ck::|_ZN2ck'):.1f} | "
+      f"ATen elementwise/copy/fill/reduce {cat('at::native|elementwise|Fill|SubTensor|batched_transpose'):.1f} | "
+      f"scan {cat('chunk_|scan_fwd_stream|reduce_partials|reduce_slices|sum_splits_kernel'):.1f} | conv1d {cat('conv1d_'):.1f} | "
+      f"morph {cat('morph_|zigzag_|coords_'):.1f} | norm(own nf_*) {cat('nf_'):.1f} | norm(library) "
+      f"{cat('BatchNorm|Rowwise|GroupNorm|ComputeInternal|batch_norm'):.1f} | small conv3x3 {cat('conv3x3s_'):.1f} | "
+      f"matrix-core conv/GEMM {cat('conv3x3_mfma|conv3x3_wgrad_mfma|gemm_tokens'):.1f} | small Mamba pre/post {cat('mamba_pre|mamba_post'):.1f}")

@@ -19,3 +19,7 @@ for _, r in df.head(top).iterrows():
     print(f"{r.TotalDurationNs/1e6/steps:8.2f} ms/step  calls/step {r.Calls/steps:6.0f}  avg {r.AverageNs/1e3:9.1f} us  {r.s}")
 print('GEMM total ms/step', df[df.s.str.startswith('GEMM')].TotalDurationNs.sum()/1e6/steps)
 print('elementwise/copy/fill total ms/step', df[df.s.str.contains('elementwise|copy|Fill|transpose')].TotalDurationNs.sum()/1e6/steps)
+for name, pat in (("scan", "chunk_|scan_fwd_stream|reduce_partials|reduce_slices|sum_splits_kernel"), ("fused normalisation (nf_*)", "nf_"),
+                  ("library normalisation", "BatchNorm|Rowwise|GroupNorm|ComputeInternal|batch_norm"),
+                  ("library convolution", "igemm|miopen|Sp3Asm|naive_conv|ck::|_ZN2ck")):
+    print(name, 'total ms/step', df[df.s.str.contains(pat)].TotalDurationNs.sum() / 1e6 / steps)
