@@ -943,3 +943,41 @@ def test_captured_optimizer_step_follows_the_learning_rate():
     step(x, t)
     torch.cuda.synchronize()
     assert torch.equal(before, p_.detach()), "scheduler-set lr = 0 did not reach the replayed step"
+
+
+def test_graph_replays_of_forward_backward_agree():
+    """Round 2 regression (DESIGN.md 7.3): targets of the atomic accumulation paths were zeroed with hipMemsetAsync;
+    captured, those memset nodes did not clear the buffers on replays, and from the second replay on the gradients of
+    the small sizes (sliced d(row) of the sampler, the Mamba projections of every MMConv) were garbage / NaN.  Three
+    replays of the captured forward + backward on fixed weights and inputs must give finite gradients that agree
+    (to the rounding of the float atomics, amplified by the network: loose bound on well-conditioned tensors only)."""
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 64, 64, generator=gen).to(DEV)
+    t = (torch.rand(2, 1, 64, 64, generator=gen) > 0.88).float().to(DEV)
+    m = _mmnet().train()
+    loss_fn = DICE_BCE_Loss()
+    for _ in range(2):
+        loss_fn(m(x), t).backward()
+        m.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = loss_fn(m(x), t)
+        loss.backward()
+    snaps = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        snaps.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        assert all(torch.isfinite(v).all() for v in snaps[-1].values()), "non-finite gradients on a replay"
+    # the Mamba projections inside the MMConvs went through the zeroed-then-accumulated buffers
+    keys = [k for k in snaps[0] if k.endswith(("mamba.in_proj.weight", "mamba.out_proj.weight", "altho"))]
+    assert len(keys) > 100
+    n0 = torch.stack([snaps[0][k].norm() for k in keys])
+    for r in (1, 2):
+        nr = torch.stack([snaps[r][k].norm() for k in keys])
+        rel = ((nr - n0).abs() / (n0 + 1e-12))
+        assert float(rel.median()) < 0.05, f"replay {r}: median relative change of the gradient norms {float(rel.median()):.3f}"
+        assert float((snaps[r]["line_predict.weight"] - snaps[0]["line_predict.weight"]).abs().max()) <= \
+            1e-3 * float(snaps[0]["line_predict.weight"].abs().max())
