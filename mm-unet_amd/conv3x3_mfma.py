@@ -7,13 +7,20 @@ the weight gradient has its own matrix-core kernel (csrc/conv3x3_wgrad_mfma.hip,
 ATen's (MIOpen) otherwise.  float32 NCHW, Cin % 16 == 0, Cout % 64 == 0, W % 4 == 0; anything else
 is the caller's ``F.conv2d``.
 """
+import os
+
 import torch
 
 from . import _lib
 
+# The hi/lo bf16 split drops the lo*lo term: ~2^-16 relative per product against 2^-24 on the library's float32 path
+# (tests pin 5e-5 / 1e-4 on randn data).  ENABLED = False (or MMUNET_CONV3X3_MFMA=0 in the environment) routes every
+# dense 3x3 convolution -- forward, input and weight gradient -- back to ATen / MIOpen for float32-exact runs.
+ENABLED = os.environ.get("MMUNET_CONV3X3_MFMA", "1") != "0"
+
 
 def supported(x, weight):
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] == x.shape[1] and weight.shape[1] % 16 == 0
             and weight.shape[0] % 64 == 0 and x.shape[3] % 4 == 0 and not torch.is_autocast_enabled())
 
