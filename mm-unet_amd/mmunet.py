@@ -406,7 +406,8 @@ class MM_Net(nn.Module):
     def forward(self, x):
         if getattr(self, "_a_batch", None) is None:
             self._a_batch = [precomputed_A(self)]   # in a list: not a sub-module, just the parameter list found once
-        with self._a_batch[0]:          # A = -exp(A_log) of all 50 Mamba blocks in two launches
+        # A = -exp(A_log) of all 50 Mamba blocks in two launches; the 56 BatchNorm batch counters in one
+        with self._a_batch[0], norm_fused.batched_counters():
             return self._forward(x)
 
     def _forward(self, x):

@@ -147,6 +147,32 @@ class GnBnActFn(torch.autograd.Function):
                 dres if dres is None else dres.to(ctx.res_dtype), None)
 
 
+class batched_counters:
+    """Context: the ``num_batches_tracked += 1`` of every BatchNorm2d that runs through this module inside it is
+    collected and applied as ONE multi-tensor add on exit (56 one-element launches per MM_Net training step
+    otherwise).  Same values as the modules' own increments; nothing reads the counters in between (momentum is a
+    number everywhere in MM-UNet)."""
+    _active = None
+
+    def __enter__(self):
+        self._prev, batched_counters._active = batched_counters._active, []
+        return self
+
+    def __exit__(self, *exc):
+        pending, batched_counters._active = batched_counters._active, self._prev
+        if pending and exc[0] is None:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
+def _count_batch(bn):
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if batched_counters._active is not None:
+            batched_counters._active.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+
+
 def supported(x, gn, bn=None):
     ok = x.is_cuda and x.dtype in _IO and x.dim() == 4 and \
         x.shape[0] * x.shape[1] < 65536 and isinstance(gn, nn.GroupNorm)
@@ -169,8 +195,7 @@ def bn_act(x, bn, act=None, residual=None, pre_bias=None, out_dtype=None):
     produced ``x``, folded into the statistics (its gradient comes out of the same backward algebra, so the
     convolution needs neither a bias add nor a bias-gradient reduction over the whole activation)."""
     training = bool(bn.training or not bn.track_running_stats)
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    _count_batch(bn)
     return GnBnActFn.apply(x, None, None, bn.weight, bn.bias, pre_bias, bn.running_mean, bn.running_var, x.shape[1],
                            -1.0, True, training, bn.eps, bn.momentum, ACT[act], False, residual, out_dtype)
 
@@ -188,8 +213,8 @@ def gn_bn_act(x, gn, bn=None, act=None, pre_bias=None, grad_channel_major=False,
         raise ValueError("gn_bn_act: a residual input needs act='relu'")
     has_bn = bn is not None
     training = bool(has_bn and (bn.training or not bn.track_running_stats))
-    if has_bn and bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    if has_bn:
+        _count_batch(bn)
     return GnBnActFn.apply(x, gn.weight, gn.bias, bn.weight if has_bn else None, bn.bias if has_bn else None,
                            pre_bias, bn.running_mean if has_bn else None, bn.running_var if has_bn else None, gn.num_groups,
                            gn.eps, has_bn, training, bn.eps if has_bn else 0.0, bn.momentum if has_bn else 0.0, ACT[act],
