@@ -57,7 +57,9 @@ template <bool BWD, typename xin_t, typename act_t>
 __global__ __launch_bounds__(256) void nf_moments_kernel(const xin_t *__restrict__ x, const act_t *__restrict__ dout,
                                                          const float *__restrict__ A, const float *__restrict__ D,
                                                          float *__restrict__ m1, float *__restrict__ m2, int HW,
-                                                         int act, const act_t *__restrict__ act_out) {
+                                                         int act, const act_t *__restrict__ act_out,
+                                                         const float *__restrict__ pre_bias, int C) {
+    // pre_bias (forward only): the moments written are those of x + pre_bias[c]
     __shared__ float red[8];
     const long base = (long)blockIdx.x * HW;
     const float Av = BWD ? A[blockIdx.x] : 0.f, Dv = BWD ? D[blockIdx.x] : 0.f;
@@ -101,6 +103,11 @@ __global__ __launch_bounds__(256) void nf_moments_kernel(const xin_t *__restrict
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
+        if (!BWD && pre_bias) {
+            const double bv = pre_bias[blockIdx.x % C], d1 = s1, d2 = s2;
+            s1 = (float)(d1 + bv * HW);
+            s2 = (float)(d2 + 2 * bv * d1 + bv * bv * HW);
+        }
         m1[blockIdx.x] = s1;
         m2[blockIdx.x] = s2;
     }
@@ -125,7 +132,103 @@ struct FinArgs {
     float *scratch;                // [2*B*C + 2*B*G + 3*C] floats of workspace for the backward algebra
 };
 
-// one workgroup; all per-(b,c) algebra in double
+// Forward constants of ONE (batch, channel) row, computed by the 256 threads of the apply block that owns the row
+// (round 2: this algebra was a single-workgroup kernel between the two passes -- 7 us of launch chain per call for
+// microseconds of work; every apply block now derives its own A, D from the moments: ~B * C/G * 2 loads and a few
+// hundred double operations, once per row of >= 1,024 elements).  p.s1 / p.s2 already hold the moments of
+// x + pre_bias (nf_moments_kernel).  Results every block needs anyway are also what the backward reads later: the row's
+// block writes A, D; the first channel of a group writes the group statistics of its batch item; batch item 0 writes
+// the channel's BatchNorm statistics and updates the running ones.
+__device__ void nf_fwd_constants(const FinArgs &p, int bc, bool writer, float &A_out, float &D_out) {
+    // writer: exactly one block per row stores the saved statistics / updates the running ones
+    __shared__ double sh_s1[64], sh_s2[64], sh_mu[64], sh_rs[64];   // [b'][channel of the group] / [b']
+    __shared__ float sh_ad[2];
+    const int cpg = p.C / p.G;
+    const int b = bc / p.C, c = bc - b * p.C, g = c / cpg;
+    const double n = (double)cpg * p.HW, N = (double)p.B * p.HW;
+    const int tid = threadIdx.x;
+    // the BatchNorm stage needs the group statistics of every batch item; batch-local if there is no BatchNorm (or
+    // it runs on running statistics)
+    const bool all_b = p.has_bn && p.training;
+    const int b_lo = all_b ? 0 : b, nb = all_b ? p.B : 1;
+    // (B * cpg <= 64 and B <= 64 are checked by the host; larger problems keep the finalize kernel)
+    if (tid < nb * cpg) {
+        const int bb = b_lo + tid / cpg, cc = g * cpg + tid % cpg;
+        sh_s1[tid] = p.s1[bb * p.C + cc];
+        sh_s2[tid] = p.s2[bb * p.C + cc];
+    }
+    __syncthreads();
+    if (tid < nb) {
+        double mu = 0, rs = 1;
+        if (p.has_gn) {
+            double a1 = 0, a2 = 0;
+            for (int j = 0; j < cpg; ++j) {
+                a1 += sh_s1[tid * cpg + j];
+                a2 += sh_s2[tid * cpg + j];
+            }
+            mu = a1 / n;
+            double var = a2 / n - mu * mu;
+            var = var < 0 ? 0 : var;
+            rs = 1.0 / sqrt(var + (double)p.eps_g);
+        }
+        sh_mu[tid] = (double)(float)mu;   // the float values the backward will read back
+        sh_rs[tid] = (double)(float)rs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int jc = c - g * cpg, ib = b - b_lo;
+        const double gw = p.gn_w ? p.gn_w[c] : 1.0, gb = p.gn_b ? p.gn_b[c] : 0.0;
+        double a = gw * sh_rs[ib], d = gb - a * sh_mu[ib];
+        if (writer && jc == 0) {   // the group statistics of this batch item (saved for the backward)
+            p.mu[b * p.G + g] = (float)sh_mu[ib];
+            p.rstd[b * p.G + g] = (float)sh_rs[ib];
+        }
+        if (p.has_bn) {
+            double m, rb;
+            if (p.training) {
+                double sm = 0, sq = 0;
+                for (int bb = 0; bb < p.B; ++bb) {
+                    const double ab = gw * sh_rs[bb], db = gb - ab * sh_mu[bb];
+                    const double s1 = sh_s1[bb * cpg + jc], s2 = sh_s2[bb * cpg + jc];
+                    sm += ab * s1 + db * p.HW;
+                    sq += ab * ab * s2 + 2 * ab * db * s1 + db * db * p.HW;
+                }
+                m = sm / N;
+                double v = sq / N - m * m;
+                v = v < 0 ? 0 : v;
+                rb = 1.0 / sqrt(v + (double)p.eps_b);
+                if (writer && b == 0 && p.run_mean) {
+                    p.run_mean[c] = (float)((1.0 - p.momentum) * p.run_mean[c] + p.momentum * m);
+                    p.run_var[c] = (float)((1.0 - p.momentum) * p.run_var[c] + p.momentum * v * (N > 1 ? N / (N - 1) : 1.0));
+                }
+            } else {
+                m = p.run_mean[c];
+                rb = 1.0 / sqrt((double)p.run_var[c] + (double)p.eps_b);
+            }
+            // the float copies are what the backward reads: use the same rounded values here
+            const float mf = (float)m, rf = (float)rb;
+            if (writer && b == 0) {
+                p.bmean[c] = mf;
+                p.brstd[c] = rf;
+            }
+            const double k = (p.bn_w ? p.bn_w[c] : 1.0) * rf;
+            d = (d - mf) * k + (p.bn_b ? p.bn_b[c] : 0.0);
+            a = a * k;
+        }
+        if (p.pre_bias) d += a * p.pre_bias[c];  // act(A (x + bias) + D) as act(A x + D')
+        if (writer) {
+            p.A[bc] = (float)a;
+            p.D[bc] = (float)d;
+        }
+        sh_ad[0] = (float)a;
+        sh_ad[1] = (float)d;
+    }
+    __syncthreads();
+    A_out = sh_ad[0];
+    D_out = sh_ad[1];
+}
+
+// one workgroup; all per-(b,c) algebra in double (forward: only for shapes nf_fwd_constants does not take)
 __global__ __launch_bounds__(1024) void nf_finalize_fwd_kernel(FinArgs p) {
     const int cpg = p.C / p.G;
     const double n = (double)cpg * p.HW, N = (double)p.B * p.HW;
@@ -377,6 +480,29 @@ __global__ __launch_bounds__(256) void nf_apply_kernel(const xin_t *__restrict__
     }
 }
 
+// Forward apply with the constants computed in its prologue (nf_fwd_constants): grid (splits, B*C), block 256; a block
+// walks its share of ONE (batch, channel) row.  HW % 4 == 0.
+template <typename xin_t, typename act_t>
+__global__ __launch_bounds__(256) void nf_apply_fwd_fused_kernel(FinArgs p, const xin_t *__restrict__ x,
+                                                                 act_t *__restrict__ out, const act_t *__restrict__ res,
+                                                                 int act) {
+    const int bc = blockIdx.y;
+    float Av, Dv;
+    nf_fwd_constants(p, bc, blockIdx.x == 0, Av, Dv);
+    const long base = (long)bc * p.HW;
+    const int n4 = p.HW / 4;
+    const int per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(lo + per, n4);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        float xv[4], o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+        load_k<xin_t, 4, true>(x + base + 4 * i, 4, true, xv);
+        if (res) load_k<act_t, 4, true>(res + base + 4 * i, 4, true, rv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xv[j], Dv) + rv[j], act);
+        store_k<act_t, 4, true>(out + base + 4 * i, 4, true, o);
+    }
+}
+
 // runtime dtype codes -> the two element types
 #define NF_TYPES(xd, ad, ...)                                   \
     do {                                                        \
@@ -431,13 +557,26 @@ extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
     const int BC = a.B * a.C;
     MMU_CHECK(!p->residual || p->act == ACT_RELU, "norm_fused_fwd: a residual input needs act = ReLU");
     dim3 grid((a.HW + 1023) / 1024, BC);
+    // the per-(b, c) algebra runs in the apply kernel's prologue when its LDS tables hold the problem (always in
+    // MM-UNet); otherwise in the single-workgroup kernel between the passes
+    const int cpg = a.C / a.G;
+    const bool fused = (a.HW & 3) == 0 && a.B * cpg <= 64 && a.B <= 64 && getenv("MMU_NF_FINALIZE_KERNEL") == nullptr;
     NF_TYPES(p->x_dtype, p->act_dtype, {
         nf_moments_kernel<false, xin_t, act_t><<<BC, 256, 0, st>>>((const xin_t *)p->input, nullptr, nullptr, nullptr, p->s1,
-                                                                  p->s2, a.HW, 0, nullptr);
-        nf_finalize_fwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
-        nf_apply_kernel<false, xin_t, act_t><<<grid, 256, 0, st>>>((const xin_t *)p->input, nullptr, a.A, a.D, nullptr,
-                                                                  nullptr, nullptr, p->out, a.HW, p->act, 0,
-                                                                  (const act_t *)p->residual, nullptr);
+                                                                  p->s2, a.HW, 0, nullptr, fused ? p->pre_bias : nullptr,
+                                                                  a.C);
+        if (fused) {
+            // a few thousand workgroups at most, each with >= 4 KB of the row
+            int splits = (a.HW / 4 + 4095) / 4096;
+            while (splits > 1 && (long)splits * BC > 8192) --splits;
+            nf_apply_fwd_fused_kernel<xin_t, act_t><<<dim3(splits, BC), 256, 0, st>>>(
+                a, (const xin_t *)p->input, (act_t *)p->out, (const act_t *)p->residual, p->act);
+        } else {
+            nf_finalize_fwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
+            nf_apply_kernel<false, xin_t, act_t><<<grid, 256, 0, st>>>((const xin_t *)p->input, nullptr, a.A, a.D, nullptr,
+                                                                      nullptr, nullptr, p->out, a.HW, p->act, 0,
+                                                                      (const act_t *)p->residual, nullptr);
+        }
     });
     MMU_HIP_LAUNCH_CHECK("norm_fused_fwd");
     return 0;
@@ -464,7 +603,7 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     dim3 grid((a.HW + 1023) / 1024, BC);
     NF_TYPES(p->x_dtype, p->act_dtype, {
         nf_moments_kernel<true, xin_t, act_t><<<BC, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
-                                                                 t1, t2, a.HW, p->act, (const act_t *)p->act_out);
+                                                                 t1, t2, a.HW, p->act, (const act_t *)p->act_out, nullptr, a.C);
         nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
         nf_apply_kernel<true, xin_t, act_t><<<grid, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
                                                                  a.c0, a.c1, a.c2, p->dinput, a.HW, p->act,
