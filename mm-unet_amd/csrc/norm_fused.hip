@@ -480,6 +480,139 @@ __global__ __launch_bounds__(256) void nf_apply_kernel(const xin_t *__restrict__
     }
 }
 
+// Backward constants of ONE (batch, channel) row, by the apply block that owns it: the algebra of
+// nf_finalize_bwd_kernel restricted to the row's group -- every quantity of (b, c) depends only on the moments of the
+// B x C/G rows of its group.  t2 is shifted by pre_bias here (the finalize kernel did it in place).  The row's block of
+// batch item 0 writes the channel's parameter gradients.  Intermediates stay in double (the kernel rounded some of
+// them to float on their way through global memory).
+__device__ void nf_bwd_constants(const FinArgs &p, int bc, bool writer, float &c0_out, float &c1_out, float &c2_out) {
+    __shared__ double T1[64], T2[64], S1[64], S2[64], U1[64], U2[64];   // [b'][channel of the group]
+    __shared__ double MU[64], RS[64], M1s[64], M2s[64];                  // [b']
+    __shared__ double KK[64], EE[64], FF[64], MX[64], GW[64], GB[64], RB[64];   // [channel of the group]
+    __shared__ float sh_c[3];
+    const int cpg = p.C / p.G;
+    const int b = bc / p.C, c = bc - b * p.C, g = c / cpg, jc0 = c - g * cpg;
+    const double n = (double)cpg * p.HW, N = (double)p.B * p.HW, HW = p.HW;
+    const int tid = threadIdx.x;
+    if (tid < p.B * cpg) {
+        const int bb = tid / cpg, cc = g * cpg + tid % cpg;
+        const double t1 = p.t1[bb * p.C + cc];
+        T1[tid] = t1;
+        T2[tid] = (double)p.t2[bb * p.C + cc] + (p.pre_bias ? (double)p.pre_bias[cc] * t1 : 0.0);   // sum_hw g2 (x + bias)
+        S1[tid] = p.s1[bb * p.C + cc];
+        S2[tid] = p.s2[bb * p.C + cc];
+    }
+    if (tid >= 64 && tid < 64 + p.B) {
+        MU[tid - 64] = p.mu[(tid - 64) * p.G + g];
+        RS[tid - 64] = p.rstd[(tid - 64) * p.G + g];
+    }
+    if (tid >= 128 && tid < 128 + cpg) {
+        const int cc = g * cpg + tid - 128;
+        GW[tid - 128] = p.gn_w ? p.gn_w[cc] : 1.0;
+        GB[tid - 128] = p.gn_b ? p.gn_b[cc] : 0.0;
+        RB[tid - 128] = p.has_bn ? p.brstd[cc] : 1.0;
+    }
+    __syncthreads();
+    if (tid < cpg) {   // per channel of the group: exact batch mean, d(bn weight / bias), k, e, f
+        const int cc = g * cpg + tid;
+        double k = 1, e = 0, f = 0, m = 0;
+        if (p.has_bn) {
+            const double gw = GW[tid], gb = GB[tid], rb = RB[tid];
+            m = p.bmean[cc];
+            if (p.training) {
+                double sm = 0;
+                for (int bb = 0; bb < p.B; ++bb) {
+                    const double a = gw * RS[bb], d = gb - a * MU[bb];
+                    sm += a * S1[bb * cpg + tid] + d * p.HW;
+                }
+                m = sm / N;
+            }
+            double db = 0, dg = 0;
+            for (int bb = 0; bb < p.B; ++bb) {
+                const double a = gw * RS[bb], d = gb - a * MU[bb];
+                const double pq = a * rb, qq = (d - m) * rb;
+                db += T1[bb * cpg + tid];
+                dg += pq * T2[bb * cpg + tid] + qq * T1[bb * cpg + tid];
+            }
+            if (writer && b == 0 && tid == jc0) {
+                if (p.dbn_w) p.dbn_w[cc] = (float)dg;
+                if (p.dbn_b) p.dbn_b[cc] = (float)db;
+            }
+            k = (p.bn_w ? p.bn_w[cc] : 1.0) * rb;
+            if (p.training) {
+                e = db / N;
+                f = dg / N;
+            }
+        }
+        KK[tid] = k; EE[tid] = e; FF[tid] = f; MX[tid] = m;
+    }
+    __syncthreads();
+    if (tid < p.B * cpg) {   // u1 = sum_hw g1, u2 = sum_hw g1 x of every row of the group
+        const int bb = tid / cpg, j = tid % cpg;
+        const double a = GW[j] * RS[bb], d = GB[j] - a * MU[bb];
+        double pq = 0, qq = 0;
+        if (p.has_bn) {
+            pq = a * RB[j];
+            qq = (d - MX[j]) * RB[j];
+        }
+        const double k = KK[j], e = EE[j], f = FF[j];
+        U1[tid] = k * (T1[tid] - e * HW - f * (pq * S1[tid] + qq * HW));
+        U2[tid] = k * (T2[tid] - e * S1[tid] - f * (pq * S2[tid] + qq * S1[tid]));
+    }
+    __syncthreads();
+    if (tid < p.B) {   // group means of gamma g1 and gamma g1 xhat, per batch item
+        double a1 = 0, a2 = 0;
+        for (int j = 0; j < cpg; ++j) {
+            a1 += GW[j] * U1[tid * cpg + j];
+            a2 += GW[j] * RS[tid] * (U2[tid * cpg + j] - MU[tid] * U1[tid * cpg + j]);
+        }
+        M1s[tid] = p.has_gn ? a1 / n : 0.0;
+        M2s[tid] = p.has_gn ? a2 / n : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double gw = GW[jc0], gb = GB[jc0], k = KK[jc0], e = EE[jc0], f = FF[jc0];
+        auto consts = [&](int bb, double &k0, double &k1, double &k2) {
+            const double mu = MU[bb], r = RS[bb];
+            const double a = gw * r, d = gb - a * mu;
+            double pq = 0, qq = 0;
+            if (p.has_bn) {
+                pq = a * RB[jc0];
+                qq = (d - MX[jc0]) * RB[jc0];
+            }
+            const double rgk = r * gw * k;
+            k0 = rgk;
+            k1 = -rgk * f * pq - r * r * M2s[bb];
+            k2 = -rgk * e - rgk * f * qq - r * M1s[bb] + r * r * mu * M2s[bb];
+        };
+        double k0, k1, k2;
+        consts(b, k0, k1, k2);
+        sh_c[0] = (float)k0;
+        sh_c[1] = (float)k1;
+        sh_c[2] = (float)(k2 + (p.pre_bias ? k1 * p.pre_bias[c] : 0.0));   // in terms of the raw x: c1 (x + bias) + c2
+        if (writer && b == 0) {   // this channel's parameter gradients
+            double dw = 0, dbv = 0, dpb = 0;
+            for (int bb = 0; bb < p.B; ++bb) {
+                const double u1 = U1[bb * cpg + jc0], u2 = U2[bb * cpg + jc0];
+                dw += RS[bb] * (u2 - MU[bb] * u1);
+                dbv += u1;
+                if (p.dpre_bias) {
+                    double q0, q1, q2;
+                    consts(bb, q0, q1, q2);
+                    dpb += q0 * T1[bb * cpg + jc0] + q1 * S1[bb * cpg + jc0] + q2 * HW;   // sum_hw dx of row (bb, c)
+                }
+            }
+            if (p.dgn_w) p.dgn_w[c] = (float)dw;
+            if (p.dgn_b) p.dgn_b[c] = (float)dbv;
+            if (p.dpre_bias) p.dpre_bias[c] = (float)dpb;
+        }
+    }
+    __syncthreads();
+    c0_out = sh_c[0];
+    c1_out = sh_c[1];
+    c2_out = sh_c[2];
+}
+
 // Forward apply with the constants computed in its prologue (nf_fwd_constants): grid (splits, B*C), block 256; a block
 // walks its share of ONE (batch, channel) row.  HW % 4 == 0.
 template <typename xin_t, typename act_t>
@@ -500,6 +633,41 @@ __global__ __launch_bounds__(256) void nf_apply_fwd_fused_kernel(FinArgs p, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xv[j], Dv) + rv[j], act);
         store_k<act_t, 4, true>(out + base + 4 * i, 4, true, o);
+    }
+}
+
+// Backward apply with its constants from the prologue (nf_bwd_constants); same grid as the fused forward.
+// out_cb_batch / res (= saved forward output: ReLU mask) / dres as in nf_apply_kernel.
+template <typename xin_t, typename act_t>
+__global__ __launch_bounds__(256) void nf_apply_bwd_fused_kernel(FinArgs p, const xin_t *__restrict__ x,
+                                                                 const act_t *__restrict__ dout, xin_t *__restrict__ dx,
+                                                                 int act, int out_cb_batch, const act_t *__restrict__ res,
+                                                                 act_t *__restrict__ dres) {
+    const int bc = blockIdx.y;
+    float k0, k1, k2;
+    nf_bwd_constants(p, bc, blockIdx.x == 0, k0, k1, k2);
+    const float Av = p.A[bc], Dv = p.D[bc];
+    const long base = (long)bc * p.HW;
+    long obase = base;
+    if (out_cb_batch > 0) {
+        const int b = bc / p.C, c = bc - b * p.C;
+        obase = ((long)c * out_cb_batch + b) * p.HW;
+    }
+    const int n4 = p.HW / 4;
+    const int per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(lo + per, n4);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        float xv[4], gv[4], rv[4] = {0.f, 0.f, 0.f, 0.f}, g2[4], o[4];
+        load_k<xin_t, 4, true>(x + base + 4 * i, 4, true, xv);
+        load_k<act_t, 4, true>(dout + base + 4 * i, 4, true, gv);
+        if (res) load_k<act_t, 4, true>(res + base + 4 * i, 4, true, rv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g2[j] = gv[j] * (res ? (rv[j] > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xv[j], Dv), act));
+            o[j] = fmaf(k0, g2[j], fmaf(k1, xv[j], k2));
+        }
+        if (dres) store_k<act_t, 4, true>(dres + base + 4 * i, 4, true, g2);
+        store_k<xin_t, 4, true>(dx + obase + 4 * i, 4, true, o);
     }
 }
 
@@ -601,14 +769,24 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     MMU_CHECK((p->act_out == nullptr) == (p->dresidual == nullptr) && (!p->act_out || p->act == ACT_RELU),
               "norm_fused_bwd: act_out and dresidual go together (residual mode, ReLU only)");
     dim3 grid((a.HW + 1023) / 1024, BC);
+    const int cpg = a.C / a.G;
+    const bool fused = (a.HW & 3) == 0 && a.B * cpg <= 64 && a.B <= 64 && getenv("MMU_NF_FINALIZE_KERNEL") == nullptr;
     NF_TYPES(p->x_dtype, p->act_dtype, {
         nf_moments_kernel<true, xin_t, act_t><<<BC, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
                                                                  t1, t2, a.HW, p->act, (const act_t *)p->act_out, nullptr, a.C);
-        nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
-        nf_apply_kernel<true, xin_t, act_t><<<grid, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
-                                                                 a.c0, a.c1, a.c2, p->dinput, a.HW, p->act,
-                                                                 p->dinput_channel_major ? a.B : 0,
-                                                                 (const act_t *)p->act_out, (act_t *)p->dresidual);
+        if (fused) {
+            int splits = (a.HW / 4 + 4095) / 4096;
+            while (splits > 1 && (long)splits * BC > 8192) --splits;
+            nf_apply_bwd_fused_kernel<xin_t, act_t><<<dim3(splits, BC), 256, 0, st>>>(
+                a, (const xin_t *)p->input, (const act_t *)p->dout, (xin_t *)p->dinput, p->act,
+                p->dinput_channel_major ? a.B : 0, (const act_t *)p->act_out, (act_t *)p->dresidual);
+        } else {
+            nf_finalize_bwd_kernel<<<1, BC >= 1024 ? 1024 : 256, 0, st>>>(a);
+            nf_apply_kernel<true, xin_t, act_t><<<grid, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
+                                                                     a.c0, a.c1, a.c2, p->dinput, a.HW, p->act,
+                                                                     p->dinput_channel_major ? a.B : 0,
+                                                                     (const act_t *)p->act_out, (act_t *)p->dresidual);
+        }
     });
     MMU_HIP_LAUNCH_CHECK("norm_fused_bwd");
     return 0;
