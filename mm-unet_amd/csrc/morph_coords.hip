@@ -330,8 +330,10 @@ extern "C" int mmu_coords_outproj_bwd(const mmu_coords_params *p, void *stream) 
               "coords_outproj_bwd: out_proj_weight, altho, out_z, dy, doffset, dout_z, dout_proj_weight, daltho required");
     CoordArgs a = to_args(p);
     hipStream_t st = (hipStream_t)stream;
-    if (mmu_zero_async(a.dwout, (size_t)2 * p->taps * p->taps, st) != hipSuccess ||
-        mmu_zero_async(a.daltho, 1, st) != hipSuccess)
+    const size_t nw = (size_t)2 * p->taps * p->taps;
+    const bool together = a.daltho == a.dwout + nw;   // one allocation: one zero fill
+    if (mmu_zero_async(a.dwout, nw + (together ? 1 : 0), st) != hipSuccess ||
+        (!together && mmu_zero_async(a.daltho, 1, st) != hipSuccess))
         return mmu_fail("coords_outproj_bwd: memset failed");
     DISPATCH_K(coords_outproj_bwd_kernel, reduce_blocks((long)a.B * a.H * a.W), st, a);
     MMU_HIP_LAUNCH_CHECK("coords_outproj_bwd");

@@ -108,8 +108,9 @@ class CoordsOutProjFn(torch.autograd.Function):
         g = dy.float().contiguous()
         doff = torch.empty_like(offset)
         doz = torch.empty_like(oz)
-        dw = torch.empty_like(w)
-        da = torch.empty_like(al)
+        # d(out_proj weight) and d(altho) in one allocation: the launcher clears both accumulation targets in one pass
+        wa = torch.empty(w.numel() + 1, device=w.device, dtype=torch.float32)
+        dw, da = wa[:w.numel()].view(w.shape), wa[w.numel():].view(al.shape)
         p = _params(offset, K, ctx.scope)
         p.out_proj_weight, p.altho, p.out_z, p.dy = w.data_ptr(), al.data_ptr(), oz.data_ptr(), g.data_ptr()
         p.doffset, p.dout_z, p.dout_proj_weight, p.daltho = doff.data_ptr(), doz.data_ptr(), dw.data_ptr(), \

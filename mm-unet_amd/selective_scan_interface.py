@@ -20,7 +20,8 @@ What each fused function computes (forward, reference lines :159-224 / :296-365)
     B, C      = row blocks of x_dblT viewed (B, 1, N, L)     (strided views, no transpose copies)
     out_z     = selective_scan(conv_out, delta, A, B, C, D, z, delta_bias, softplus)  -> HIP kernels
     [out      = out_z^T @ out_proj_weight^T + out_proj_bias]
-Backward recomputes conv_out and delta (the reference's checkpoint_lvl=1, :218-219,238-241) and
+Backward recomputes conv_out and delta (the reference's checkpoint_lvl=1, :218-219,238-241; the small fused blocks
+keep them instead) and
 writes dx / dz straight into the two halves of one dxz buffer (:244-245).
 
 No CPU path: tensors must live on the GPU, the HIP library must be present.
@@ -260,8 +261,10 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.checkpoint_lvl = checkpoint_lvl
     ctx.with_out_proj = with_out_proj
     ctx.out_proj_bias_is_None = out_proj_bias is None
-    if checkpoint_lvl >= 1:  # recomputed in the backward pass
+    if checkpoint_lvl >= 1 and not ctx.pre_small:  # recomputed in the backward pass (the reference's checkpoint_lvl=1)
         conv1d_out, delta = None, None
+    # (the small blocks keep both: 2 x 6 channels per token against one more launch per block and step -- the launch
+    #  chain, not memory, is what the 47 small Mamba blocks cost)
     # B and C are views of x_dblT when they are input-dependent: save the matrix, rebuild the views
     ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dblT, x_proj_weight, delta_proj_weight,
                           out_proj_weight if with_out_proj else None, conv1d_out, delta, A,
@@ -286,7 +289,8 @@ def _inner_backward(ctx, dout):
     x, z = xz.chunk(2, dim=1)
     dim = x.shape[1]
     if ctx.checkpoint_lvl == 1 and ctx.pre_small:
-        conv1d_out, _, delta = _pre_small(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, False)
+        if conv1d_out is None:
+            conv1d_out, _, delta = _pre_small(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, False)
     elif ctx.checkpoint_lvl == 1:
         conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
         delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
