@@ -231,6 +231,8 @@ typedef struct {
     float *workspace;       /* fwd: mmu_conv3x3_small_fwd_splits() x (elements of out) floats when splits > 1;
                              * bwd: mmu_conv3x3_small_wgrad_workspace_floats() floats or NULL */
     int32_t in_dtype;       /* MMU_DTYPE_F32 (0, the default of a zeroed struct) or MMU_DTYPE_BF16 */
+    const void *dinput_addend;  /* bwd, optional, shape / type of dinput: dinput = conv gradient + addend (the gradient
+                                 * another consumer of the same input already produced; may alias dinput) */
 } mmu_conv3x3s_params;
 
 /* small images have too few pixels to fill the chip: the forward then slices the input channels and sums the

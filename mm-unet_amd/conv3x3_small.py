@@ -20,9 +20,22 @@ def supported(x, weight):
             and weight.shape[2:] == (3, 3) and weight.shape[0] in SUPPORTED_CO)
 
 
+class GradSlot:
+    """Hand-over of an input gradient between the two consumers of one tensor (MMConv: the offset convolution and
+    the sampler both read the block's input).  The consumer whose backward runs FIRST (the sampler: the convolution's
+    output gradient depends on the sampler's d(row)) parks its input gradient here and returns None; the convolution's
+    backward adds its own contribution to it in the same kernel and returns the sum -- autograd has one gradient to
+    route instead of two to add (41 activation-sized adds per training step).  ``armed`` is set by the convolution's
+    forward when its backward will produce an input gradient."""
+    __slots__ = ("armed", "grad")
+
+    def __init__(self):
+        self.armed, self.grad = False, None
+
+
 class Conv3x3SmallFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, slot=None):
         _lib.require_gpu(x, weight)
         if not supported(x, weight) or weight.shape[1] != x.shape[1] or \
                 (bias is not None and (bias.dtype != torch.float32 or bias.numel() != weight.shape[0])):
@@ -47,6 +60,9 @@ class Conv3x3SmallFn(torch.autograd.Function):
         ctx.save_for_backward(x, wt)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
+        ctx.slot = slot
+        if slot is not None:
+            slot.armed = bool(ctx.needs_input_grad[0])
         return out
 
     @staticmethod
@@ -58,10 +74,16 @@ class Conv3x3SmallFn(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = dw = db = None
         if need_x:
-            dx = torch.empty_like(x)
+            parked = None
+            if ctx.slot is not None and ctx.slot.grad is not None:
+                parked, ctx.slot.grad = ctx.slot.grad, None
+                if parked.shape != x.shape or parked.dtype != x.dtype or not parked.is_contiguous():
+                    raise RuntimeError("conv3x3_small: parked input gradient does not match the input")
+            dx = parked if parked is not None else torch.empty_like(x)     # (in place on the parked gradient)
             p = _lib.Conv3x3sParams()
             p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
             p.input, p.weight_t, p.dout, p.dinput = x.data_ptr(), wt.data_ptr(), g.data_ptr(), dx.data_ptr()
+            p.dinput_addend = _lib.ptr(parked)
             p.in_dtype = _lib.dtype_code(x)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
@@ -86,8 +108,8 @@ class Conv3x3SmallFn(torch.autograd.Function):
                 _, dw, db = torch.ops.aten.convolution_backward(
                     g, x.float(), w, [CO] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                     [False, bool(need_w), bool(need_b)])
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def conv3x3_small(x, weight, bias=None):
-    return Conv3x3SmallFn.apply(x, weight, bias)
+def conv3x3_small(x, weight, bias=None, slot=None):
+    return Conv3x3SmallFn.apply(x, weight, bias, slot)

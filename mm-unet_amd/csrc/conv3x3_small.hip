@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void conv3x3s_sum_splits_kernel(const float *_
 template <int CO, typename in_t>
 __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__restrict__ g, const float *__restrict__ wt,
                                                                 in_t *__restrict__ dx, int B, int Cin, int H, int W,
-                                                                int cps) {
+                                                                int cps, const in_t *__restrict__ addend) {
+    // addend (optional, same shape as dx): dx = conv gradient + addend -- the gradient the OTHER consumer of the
+    // convolution's input already produced (MMConv: the sampler), so that autograd has nothing left to add
     const int wq = (W + 1) / 2;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * H * wq) return;
@@ -144,10 +146,23 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__r
         }
     }
     in_t *dp = dx + ((long)b * Cin + c_lo) * HW + (long)h * W + w0;
+    const in_t *ap = addend ? addend + ((long)b * Cin + c_lo) * HW + (long)h * W + w0 : nullptr;
     const bool two = (W & 1) == 0;
     for (int ci = c_lo; ci < c_hi; ++ci, dp += HW) {
         const float *wc = wt + (long)ci * 9 * CO;
         float a0 = 0.f, a1 = 0.f;
+        if (ap) {
+            const in_t *aq = ap + (long)(ci - c_lo) * HW;
+            if (two) {
+                float t2[2];
+                load_k<in_t, 2, true>(aq, 2, true, t2);
+                a0 = t2[0];
+                a1 = t2[1];
+            } else {
+                a0 = to_f32(aq[0]);
+                a1 = w0 + 1 < W ? to_f32(aq[1]) : 0.f;
+            }
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -454,7 +469,7 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
         dim3 grid((unsigned)((total + 255) / 256), splits);
         CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO, in_t><<<grid, 256, 0, st>>>(
                                          p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
-                                         p->width, cps);)
+                                         p->width, cps, (const in_t *)p->dinput_addend);)
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(data)");
     }
     int lwq = 0, rs = 0, nrb = 0;

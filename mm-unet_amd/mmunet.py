@@ -27,12 +27,12 @@ from .tall_gemm import dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
 
-def _small_conv3x3(c, input):
+def _small_conv3x3(c, input, slot=None):
     """A 3x3 / stride 1 / padding 1 ``nn.Conv2d`` with 1, 2, 6 or 8 output channels through the direct kernels of
     csrc/conv3x3_small.hip (a matrix core has nothing to do there); anything else stays the module's own call."""
     if conv3x3_small.supported(input, c.weight) and c.stride == (1, 1) and c.padding == (1, 1) and \
             c.dilation == (1, 1) and c.groups == 1:
-        return conv3x3_small.conv3x3_small(input, c.weight, c.bias)
+        return conv3x3_small.conv3x3_small(input, c.weight, c.bias, slot)
     return c(input)
 
 
@@ -145,8 +145,8 @@ class MMConv(nn.Module):
                                                m.D.float(), delta_bias=m.dt_proj.bias.float(), delta_softplus=True)
             return morph_coords.coords_outproj(offset, out_z, m.out_proj.weight, self.altho, self.extend_scope)
 
-    def _offset_conv(self, input):
-        return _small_conv3x3(self.offset_conv, input)   # 6 output channels: direct kernels
+    def _offset_conv(self, input, slot=None):
+        return _small_conv3x3(self.offset_conv, input, slot)   # 6 output channels: direct kernels
 
     def forward(self, input):
         """GroupNorm(K x 1 DSC conv(deformable samples)) -- MMUNet.py:244-265."""
@@ -159,7 +159,9 @@ class MMConv(nn.Module):
         """Everything of forward() before the final GroupNorm (run_fused joins that GroupNorm with the
         BatchNorm2d / ReLU that follow the block in its nn.Sequential).  Returns (conv output WITHOUT its
         bias, bias or None): the fused normalisation folds the bias into its statistics."""
-        raw = self._offset_conv(input)
+        # the offset convolution and the sampler both read `input`: their input gradients leave as one (GradSlot)
+        slot = conv3x3_small.GradSlot() if input.requires_grad and torch.is_grad_enabled() else None
+        raw = self._offset_conv(input, slot)
         if norm_fused.supported(raw, self.gn_offset):
             # GroupNorm -> tanh in 2 passes; float32 also under autocast (coordinates: the reference's group_norm and
             # tanh run in float32 there)
@@ -181,10 +183,10 @@ class MMConv(nn.Module):
             # for this conv spent as long in NCHW<->NHWC transposes of the K x inflated tensor as in the math.
             B, _, H, W = input.shape
             conv = self.dsc_conv_x
-            samples = morph_sample(input, y_rows, tokens_last=True)
+            samples = morph_sample(input, y_rows, tokens_last=True, slot=slot)
             output = dsc_gemm(conv.weight.view(conv.out_channels, -1), samples, B).view(B, conv.out_channels, H, W)
             return output, conv.bias
-        return self.dsc_conv_y(morph_sample(input, y_rows)), None
+        return self.dsc_conv_y(morph_sample(input, y_rows, slot=slot)), None
 
 
 def run_fused(seq, x, residual=None):

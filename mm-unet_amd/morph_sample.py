@@ -25,7 +25,7 @@ from . import _lib
 
 class MorphSampleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, input, y, tokens_last=False):
+    def forward(ctx, input, y, tokens_last=False, slot=None):
         _lib.require_gpu(input, y)
         if input.dim() != 4 or y.dim() != 4 or y.shape[0] != input.shape[0] or y.shape[2:] != input.shape[2:]:
             raise RuntimeError("morph_sample: input must be (B, C, H, W) and y (B, K, H, W)")
@@ -46,6 +46,7 @@ class MorphSampleFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_morph_sample_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, yy)
         ctx.in_dtype, ctx.y_dtype, ctx.tokens_last = input.dtype, y.dtype, bool(tokens_last)
+        ctx.slot = slot
         return out
 
     @staticmethod
@@ -64,10 +65,18 @@ class MorphSampleFn(torch.autograd.Function):
         p.in_dtype = _lib.dtype_code(x)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_morph_sample_bwd(p, _lib.stream_of(x)))
-        return dinput.to(ctx.in_dtype), dy.to(ctx.y_dtype), None
+        dinput = dinput.to(ctx.in_dtype)
+        slot = ctx.slot
+        # conv3x3_small.GradSlot: the offset convolution's backward (which needs this call's d(row) and therefore
+        # runs after it) adds its own input gradient to this one and returns the sum
+        if slot is not None and slot.armed and ctx.needs_input_grad[1] and slot.grad is None and x.dtype == ctx.in_dtype:
+            slot.grad = dinput
+            dinput = None
+        return dinput, dy.to(ctx.y_dtype), None, None
 
 
-def morph_sample(input, y, tokens_last=False):
+def morph_sample(input, y, tokens_last=False, slot=None):
     """input (B, C, H, W), y (B, K, H, W) row coordinates in pixels -> (B, C, H*K, W), or the
-    (C*K, B*H*W) matrix ``[c][k][b][h][w]`` with ``tokens_last=True``."""
-    return MorphSampleFn.apply(input, y, tokens_last)
+    (C*K, B*H*W) matrix ``[c][k][b][h][w]`` with ``tokens_last=True``.  ``slot``: a conv3x3_small.GradSlot shared
+    with the offset convolution that reads the same input (see there)."""
+    return MorphSampleFn.apply(input, y, tokens_last, slot)
