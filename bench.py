@@ -225,11 +225,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # rehearsal of the N > 1 path on a one-GPU box (never a measurement): every rank on device 0, gloo instead of RCCL
+    # (RCCL refuses two ranks on one device):  MMUNET_BENCH_REHEARSAL=1 python -m torch.distributed.run ... bench.py
+    rehearsal = os.environ.get("MMUNET_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.roofline_only:
         legs = scan_rooflines(dev)
