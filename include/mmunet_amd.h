@@ -349,6 +349,28 @@ typedef struct {
 size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner);
 int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream);
 
+/* ---- C (m x n) = sum over tokens of A[i][t] * B[j][t]: token-contraction ("NT") product on the fp32 matrix cores - */
+/* The weight gradient of every projection applied per token: in_proj / out_proj / x_proj / dt_proj of the Mamba blocks
+ * (mamba_ssm/ops/selective_scan_interface.py:272-277,394; mamba_simple.py:201-205,270) and MMConv's K x 1 DSC
+ * convolution (src/UM_Net/MMUNet.py:262): dW = G . X^T over batch * seqlen tokens.  Token (b, l) of A's row i is at
+ * a + i*a_rs + b*a_bs + l (same for B): channel-major and batch-major operands are both read in place.  float32 in
+ * and out, float32 accumulation; products on the bf16 matrix pipe from a hi/lo split of each operand element (three
+ * MFMAs per product, ~2^-16 relative per product; HBM-bound), or -- exact_products = 1 -- exact on the fp32 pipe
+ * (v_mfma_f32_32x32x2_f32; bound by that pipe).  Split over the token axis with the slab partials added in a fixed
+ * order (deterministic).  seqlen % 32 == 0; a, b 16-byte aligned; strides multiples of 4.
+ * workspace: mmu_gemm_nt_splitk_workspace_floats() floats. */
+typedef struct {
+    int32_t m, n, batch, seqlen;
+    int32_t exact_products, reserved;
+    const float *a;  int64_t a_rs, a_bs;
+    const float *b;  int64_t b_rs, b_bs;
+    float *c;        /* [m][n] contiguous */
+    float *workspace;
+} mmu_gemm_nt_params;
+
+size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);
+int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream);
+
 /* ---- conv1d + SiLU + x_proj + dt_proj of a small Mamba block in one kernel (a5/a6 glue, MMConv's blocks) ---- */
 /* mamba_ssm/ops/selective_scan_interface.py:173-210 for inner width dim in {2, 6}, conv width 4, dt_rank 1,
  * float32:  conv_out = silu(causal_conv1d(x)),  x_dbl[j] = sum_d x_proj_weight[j][d] conv_out[d]  (rows = dt_rank

@@ -111,6 +111,12 @@ class GemmTokensParams(ctypes.Structure):
                 ("out", _vp), ("out_rs", _i64), ("out_bs", _i64), ("workspace", _vp)]
 
 
+class GemmNtParams(ctypes.Structure):
+    _fields_ = [("m", _i32), ("n", _i32), ("batch", _i32), ("seqlen", _i32), ("exact_products", _i32), ("reserved", _i32),
+                ("a", _vp), ("a_rs", _i64), ("a_bs", _i64), ("b", _vp), ("b_rs", _i64), ("b_bs", _i64),
+                ("c", _vp), ("workspace", _vp)]
+
+
 class MambaPreParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("dim", _i32), ("seqlen", _i32), ("rows", _i32),
                 ("x", _vp), ("x_bs", _i64), ("x_ds", _i64), ("conv_weight", _vp), ("conv_bias", _vp),
@@ -141,7 +147,7 @@ EXPORTS = (
     "mmu_conv3x3_small_wgrad_workspace_floats",
     "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
-    "mmu_gemm_tokens_workspace_bytes", "mmu_mamba_pre_small", "mmu_mamba_post_small",
+    "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_debug_wave_scan",
 )
@@ -179,7 +185,8 @@ def lib():
                      ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
-                     ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams)):
+                     ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams),
+                     ("mmu_gemm_nt_splitk", GemmNtParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -191,6 +198,8 @@ def lib():
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_gemm_tokens_workspace_bytes.restype = ctypes.c_size_t
     L.mmu_gemm_tokens_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mmu_gemm_nt_splitk_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_gemm_nt_splitk_workspace_floats.argtypes = [ctypes.c_int] * 4
     L.mmu_conv3x3_wgrad_mfma_workspace_floats.restype = ctypes.c_size_t
     L.mmu_conv3x3_wgrad_mfma_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_conv3x3_mfma_workspace_bytes.restype = ctypes.c_size_t

@@ -1,6 +1,8 @@
 """``gemm_tokens`` -- ``W (M, K) @ X (K, T)`` for tokens-last ``X`` on the bf16 matrix cores with float32 accuracy
 (csrc/gemm_tokens_mfma.hip; hi/lo bf16 split, three MFMAs per product).  float32 only, M % 64 == 0, K % 16 == 0;
 callers keep their hipBLASLt path for everything else."""
+import os
+
 import torch
 
 from . import _lib
@@ -39,3 +41,36 @@ def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, 
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().mmu_gemm_tokens_mfma(p, _lib.stream_of(x)))
     return out
+
+
+# False (or MMUNET_GEMM_NT=0): callers keep their batched-GEMM split-K (tests compare the two)
+NT_ENABLED = os.environ.get("MMUNET_GEMM_NT", "1") != "0"
+
+
+def nt_supported(a, b, seqlen):
+    """Token-contraction product on the fp32 matrix cores (csrc/gemm_nt_splitk.hip): float32 operands with unit token
+    stride, 16-byte aligned, seqlen a multiple of 32."""
+    return (NT_ENABLED and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and seqlen % 32 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False):
+    """C (m, n) = sum over the batch * seqlen tokens of A[i][t] * B[j][t]; token (bi, l) of row i of ``a`` lies at
+    element offset i * a_rs + bi * a_bs + l of its storage (same for ``b``): channel-major and batch-major operands are
+    both read in place.  float32, deterministic."""
+    _lib.require_gpu(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise RuntimeError("gemm_nt: float32 tensors required")
+    if seqlen % 32 != 0 or any(v % 4 != 0 for v in (a_rs, a_bs, b_rs, b_bs)):
+        raise RuntimeError("gemm_nt: seqlen must be a multiple of 32 and the strides multiples of 4")
+    L = _lib.lib()
+    c = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    ws = torch.empty(L.mmu_gemm_nt_splitk_workspace_floats(m, n, batch, seqlen), device=a.device, dtype=torch.float32)
+    p = _lib.GemmNtParams()
+    p.m, p.n, p.batch, p.seqlen, p.exact_products = m, n, batch, seqlen, int(exact)
+    p.a, p.a_rs, p.a_bs = a.data_ptr(), a_rs, a_bs
+    p.b, p.b_rs, p.b_bs = b.data_ptr(), b_rs, b_bs
+    p.c, p.workspace = c.data_ptr(), ws.data_ptr()
+    with torch.cuda.device(a.device):
+        _lib.check(L.mmu_gemm_nt_splitk(p, _lib.stream_of(a)))
+    return c

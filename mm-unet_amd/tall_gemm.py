@@ -3,8 +3,9 @@
 The reference writes them as plain ``F.linear`` / ``einsum`` (selective_scan_interface.py:181-182,
 272-277, 394; mamba_simple.py:201-205,270).  Their *weight gradients* are ``[I x T] @ [T x J]`` products
 with T = B*L up to 524,288 and I*J <= 4,608: hipBLASLt has no split-K for these and takes up to 1.5 ms
-per call (measured on MI355X; 44 MMConv blocks x 3 such products per step).  Splitting T into slabs
-turns each into one strided batched GEMM + a small sum: 27 us.
+per call (measured on MI355X; 44 MMConv blocks x 3 such products per step).  float32 operands go to the
+token-contraction matrix-core kernel (csrc/gemm_nt_splitk.hip: both layouts read in place, ordered slab sums);
+other dtypes split T into slabs as one strided batched GEMM + a small sum.
 """
 import torch
 
@@ -19,6 +20,8 @@ def nt_splitk(X, Y):
     J = Y.shape[0]
     if T < 4 * _SLAB:
         return X @ Y.t()
+    if X.dtype == Y.dtype and mfma_gemm.nt_supported(X, Y, T) and X.stride(0) % 4 == 0 and Y.stride(0) % 4 == 0:
+        return mfma_gemm.gemm_nt(X, Y, I, J, 1, T, X.stride(0), 0, Y.stride(0), 0)   # one kernel + its slab sum
     S = T // _SLAB
     Tm = S * _SLAB
     Xs = X[:, :Tm].reshape(I, S, _SLAB).transpose(0, 1)          # (S, I, slab) view
@@ -178,7 +181,13 @@ class _ProjBclFn(torch.autograd.Function):
             # one split-K product over all (batch, token) pairs: both operands as (channels, B*L) matrices.  One of the
             # two is batch-major by construction (the layouts meet here); it is brought to channel-major with one
             # transposing copy -- 2-3 launches instead of three per batch item (24 -> 4 for B = 8)
-            dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(X)).to(W.dtype)
+            if (G.stride(2) == 1 and X.stride(2) == 1 and mfma_gemm.nt_supported(G, X, L) and B * L >= 4 * _SLAB
+                    and all(t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 for t in (G, X))):
+                # both layouts addressed in place: no transposing copy of the batch-major operand
+                dW = mfma_gemm.gemm_nt(G, X, W.shape[0], I, B, L, G.stride(1), G.stride(0), X.stride(1),
+                                       X.stride(0)).to(W.dtype)
+            else:
+                dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(X)).to(W.dtype)
         return dW, dX, None
 
 

@@ -683,3 +683,40 @@ def test_conv1d_full_size_shift_property():
     outs = cc.causal_conv1d_fwd(xs, w, None, False)
     close(outs[..., 4:], out[..., :-4], 1e-6, 1e-6, "shift invariance")
     close(cc.causal_conv1d_fwd(3 * x, w, None, False), 3 * out, 1e-5, 1e-5, "linearity")
+
+
+@pytest.mark.parametrize("case", [
+    # (m, n, batch, L, a layout, b layout)   layouts: "cm" = [C][B][L] storage, "bm" = [B][C][L]
+    (256, 64, 2, 1024, "cm", "bm"),       # in_proj weight gradient: G channel-major, X batch-major
+    (64, 128, 3, 512, "bm", "cm"),        # out_proj
+    (36, 128, 2, 2048, "cm", "cm"),       # x_proj: 36 rows (a partial 128-row tile)
+    (128, 4, 2, 1024, "cm", "cm"),        # dt_proj: 4 columns (a partial 64-column tile)
+    (64, 192, 1, 4096, "cm", "cm"),       # DSC weight gradient
+    (200, 70, 2, 96, "bm", "bm"),         # ragged tile counts, three chunks per batch item
+])
+def test_gemm_nt_splitk_vs_float64(case):
+    """csrc/gemm_nt_splitk.hip (token-contraction product on the matrix cores, operands addressed in place in either
+    layout) against a float64 einsum, for the hi/lo-split bf16 form and the exact fp32 form; and bit-reproducible."""
+    from mm_unet_amd import mfma_gemm
+    m, n, b, l, la, lb = case
+    gen = torch.Generator().manual_seed(17)
+
+    def make(rows, layout):
+        t = torch.randn(b, rows, l, generator=gen)
+        if layout == "cm":
+            st = t.permute(1, 0, 2).contiguous().to(DEV)        # storage [rows][B][L]
+            return t, st, b * l, l
+        return t, t.to(DEV), l, rows * l                        # storage [B][rows][L]
+
+    a_ref, a_dev, a_rs, a_bs = make(m, la)
+    b_ref, b_dev, b_rs, b_bs = make(n, lb)
+    assert mfma_gemm.nt_supported(a_dev, b_dev, l)
+    ref = torch.einsum("bil,bjl->ij", a_ref.double(), b_ref.double())
+    # randn operands: a sum of T products has standard deviation sqrt(T); float32 accumulation rounds at 2^-24 of it per
+    # add, the split form adds 2^-16-relative product errors that average out over T
+    for exact, tol in ((False, 2e-5), (True, 4e-6)):
+        c1 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs, exact=exact)
+        c2 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs, exact=exact)
+        assert torch.equal(c1, c2)
+        err = float((c1.double().cpu() - ref).abs().max())
+        assert err <= tol * (b * l) ** 0.5, f"exact={exact}: max abs err {err:.3e}"

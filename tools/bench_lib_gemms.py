@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mm_unet_amd.tall_gemm import nt_splitk  # noqa: E402
+from mm_unet_amd import mfma_gemm  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -37,6 +38,7 @@ for name, m, n, t in cases:
     g = torch.randn(m, t, device=DEV)
     x = torch.randn(n, t, device=DEV)
     byt = 4.0 * t * (m + n)
-    for how, fn in (("one GEMM", lambda: g @ x.t()), ("nt_splitk", lambda: nt_splitk(g, x))):
+    for how, fn in (("one GEMM", lambda: g @ x.t()), ("nt_splitk", lambda: nt_splitk(g, x)),
+                    ("gemm_nt HIP", lambda: mfma_gemm.gemm_nt(g, x, m, n, 1, t, t, 0, t, 0))):
         ms = timeit(fn)
         print(f"{name:42s} {how:10s} {ms*1e3:8.1f} us  {byt/ms/1e6:7.0f} GB/s of operands  {2.0*m*n*t/ms/1e9:7.1f} TFLOP/s")
