@@ -361,7 +361,8 @@ int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream);
  * workspace: mmu_gemm_nt_splitk_workspace_floats() floats. */
 typedef struct {
     int32_t m, n, batch, seqlen;
-    int32_t exact_products, reserved;
+    int32_t exact_products;   /* 1: exact float32 products on the fp32 matrix pipe */
+    int32_t narrow_steps;     /* 1: always the 32-token-step kernel (default: 128-token steps when seqlen % 128 == 0) */
     const float *a;  int64_t a_rs, a_bs;
     const float *b;  int64_t b_rs, b_bs;
     float *c;        /* [m][n] contiguous */

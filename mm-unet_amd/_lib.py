@@ -112,7 +112,7 @@ class GemmTokensParams(ctypes.Structure):
 
 
 class GemmNtParams(ctypes.Structure):
-    _fields_ = [("m", _i32), ("n", _i32), ("batch", _i32), ("seqlen", _i32), ("exact_products", _i32), ("reserved", _i32),
+    _fields_ = [("m", _i32), ("n", _i32), ("batch", _i32), ("seqlen", _i32), ("exact_products", _i32), ("narrow_steps", _i32),
                 ("a", _vp), ("a_rs", _i64), ("a_bs", _i64), ("b", _vp), ("b_rs", _i64), ("b_bs", _i64),
                 ("c", _vp), ("workspace", _vp)]
 

@@ -207,6 +207,96 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(NtArgs p) {
     }
 }
 
+// ---- the wide form: 128 tokens per step, one workgroup of 8 waves per CU ---------------------------------------------
+// Rows of an operand are typically a power of two apart (B * L tokens): the 192 row segments a workgroup asks for per
+// step then lie in ONE HBM channel / bank, each in a different DRAM row.  With 128-byte segments (32 tokens) the kernel
+// above reaches 3.5-3.7 TB/s on such operands against 5.0-5.6 TB/s when the rows are padded apart
+// (tools/dbg/nt_layout_probe.py).  Here a wave-wide load covers 512 contiguous bytes of each of two rows, a quarter of
+// the row activations per byte.  192 rows x 128 tokens as hi | lo bf16 = 99 KB of LDS, single-buffered: the next step's
+// 96 KB travel in registers (12 x 16 bytes per thread) while the matrix cores work through the current one -- at 768
+// MFMA cycles per wave and step the kernel does not need LDS double buffering to stay HBM-bound.
+constexpr int NW_TK = 128, NW_LD = 132;                 // LDS row: [128 hi bf16 | 128 lo bf16 | 16 B pad] = 132 dwords
+constexpr int NW_ROWS = NT_TM + NT_TN;                  // 192
+constexpr int NW_LDS_BYTES = NW_ROWS * NW_LD * 4;       // 101,376
+constexpr int NW_LOADS = NW_ROWS / 16;                  // 12 row passes of 16 rows (512 threads = 16 rows x 32 pieces)
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(NtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * NT_TM, n0 = blockIdx.y * NT_TN, slab = blockIdx.z;
+    const int c_lo = slab * p.slab_chunks;                       // in steps of 128 tokens
+    const int c_hi = min(c_lo + p.slab_chunks, p.n_chunks);
+    const int piece = tid & 31, row_p = tid >> 5;                // 16-byte piece of the 512-byte row segment; row of the pass
+    const float *src[NW_LOADS];
+    bool valid[NW_LOADS];
+#pragma unroll
+    for (int j = 0; j < NW_LOADS; ++j) {
+        const int r = row_p + 16 * j;                            // tile row: 0..127 = A, 128..191 = B
+        if (r < NT_TM) {
+            valid[j] = m0 + r < p.M;
+            src[j] = p.a + (long)min(m0 + r, p.M - 1) * p.a_rs + 4 * piece;
+        } else {
+            valid[j] = n0 + r - NT_TM < p.N;
+            src[j] = p.b + (long)min(n0 + r - NT_TM, p.N - 1) * p.b_rs + 4 * piece;
+        }
+    }
+    const int cpb = p.L / NW_TK;
+    float4 regs[NW_LOADS];
+#pragma unroll
+    for (int j = 0; j < NW_LOADS; ++j) regs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](int c) {
+        const int bi = c / cpb, l0 = (c - bi * cpb) * NW_TK;
+        const long oa = (long)bi * p.a_bs + l0, ob = (long)bi * p.b_bs + l0;
+#pragma unroll
+        for (int j = 0; j < NW_LOADS; ++j)
+            if (valid[j]) regs[j] = *reinterpret_cast<const float4 *>(src[j] + (j < NT_TM / 16 ? oa : ob));
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NW_LOADS; ++j) {
+            float *row = wlds + (row_p + 16 * j) * NW_LD;
+            uint2 hi, lo;
+            nt_split2(regs[j].x, regs[j].y, hi.x, lo.x);
+            nt_split2(regs[j].z, regs[j].w, hi.y, lo.y);
+            *reinterpret_cast<uint2 *>(row + 2 * piece) = hi;
+            *reinterpret_cast<uint2 *>(row + 64 + 2 * piece) = lo;
+        }
+    };
+    // wave w: rows 32 (w & 3) .. + 31 of A against columns 32 (w >> 2) .. + 31 of B
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int a_off = (32 * (w & 3) + (lane & 31)) * NW_LD + 4 * (lane >> 5);
+    const int b_off = (NT_TM + 32 * (w >> 2) + (lane & 31)) * NW_LD + 4 * (lane >> 5);
+    if (c_lo < c_hi) {
+        load(c_lo);
+        for (int c = c_lo; c < c_hi; ++c) {
+            stage();                                   // (waits for the loads of step c)
+            if (c + 1 < c_hi) load(c + 1);
+            MMU_LDS_BARRIER();
+#pragma unroll
+            for (int s = 0; s < NW_TK / 16; ++s) {     // lane (r, h): tokens 16 s + 8 h .. + 7 of its row
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wlds + a_off + 8 * s);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(wlds + a_off + 64 + 8 * s);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(wlds + b_off + 8 * s);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(wlds + b_off + 64 + 8 * s);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+            MMU_LDS_BARRIER();                         // everyone is done reading before the next step is staged
+        }
+    }
+    float *op = p.part + ((long)slab * p.M) * p.N;
+    const int col = n0 + 32 * (w >> 2) + (lane & 31);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + 32 * (w & 3) + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (row < p.M && col < p.N) op[(long)row * p.N + col] = acc[e];
+    }
+}
+
 // C[i] = sum over slabs of part[s][i] in a fixed order: 16 slab groups per output in parallel (each a strided serial
 // sum), then the 16 group sums in order.  transpose_out: part is (N x M) row-major and C is (M x N).
 __global__ __launch_bounds__(1024) void gemm_nt_reduce_kernel(const float *__restrict__ part, float *__restrict__ c,
@@ -240,13 +330,18 @@ __global__ __launch_bounds__(1024) void gemm_nt_reduce_kernel(const float *__res
 }
 
 // slabs: all workgroups co-resident (2 per CU), at least 8 chunks (256 tokens) per slab
-int nt_plan(int M, int N, long tokens, int &slab_chunks) {
-    const long n_chunks = tokens / NT_TK;
+// the wide form: 128-token steps, one workgroup per CU, at least 2 steps per slab
+bool nt_wide(int seqlen, int exact) {
+    static const int on = []() { const char *e = getenv("MMU_GEMM_NT_WIDE"); return e ? atoi(e) : 1; }();
+    return on && !exact && seqlen % NW_TK == 0;
+}
+int nt_plan(int M, int N, long tokens, int &slab_chunks, bool wide = false) {
+    const long n_chunks = tokens / (wide ? NW_TK : NT_TK);
     const long tiles = (long)((M + NT_TM - 1) / NT_TM) * ((N + NT_TN - 1) / NT_TN);
-    long want = (2L * mmu_cu_count()) / tiles;
+    long want = ((wide ? 1L : 2L) * mmu_cu_count()) / tiles;
     if (want < 1) want = 1;
     long sc = (n_chunks + want - 1) / want;
-    if (sc < 8) sc = 8;
+    if (sc < (wide ? 2 : 8)) sc = wide ? 2 : 8;
     // An ODD number of chunks per slab.  Rows of an operand are typically a power of two apart (B * L tokens), so the
     // 192 row segments a workgroup requests per chunk fall into one HBM channel; with power-of-two slabs every
     // workgroup would also START in the same channel and walk the channels in lockstep (measured: 3.5 instead of
@@ -269,7 +364,9 @@ extern "C" size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, i
     if (m <= 0 || n <= 0 || batch <= 0 || seqlen <= 0) return 0;
     int sc = 0;
     const bool swap = nt_rows_loaded(n, m) < nt_rows_loaded(m, n);
-    const int slabs = swap ? nt_plan(n, m, (long)batch * seqlen, sc) : nt_plan(m, n, (long)batch * seqlen, sc);
+    const int M = swap ? n : m, N = swap ? m : n;
+    int slabs = nt_plan(M, N, (long)batch * seqlen, sc, false);      // enough for either form
+    if (seqlen % NW_TK == 0) slabs = max(slabs, nt_plan(M, N, (long)batch * seqlen, sc, true));
     return (size_t)slabs * m * n;
 }
 
@@ -294,14 +391,22 @@ extern "C" int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream) {
     }
     a.L = p->seqlen; a.batch = p->batch;
     const long tokens = (long)p->batch * p->seqlen;
-    a.n_chunks = (int)(tokens / NT_TK);
-    const int slabs = nt_plan(a.M, a.N, tokens, a.slab_chunks);
+    static const bool exact_env = []() { const char *e = getenv("MMU_GEMM_NT_EXACT"); return e && e[0] == '1'; }();
+    const bool exact = exact_env || p->exact_products;
+    const bool wide = !p->narrow_steps && nt_wide(p->seqlen, exact);
+    a.n_chunks = (int)(tokens / (wide ? NW_TK : NT_TK));
+    const int slabs = nt_plan(a.M, a.N, tokens, a.slab_chunks, wide);
     dim3 grid((a.M + NT_TM - 1) / NT_TM, (a.N + NT_TN - 1) / NT_TN, slabs);
-    static const bool exact = []() { const char *e = getenv("MMU_GEMM_NT_EXACT"); return e && e[0] == '1'; }();
-    if (exact || p->exact_products)
+    if (wide) {
+        static unsigned long long attr_mask = 0;  // per device
+        if (hipError_t e = mmu_set_lds_once(gemm_nt_wide_kernel, NW_LDS_BYTES, attr_mask); e != hipSuccess)
+            return mmu_fail("gemm_nt_splitk: LDS attribute: %s", hipGetErrorString(e));
+        gemm_nt_wide_kernel<<<grid, 512, NW_LDS_BYTES, st>>>(a);
+    } else if (exact) {
         gemm_nt_splitk_kernel<false><<<grid, 256, 0, st>>>(a);
-    else
+    } else {
         gemm_nt_splitk_kernel<true><<<grid, 256, 0, st>>>(a);
+    }
     MMU_HIP_LAUNCH_CHECK("gemm_nt_splitk");
     const long n = (long)p->m * p->n;
     gemm_nt_reduce_kernel<<<(unsigned)((n + 63) / 64), 1024, 0, st>>>(p->workspace, p->c, n, slabs, a.M, a.N, swap ? 1 : 0);

@@ -54,7 +54,7 @@ def nt_supported(a, b, seqlen):
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
-def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False):
+def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False, narrow=False):
     """C (m, n) = sum over the batch * seqlen tokens of A[i][t] * B[j][t]; token (bi, l) of row i of ``a`` lies at
     element offset i * a_rs + bi * a_bs + l of its storage (same for ``b``): channel-major and batch-major operands are
     both read in place.  float32, deterministic."""
@@ -67,7 +67,7 @@ def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False):
     c = torch.empty((m, n), device=a.device, dtype=torch.float32)
     ws = torch.empty(L.mmu_gemm_nt_splitk_workspace_floats(m, n, batch, seqlen), device=a.device, dtype=torch.float32)
     p = _lib.GemmNtParams()
-    p.m, p.n, p.batch, p.seqlen, p.exact_products = m, n, batch, seqlen, int(exact)
+    p.m, p.n, p.batch, p.seqlen, p.exact_products, p.narrow_steps = m, n, batch, seqlen, int(exact), int(narrow)
     p.a, p.a_rs, p.a_bs = a.data_ptr(), a_rs, a_bs
     p.b, p.b_rs, p.b_bs = b.data_ptr(), b_rs, b_bs
     p.c, p.workspace = c.data_ptr(), ws.data_ptr()

@@ -693,6 +693,7 @@ def test_conv1d_full_size_shift_property():
     (128, 4, 2, 1024, "cm", "cm"),        # dt_proj: 4 columns (a partial 64-column tile)
     (64, 192, 1, 4096, "cm", "cm"),       # DSC weight gradient
     (200, 70, 2, 96, "bm", "bm"),         # ragged tile counts, three chunks per batch item
+    (130, 65, 3, 384, "cm", "bm"),        # ragged tiles on the 128-token-step kernel, three steps per batch item
 ])
 def test_gemm_nt_splitk_vs_float64(case):
     """csrc/gemm_nt_splitk.hip (token-contraction product on the matrix cores, operands addressed in place in either
@@ -714,9 +715,10 @@ def test_gemm_nt_splitk_vs_float64(case):
     ref = torch.einsum("bil,bjl->ij", a_ref.double(), b_ref.double())
     # randn operands: a sum of T products has standard deviation sqrt(T); float32 accumulation rounds at 2^-24 of it per
     # add, the split form adds 2^-16-relative product errors that average out over T
-    for exact, tol in ((False, 2e-5), (True, 4e-6)):
-        c1 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs, exact=exact)
-        c2 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs, exact=exact)
+    # three kernels: 128-token steps (taken when L % 128 == 0), 32-token steps, 32-token steps with exact products
+    for exact, narrow, tol in ((False, False, 2e-5), (False, True, 2e-5), (True, True, 4e-6)):
+        c1 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs, exact=exact, narrow=narrow)
+        c2 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs, exact=exact, narrow=narrow)
         assert torch.equal(c1, c2)
         err = float((c1.double().cpu() - ref).abs().max())
-        assert err <= tol * (b * l) ** 0.5, f"exact={exact}: max abs err {err:.3e}"
+        assert err <= tol * (b * l) ** 0.5, f"exact={exact} narrow={narrow}: max abs err {err:.3e}"

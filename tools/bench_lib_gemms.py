@@ -38,7 +38,14 @@ for name, m, n, t in cases:
     g = torch.randn(m, t, device=DEV)
     x = torch.randn(n, t, device=DEV)
     byt = 4.0 * t * (m + n)
-    for how, fn in (("one GEMM", lambda: g @ x.t()), ("nt_splitk", lambda: nt_splitk(g, x)),
-                    ("gemm_nt HIP", lambda: mfma_gemm.gemm_nt(g, x, m, n, 1, t, t, 0, t, 0))):
+    def batched():
+        mfma_gemm.NT_ENABLED = False          # the earlier form: slabs of the token axis as one batched library GEMM + a sum
+        try:
+            return nt_splitk(g, x)
+        finally:
+            mfma_gemm.NT_ENABLED = True
+    for how, fn in (("one GEMM", lambda: g @ x.t()), ("batched slabs", batched),
+                    ("gemm_nt HIP", lambda: mfma_gemm.gemm_nt(g, x, m, n, 1, t, t, 0, t, 0)),
+                    ("gemm_nt exact", lambda: mfma_gemm.gemm_nt(g, x, m, n, 1, t, t, 0, t, 0, exact=True))):
         ms = timeit(fn)
         print(f"{name:42s} {how:10s} {ms*1e3:8.1f} us  {byt/ms/1e6:7.0f} GB/s of operands  {2.0*m*n*t/ms/1e9:7.1f} TFLOP/s")

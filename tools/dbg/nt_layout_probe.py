@@ -18,8 +18,8 @@ for (m, n) in ((256, 64), (128, 64), (128, 4)):
     for pad in (0, 64, 1056):
         Tp = T + pad
         ap = torch.randn(m * Tp, device=DEV); bp = torch.randn(n * Tp, device=DEV)
-        for ex in (False, True):
-            t = timeit(lambda: mfma_gemm.gemm_nt(ap, bp, m, n, 1, T, Tp, 0, Tp, 0, exact=ex))
-            print(f"{m}x{n}: exact={int(ex)} row stride T+{pad:<5d} {t:7.1f} us  {(m + n) * T * 4 / t / 1e6:6.2f} TB/s")
-    t = timeit(lambda: mfma_gemm.gemm_nt(a, b, m, n, T // 32, 32, 32, m * 32, 32, n * 32))
+        for ex, nar in ((False, False), (False, True), (True, True)):
+            t = timeit(lambda: mfma_gemm.gemm_nt(ap, bp, m, n, 1, T, Tp, 0, Tp, 0, exact=ex, narrow=nar))
+            print(f"{m}x{n}: {'exact' if ex else 'split'} {'32' if nar else '128'}-token steps, row stride T+{pad:<5d} {t:7.1f} us  {(m + n) * T * 4 / t / 1e6:6.2f} TB/s")
+    t = timeit(lambda: mfma_gemm.gemm_nt(a, b, m, n, T // 32, 32, 32, m * 32, 32, n * 32, narrow=True))
     print(f"{m}x{n}: chunk tiles contiguous  {t:7.1f} us  {(m + n) * T * 4 / t / 1e6:6.2f} TB/s")
