@@ -276,9 +276,13 @@ CoordArgs to_args(const mmu_coords_params *p) {
 }
 
 inline unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
-inline unsigned reduce_blocks(long n) {  // grid-stride kernels: enough blocks to fill the chip, few atomics
-    long b = (n + 256 * 8 - 1) / (256 * 8);
-    return (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+// grid-stride kernels that end in one float atomic per block and weight: one position per thread up to 256 blocks (a
+// block's iterations are serial memory round trips -- 8 positions per thread made the 2,048-position calls 16-19 us
+// for ONE workgroup, the forward kernels next to them take 5), more positions per thread beyond, so that no address
+// sees more than 256 atomics
+inline unsigned reduce_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 
 }  // namespace
