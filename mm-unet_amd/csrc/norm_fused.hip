@@ -51,16 +51,17 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return t;
 }
 
-// moments per (b, c): grid (B*C), block 256.  BWD: t1 = sum g2, t2 = sum g2 x with g2 = dout * act'(A x + D)
+// moments per (b, c): grid (B*C), block 256 -- or 1024 for long rows when there are few of them (nf_moment_threads: 512
+// rows of 16,384 floats on 256 threads each took 16.8 us = 2 TB/s, too few bytes in flight per CU).  BWD: t1 = sum g2, t2 = sum g2 x with g2 = dout * act'(A x + D)
 // act_out (BWD, residual mode): the forward output relu(A x + D + residual); its sign is the ReLU mask
 template <bool BWD, typename xin_t, typename act_t>
-__global__ __launch_bounds__(256) void nf_moments_kernel(const xin_t *__restrict__ x, const act_t *__restrict__ dout,
+__global__ __launch_bounds__(1024) void nf_moments_kernel(const xin_t *__restrict__ x, const act_t *__restrict__ dout,
                                                          const float *__restrict__ A, const float *__restrict__ D,
                                                          float *__restrict__ m1, float *__restrict__ m2, int HW,
                                                          int act, const act_t *__restrict__ act_out,
                                                          const float *__restrict__ pre_bias, int C) {
     // pre_bias (forward only): the moments written are those of x + pre_bias[c]
-    __shared__ float red[8];
+    __shared__ float red[16];
     const long base = (long)blockIdx.x * HW;
     const float Av = BWD ? A[blockIdx.x] : 0.f, Dv = BWD ? D[blockIdx.x] : 0.f;
     float s1 = 0.f, s2 = 0.f;
@@ -713,6 +714,16 @@ int fill(const mmu_norm_params *p, FinArgs &a, const char *name) {
 
 }  // namespace
 
+// launch shapes of the streaming kernels: enough bytes in flight when the rows are few
+static inline int nf_moment_threads(int BC, int HW) { return (HW / 4 >= 2048 && BC <= 2048) ? 1024 : 256; }
+// apply kernels: a few thousand workgroups at most, each with >= 16 KB of its row (a block's prologue computes the row's
+// constants: too small a share and the prologue dominates)
+static inline int nf_apply_splits(int BC, int HW) {
+    int splits = (HW / 4 + 1023) / 1024;
+    while (splits > 1 && (long)splits * BC > 8192) --splits;
+    return splits;
+}
+
 extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
     FinArgs a;
     if (int r = fill(p, a, "norm_fused_fwd")) return r;
@@ -730,13 +741,11 @@ extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
     const int cpg = a.C / a.G;
     const bool fused = (a.HW & 3) == 0 && a.B * cpg <= 64 && a.B <= 64 && getenv("MMU_NF_FINALIZE_KERNEL") == nullptr;
     NF_TYPES(p->x_dtype, p->act_dtype, {
-        nf_moments_kernel<false, xin_t, act_t><<<BC, 256, 0, st>>>((const xin_t *)p->input, nullptr, nullptr, nullptr, p->s1,
+        nf_moments_kernel<false, xin_t, act_t><<<BC, nf_moment_threads(BC, a.HW), 0, st>>>((const xin_t *)p->input, nullptr, nullptr, nullptr, p->s1,
                                                                   p->s2, a.HW, 0, nullptr, fused ? p->pre_bias : nullptr,
                                                                   a.C);
         if (fused) {
-            // a few thousand workgroups at most, each with >= 4 KB of the row
-            int splits = (a.HW / 4 + 4095) / 4096;
-            while (splits > 1 && (long)splits * BC > 8192) --splits;
+            const int splits = nf_apply_splits(BC, a.HW);
             nf_apply_fwd_fused_kernel<xin_t, act_t><<<dim3(splits, BC), 256, 0, st>>>(
                 a, (const xin_t *)p->input, (act_t *)p->out, (const act_t *)p->residual, p->act);
         } else {
@@ -772,11 +781,10 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     const int cpg = a.C / a.G;
     const bool fused = (a.HW & 3) == 0 && a.B * cpg <= 64 && a.B <= 64 && getenv("MMU_NF_FINALIZE_KERNEL") == nullptr;
     NF_TYPES(p->x_dtype, p->act_dtype, {
-        nf_moments_kernel<true, xin_t, act_t><<<BC, 256, 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
+        nf_moments_kernel<true, xin_t, act_t><<<BC, nf_moment_threads(BC, a.HW), 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
                                                                  t1, t2, a.HW, p->act, (const act_t *)p->act_out, nullptr, a.C);
         if (fused) {
-            int splits = (a.HW / 4 + 4095) / 4096;
-            while (splits > 1 && (long)splits * BC > 8192) --splits;
+            const int splits = nf_apply_splits(BC, a.HW);
             nf_apply_bwd_fused_kernel<xin_t, act_t><<<dim3(splits, BC), 256, 0, st>>>(
                 a, (const xin_t *)p->input, (const act_t *)p->dout, (xin_t *)p->dinput, p->act,
                 p->dinput_channel_major ? a.B : 0, (const act_t *)p->act_out, (act_t *)p->dresidual);
