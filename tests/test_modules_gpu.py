@@ -436,7 +436,11 @@ def test_morph_sample_tokens_last_layout():
 
 @pytest.mark.parametrize("case", [((2, 5, 16, 16), (32, 32)), ((1, 3, 17, 9), (40, 33)), ((2, 2, 64, 64), (16, 16)),
                                   ((1, 2, 8, 8), (64, 64)), ((1, 1, 1, 7), (5, 1)), ((1, 2, 33, 20), (33, 20)),
-                                  ((2, 3, 31, 29), (12, 50))])
+                                  ((2, 3, 31, 29), (12, 50)),
+                                  # the LDS-tiled backward (ratios <= ~2.3): ragged 64 x 8 tiles, x2 and non-integer ratios
+                                  ((1, 2, 70, 100), (140, 200)), ((2, 1, 30, 70), (66, 150)), ((1, 3, 9, 130), (13, 259)),
+                                  # ... and its few-candidates form (down-sampling by >= 2)
+                                  ((1, 2, 140, 200), (70, 100)), ((2, 1, 64, 256), (16, 32)), ((1, 2, 100, 90), (37, 41))])
 def test_bilinear_resize_vs_interpolate(case):
     """bilinear_resize == F.interpolate(mode="bilinear", align_corners=True) evaluated on CPU
     (MMUNet.py:362,384,571-575), forward and input gradient, up- and down-sampling, degenerate sizes."""
@@ -452,11 +456,14 @@ def test_bilinear_resize_vs_interpolate(case):
     xg = x.to(DEV).requires_grad_()
     out = bilinear_resize(xg, size=size)
     out.backward(g.to(DEV))
-    close(out, ref, 1e-5, 1e-5, "resize")
-    close(xg.grad, xr.grad, 1e-5, 1e-4, "d input")
+    # (source coordinates beyond 64 have an fp32 ulp of 8e-6 and more; ATen rounds r*o before subtracting the integer
+    # part, the kernel's fma does not)
+    tol = 1e-5 if max(*shape[2:], *size) <= 64 else 5e-5
+    close(out, ref, tol, tol, "resize")
+    close(xg.grad, xr.grad, tol, 1e-4, "d input")
     # scale_factor form (DecoderBlock)
     if size == (2 * shape[2], 2 * shape[3]):
-        close(bilinear_resize(x.to(DEV), scale_factor=2), ref, 1e-5, 1e-5, "scale_factor=2")
+        close(bilinear_resize(x.to(DEV), scale_factor=2), ref, tol, tol, "scale_factor=2")
 
 
 @pytest.mark.parametrize("case", [(2, 16, 6, 32, 32), (1, 7, 6, 13, 10), (2, 5, 1, 9, 17), (1, 64, 8, 16, 16),
