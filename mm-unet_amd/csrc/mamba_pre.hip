@@ -108,6 +108,10 @@ extern "C" int mmu_mamba_pre_small(const mmu_mamba_pre_params *p, void *stream) 
 // one partial per workgroup, a second kernel adds the workgroups in fixed order (deterministic, no atomics).
 namespace {
 
+// A workgroup owns 256 tokens (lane = 4 consecutive tokens) and its four waves SPLIT THE ROWS of x_dbl: wave 0 takes the
+// dt row (built from ddelta) and rows 1..5, waves 1..3 nine rows each.  A row's weight gradients belong to one wave (no
+// cross-wave reduction: wave_sum4_swap and a store), the partial d conv_out of waves 1..3 meet wave 0 through LDS.  The
+// first form gave every thread all 33 rows: 3,000 instructions on one wave per SIMD, 15-18 us whatever the size.
 template <int D, int R>
 __global__ __launch_bounds__(256, 1) void mamba_post_small_kernel(const float *__restrict__ ddelta,
                                                                   const float *__restrict__ dt,
@@ -117,69 +121,101 @@ __global__ __launch_bounds__(256, 1) void mamba_post_small_kernel(const float *_
                                                                   const float *__restrict__ wx,
                                                                   const float *__restrict__ wdt,
                                                                   float *__restrict__ part, long T) {
+    static_assert(R == 33, "row split written for 33 rows");
     constexpr int NV = R * D + D, NV4 = (NV + 3) & ~3;
-    __shared__ float red[4 * NV4];
+    constexpr int JW = 9;                                  // rows per wave at most
+    __shared__ float4 xch[3][D][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jlo = w == 0 ? 0 : 6 + JW * (w - 1), nrows = w == 0 ? 6 : JW;
     const long ngroups = T >> 2;
-    float v[NV];
+    long gi = (long)blockIdx.x * 64 + lane;
+    const float live = gi < ngroups ? 1.f : 0.f;           // lanes past the end re-read the last group with weight 0
+    gi = gi < ngroups ? gi : ngroups - 1;
+    const long col = gi * 4;
+
+    float4 rows[JW];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = 0.f;
-    {   // one group of 4 tokens per thread: a loop here makes the 198 wave-uniform weights loop invariants that
-        // the compiler pins in SGPRs (450 spilled)
-        long gi = (long)blockIdx.x * 256 + threadIdx.x;
-        const float live = gi < ngroups ? 1.f : 0.f;  // lanes past the end re-read the last group with weight 0
-        gi = gi < ngroups ? gi : ngroups - 1;
-        const long col = gi * 4;
-        float cv[D][4], dc[D][4], row[4];
+    for (int jj = 0; jj < JW; ++jj) {
+        rows[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jj < nrows && jlo + jj > 0) rows[jj] = *reinterpret_cast<const float4 *>(dxdbl + (long)(jlo + jj) * T + col);
+    }
+    float cv[D][4], pc[D][4];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float4 c4 = *reinterpret_cast<const float4 *>(conv + d * T + col);
+        cv[d][0] = c4.x * live; cv[d][1] = c4.y * live; cv[d][2] = c4.z * live; cv[d][3] = c4.w * live;
+        pc[d][0] = pc[d][1] = pc[d][2] = pc[d][3] = 0.f;
+    }
+    float vdt[D];
+    if (w == 0) {   // the dt row = sum_d W_dt[d] ddelta[d];  dW_dt[d] = sum_t ddelta[d] dt
         const float4 t4 = *reinterpret_cast<const float4 *>(dt + col);
         const float dtv[4] = {t4.x, t4.y, t4.z, t4.w};
-        row[0] = row[1] = row[2] = row[3] = 0.f;
+        float r0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(conv + d * T + col);
-            const float4 g4 = *reinterpret_cast<const float4 *>(dconv + d * T + col);
             const float4 e4 = *reinterpret_cast<const float4 *>(ddelta + d * T + col);
-            cv[d][0] = c4.x * live; cv[d][1] = c4.y * live; cv[d][2] = c4.z * live; cv[d][3] = c4.w * live;
-            dc[d][0] = g4.x; dc[d][1] = g4.y; dc[d][2] = g4.z; dc[d][3] = g4.w;
+            const float4 g4 = *reinterpret_cast<const float4 *>(dconv + d * T + col);
             const float e[4] = {e4.x, e4.y, e4.z, e4.w};
+            pc[d][0] = g4.x; pc[d][1] = g4.y; pc[d][2] = g4.z; pc[d][3] = g4.w;
             const float wv = wdt[d];
+            vdt[d] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                row[i] = fmaf(wv, e[i], row[i]);                                  // d dt
-                v[R * D + d] = fmaf(e[i] * live, dtv[i], v[R * D + d]);           // dW_dt
+                r0[i] = fmaf(wv, e[i], r0[i]);
+                vdt[d] = fmaf(e[i] * live, dtv[i], vdt[d]);
             }
         }
+        rows[0] = make_float4(r0[0], r0[1], r0[2], r0[3]);
+    }
+    float v[JW * D];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            if (j > 0) {
-                const float4 r4 = *reinterpret_cast<const float4 *>(dxdbl + (long)j * T + col);
-                row[0] = r4.x; row[1] = r4.y; row[2] = r4.z; row[3] = r4.w;
+    for (int jj = 0; jj < JW; ++jj) {
+        const float row[4] = {rows[jj].x, rows[jj].y, rows[jj].z, rows[jj].w};
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float wv = jj < nrows ? wx[(jlo + jj) * D + d] : 0.f;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pc[d][i] = fmaf(wv, row[i], pc[d][i]);
+                acc = fmaf(row[i], cv[d][i], acc);
             }
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const float wv = wx[j * D + d];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dc[d][i] = fmaf(wv, row[i], dc[d][i]);
-                    v[j * D + d] = fmaf(row[i], cv[d][i], v[j * D + d]);
-                }
-            }
-        }
-        if (live != 0.f) {
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-                *reinterpret_cast<float4 *>(dconv + d * T + col) = make_float4(dc[d][0], dc[d][1], dc[d][2], dc[d][3]);
+            v[jj * D + d] = acc;
         }
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w > 0) {
 #pragma unroll
-    for (int i = 0; i < NV4; i += 4) {
-        const float r = wave_sum4(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
-                                  i + 3 < NV ? v[i + 3] : 0.f);
-        if (lane >= 12 && lane < 16) red[w * NV4 + i + lane - 12] = r;
+        for (int d = 0; d < D; ++d) xch[w - 1][d][lane] = make_float4(pc[d][0], pc[d][1], pc[d][2], pc[d][3]);
+    }
+    // this wave's rows of dW_x (and dW_dt from wave 0): sums over the 64 lanes land in lanes 12..15 of a group of four
+    float *pb = part + (long)blockIdx.x * NV4;
+#pragma unroll
+    for (int i = 0; i < JW * D; i += 4) {
+        const float r = wave_sum4_swap(v[i], i + 1 < JW * D ? v[i + 1] : 0.f, i + 2 < JW * D ? v[i + 2] : 0.f,
+                                       i + 3 < JW * D ? v[i + 3] : 0.f);
+        const int k = i + lane - 12;
+        if (lane >= 12 && lane < 16 && k < nrows * D) pb[jlo * D + k] = r;
+    }
+    if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < D; i += 4) {
+            const float r = wave_sum4_swap(vdt[i], i + 1 < D ? vdt[i + 1] : 0.f, i + 2 < D ? vdt[i + 2] : 0.f,
+                                           i + 3 < D ? vdt[i + 3] : 0.f);
+            const int k = i + lane - 12;
+            if (lane >= 12 && lane < 16 && k < D) pb[R * D + k] = r;
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NV; i += 256)
-        part[(long)blockIdx.x * NV4 + i] = (red[i] + red[NV4 + i]) + (red[2 * NV4 + i] + red[3 * NV4 + i]);
+    if (w == 0 && live != 0.f) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float4 a = xch[0][d][lane], b = xch[1][d][lane], c = xch[2][d][lane];
+            *reinterpret_cast<float4 *>(dconv + d * T + col) =
+                make_float4(pc[d][0] + a.x + b.x + c.x, pc[d][1] + a.y + b.y + c.y, pc[d][2] + a.z + b.z + c.z,
+                            pc[d][3] + a.w + b.w + c.w);
+        }
+    }
 }
 
 // one wave per result: lanes stride over the workgroups' partials, fixed-order butterfly at the end
@@ -199,8 +235,8 @@ __global__ __launch_bounds__(256) void mamba_post_small_sum_kernel(const float *
     }
 }
 
-int post_blocks(long tokens) {
-    const long g = (tokens / 4 + 255) / 256;
+int post_blocks(long tokens) {   // 256 tokens per workgroup
+    const long g = (tokens / 4 + 63) / 64;
     return (int)(g < 1 ? 1 : g);
 }
 
