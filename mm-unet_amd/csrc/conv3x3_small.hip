@@ -111,6 +111,29 @@ __global__ __launch_bounds__(256) void conv3x3s_sum_splits_kernel(const float *_
     out[i] = s;
 }
 
+// The same for many splits of a small map (16 x 16 maps of 512 channels: 64 splits of 12,288 outputs -- one thread per
+// output walked 64 dependent round trips, 25-38 us): 64 outputs x 4 split groups per workgroup, each group a strided
+// serial sum with four loads in flight, the four group sums added in order.
+__global__ __launch_bounds__(256) void conv3x3s_sum_splits_wide_kernel(const float *__restrict__ part,
+                                                                       float *__restrict__ out, long n, int splits) {
+    __shared__ float sums[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (i < n) {
+        int k = g;
+        for (; k + 12 < splits; k += 16) {
+            const float v0 = part[(long)k * n + i], v1 = part[(long)(k + 4) * n + i];
+            const float v2 = part[(long)(k + 8) * n + i], v3 = part[(long)(k + 12) * n + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < splits; k += 4) s += part[(long)k * n + i];
+    }
+    sums[g][o] = s;
+    __syncthreads();
+    if (g == 0 && i < n) out[i] = (sums[0][o] + sums[1][o]) + (sums[2][o] + sums[3][o]);
+}
+
 // dx[b,ci,y,x] = sum_co sum_{ky,kx} W[co][ci][ky][kx] * g[b,co,y-ky+1,x-kx+1]
 // grid (ceil(B*H*ceil(W/2) / 256), channel slices): every slice re-reads the (small) dout neighbourhood
 template <int CO, typename in_t>
@@ -445,7 +468,10 @@ extern "C" int mmu_conv3x3_small_fwd(const mmu_conv3x3s_params *p, void *stream)
     MMU_HIP_LAUNCH_CHECK("conv3x3_small_fwd");
     if (splits > 1) {
         const long n = (long)p->batch * p->out_channels * p->height * p->width;
-        conv3x3s_sum_splits_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, p->out, n, splits);
+        if (splits >= 8 && n <= (1L << 21))
+            conv3x3s_sum_splits_wide_kernel<<<(unsigned)((n + 63) / 64), 256, 0, st>>>(part, p->out, n, splits);
+        else
+            conv3x3s_sum_splits_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, p->out, n, splits);
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_fwd(sum)");
     }
     return 0;
