@@ -215,7 +215,8 @@ int mmu_bilinear_resize_bwd(const mmu_resize_params *p, void *stream);
 /* ---- 3x3 / stride 1 / pad 1 convolution with few output channels (a9: MMConv.offset_conv) ------------ */
 /* nn.Conv2d(Cin, CO, 3, padding=1) for CO in {1, 2, 6, 8} (src/UM_Net/MMUNet.py:46,250: Cin -> 2K = 6), contiguous
  * NCHW; input / dinput in in_dtype (float32, or bfloat16 activations under autocast), everything else float32.
- * weight_t is the weight transposed to [Cin][3][3][CO] (a channel's CO*9 weights contiguous).
+ * weight_t is the weight transposed to [Cin][3][3][CO] (a channel's CO*9 weights contiguous) -- or, with weight_native = 1,
+ * the weight as the module holds it, [CO][Cin][3][3] (no transposed copy per call).
  *   fwd : out[b,co,h,w] = bias[co] + sum_{ci,ky,kx} W[co][ci][ky][kx] * in[b,ci,h+ky-1,w+kx-1]
  *   bwd : dinput (if non-NULL), dweight [CO][Cin][3][3] and dbias [CO] (if non-NULL; zeroed inside, float atomics) */
 typedef struct {
@@ -233,6 +234,7 @@ typedef struct {
     int32_t in_dtype;       /* MMU_DTYPE_F32 (0, the default of a zeroed struct) or MMU_DTYPE_BF16 */
     const void *dinput_addend;  /* bwd, optional, shape / type of dinput: dinput = conv gradient + addend (the gradient
                                  * another consumer of the same input already produced; may alias dinput) */
+    int32_t weight_native;  /* 1: weight_t points at the [out_channels, in_channels, 3, 3] weight itself */
 } mmu_conv3x3s_params;
 
 /* small images have too few pixels to fill the chip: the forward then slices the input channels and sums the

@@ -81,7 +81,7 @@ class Conv3x3sParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "in_channels", "out_channels", "height", "width")]
                 + [(n, _vp) for n in ("input", "weight_t", "bias", "out", "dout", "dinput", "dweight", "dbias",
                                       "workspace")]
-                + [("in_dtype", _i32), ("dinput_addend", _vp)])
+                + [("in_dtype", _i32), ("dinput_addend", _vp), ("weight_native", _i32)])
 
 
 class TriParams(ctypes.Structure):

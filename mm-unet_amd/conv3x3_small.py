@@ -46,11 +46,12 @@ class Conv3x3SmallFn(torch.autograd.Function):
         bias = bias.contiguous() if bias is not None else None
         B, Cin, H, W = x.shape
         CO = weight.shape[0]
-        wt = weight.permute(1, 2, 3, 0).contiguous()          # [Cin][3][3][CO]
+        wt = weight                                           # read in place ([CO][Cin][3][3]: weight_native)
         out = torch.empty((B, CO, H, W), device=x.device, dtype=torch.float32)
         p = _lib.Conv3x3sParams()
         p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
         p.input, p.weight_t, p.bias, p.out = x.data_ptr(), wt.data_ptr(), _lib.ptr(bias), out.data_ptr()
+        p.weight_native = 1
         p.in_dtype = _lib.dtype_code(x)
         splits = _lib.lib().mmu_conv3x3_small_fwd_splits(B, Cin, H, W)
         ws = torch.empty((splits,) + tuple(out.shape), device=x.device, dtype=torch.float32) if splits > 1 else None
@@ -83,6 +84,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
             p = _lib.Conv3x3sParams()
             p.batch, p.in_channels, p.out_channels, p.height, p.width = B, Cin, CO, H, W
             p.input, p.weight_t, p.dout, p.dinput = x.data_ptr(), wt.data_ptr(), g.data_ptr(), dx.data_ptr()
+            p.weight_native = 1
             p.dinput_addend = _lib.ptr(parked)
             p.in_dtype = _lib.dtype_code(x)
             with torch.cuda.device(x.device):
@@ -104,7 +106,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
             else:
                 # ATen / MIOpen weight gradient (kept for comparison: its implicit-GEMM kernel plus layout
                 # transposes take 50-110 us where the row-walking kernel needs a fraction of that)
-                w = wt.permute(3, 0, 1, 2)
+                w = wt
                 _, dw, db = torch.ops.aten.convolution_backward(
                     g, x.float(), w, [CO] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                     [False, bool(need_w), bool(need_b)])

@@ -23,7 +23,8 @@ namespace {
 
 // fwd.  grid (ceil(B*H*ceil(W/4) / 256), splits): split s handles input channels [s*cps, (s+1)*cps) and
 // writes its partial sums to part[s] ([B][CO][H][W]); with one split `part` is the output itself.
-template <int CO, typename in_t>
+// NATIVE: wt is the weight as the module holds it, [CO][Cin][3][3] (no transposed copy); else [Cin][3][3][CO]
+template <int CO, typename in_t, bool NATIVE>
 __global__ __launch_bounds__(256) void conv3x3s_fwd_kernel(const in_t *__restrict__ x, const float *__restrict__ wt,
                                                            const float *__restrict__ bias, float *__restrict__ part,
                                                            int B, int Cin, int H, int W, int cps) {
@@ -76,14 +77,14 @@ __global__ __launch_bounds__(256) void conv3x3s_fwd_kernel(const in_t *__restric
                 for (int j = 0; j < 6; ++j) v[dy][j] = to_f32(rp[coff[j]]) * (rm[dy] * cm[j]);
             }
         }
-        const float *wc = wt + (long)ci * 9 * CO;  // wave-uniform: scalar loads
+        const float *wc = NATIVE ? wt + (long)ci * 9 : wt + (long)ci * 9 * CO;  // wave-uniform: scalar loads
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                 for (int co = 0; co < CO; ++co) {
-                    const float wv = wc[(dy * 3 + dx) * CO + co];
+                    const float wv = NATIVE ? wc[(long)co * Cin * 9 + dy * 3 + dx] : wc[(dy * 3 + dx) * CO + co];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(wv, v[dy][j + dx], acc[co][j]);
                 }
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void conv3x3s_sum_splits_wide_kernel(const flo
 
 // dx[b,ci,y,x] = sum_co sum_{ky,kx} W[co][ci][ky][kx] * g[b,co,y-ky+1,x-kx+1]
 // grid (ceil(B*H*ceil(W/2) / 256), channel slices): every slice re-reads the (small) dout neighbourhood
-template <int CO, typename in_t>
+template <int CO, typename in_t, bool NATIVE>
 __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__restrict__ g, const float *__restrict__ wt,
                                                                 in_t *__restrict__ dx, int B, int Cin, int H, int W,
                                                                 int cps, const in_t *__restrict__ addend) {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__r
     const in_t *ap = addend ? addend + ((long)b * Cin + c_lo) * HW + (long)h * W + w0 : nullptr;
     const bool two = (W & 1) == 0;
     for (int ci = c_lo; ci < c_hi; ++ci, dp += HW) {
-        const float *wc = wt + (long)ci * 9 * CO;
+        const float *wc = NATIVE ? wt + (long)ci * 9 : wt + (long)ci * 9 * CO;
         float a0 = 0.f, a1 = 0.f;
         if (ap) {
             const in_t *aq = ap + (long)(ci - c_lo) * HW;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__r
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int co = 0; co < CO; ++co) {
-                    const float wv = wc[(ky * 3 + kx) * CO + co];
+                    const float wv = NATIVE ? wc[(long)co * Cin * 9 + ky * 3 + kx] : wc[(ky * 3 + kx) * CO + co];
                     // pixel (h, w0 + p): g row h-ky+1 -> dy = 2-ky ; col w0+p-kx+1 -> j = p - kx + 2
                     a0 = fmaf(wv, gv[co][2 - ky][2 - kx], a0);
                     a1 = fmaf(wv, gv[co][2 - ky][3 - kx], a1);
@@ -462,9 +463,15 @@ extern "C" int mmu_conv3x3_small_fwd(const mmu_conv3x3s_params *p, void *stream)
     hipStream_t st = (hipStream_t)stream;
     float *part = splits == 1 ? p->out : p->workspace;
     dim3 grid((unsigned)((total + 255) / 256), splits);
-    CO_DISPATCH(p->out_channels, conv3x3s_fwd_kernel<CO, in_t><<<grid, 256, 0, st>>>(
-                                     (const in_t *)p->input, p->weight_t, p->bias, part, p->batch, p->in_channels, p->height,
-                                     p->width, cps);)
+    if (p->weight_native) {
+        CO_DISPATCH(p->out_channels, conv3x3s_fwd_kernel<CO, in_t, true><<<grid, 256, 0, st>>>(
+                                         (const in_t *)p->input, p->weight_t, p->bias, part, p->batch, p->in_channels,
+                                         p->height, p->width, cps);)
+    } else {
+        CO_DISPATCH(p->out_channels, conv3x3s_fwd_kernel<CO, in_t, false><<<grid, 256, 0, st>>>(
+                                         (const in_t *)p->input, p->weight_t, p->bias, part, p->batch, p->in_channels,
+                                         p->height, p->width, cps);)
+    }
     MMU_HIP_LAUNCH_CHECK("conv3x3_small_fwd");
     if (splits > 1) {
         const long n = (long)p->batch * p->out_channels * p->height * p->width;
@@ -493,9 +500,15 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
         const int splits = channel_splits(total, p->in_channels);
         const int cps = (p->in_channels + splits - 1) / splits;
         dim3 grid((unsigned)((total + 255) / 256), splits);
-        CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO, in_t><<<grid, 256, 0, st>>>(
-                                         p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
-                                         p->width, cps, (const in_t *)p->dinput_addend);)
+        if (p->weight_native) {
+            CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO, in_t, true><<<grid, 256, 0, st>>>(
+                                             p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
+                                             p->width, cps, (const in_t *)p->dinput_addend);)
+        } else {
+            CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO, in_t, false><<<grid, 256, 0, st>>>(
+                                             p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
+                                             p->width, cps, (const in_t *)p->dinput_addend);)
+        }
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(data)");
     }
     int lwq = 0, rs = 0, nrb = 0;
