@@ -69,8 +69,9 @@ class _DscGemmFn(torch.autograd.Function):
     """The K x 1 / stride K x 1 ``dsc_conv_x`` of MMConv (MMUNet.py:262) on the tokens-last sampler output:
     W2 (Cout, Cin*K) times samples (Cin*K, B*T) -> (B, Cout, T) **batch-major** (what GroupNorm wants), as
     a strided batched GEMM -- batch b's operand is rows of ``samples`` with leading dimension B*T, so
-    neither the K x inflated samples nor the output are ever copied.  Backward: the (small) output
-    gradient is brought to tokens-last once; dX = W2^T @ G lands in the samples' layout, dW uses split-K."""
+    neither the K x inflated samples nor the output are ever copied.  Backward: the batch-major output gradient is read
+    in place too (row stride T, batch stride O*T); dX = W2^T @ G lands in the samples' layout, dW is the
+    token-contraction product (csrc/gemm_nt_splitk.hip)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -92,19 +93,31 @@ class _DscGemmFn(torch.autograd.Function):
         W2, samples = ctx.saved_tensors
         G = G.float()
         B = ctx.batch
-        O = W2.shape[0]
-        G2 = G.permute(1, 0, 2).reshape(O, -1)                             # (O, B*T): the one small copy
+        O, I = W2.shape
+        T = G.shape[2]
         dW = dX = None
+        # the batch-major output gradient is read in place by both products (row stride T, batch stride O*T)
+        inplace = G.is_contiguous() and samples.is_contiguous() and T % 4 == 0 and W2.stride(1) == 1
+        G2 = None
         if ctx.needs_input_grad[0]:
-            dW = nt_splitk(G2, samples).to(W2.dtype)
-        if ctx.needs_input_grad[1]:
-            I = W2.shape[1]
-            if mfma_gemm.supported(I, O, G2.shape[1], W2, G2) and W2.stride(1) == 1 and G2.is_contiguous():
-                NT = G2.shape[1]
-                dX = torch.empty((I, NT), device=G2.device, dtype=torch.float32)
-                mfma_gemm.gemm_tokens(W2, G2, dX, I, O, NT, 1, NT, 0, NT, 0, transposed_weight=True)
+            if inplace and T % 32 == 0 and B * T >= 4 * _SLAB and mfma_gemm.nt_supported(G, samples, T):
+                dW = mfma_gemm.gemm_nt(G, samples, O, I, B, T, T, O * T, B * T, T).to(W2.dtype)
             else:
-                dX = W2.t() @ G2
+                G2 = G.permute(1, 0, 2).reshape(O, -1)                         # (O, B*T): one small copy
+                dW = nt_splitk(G2, samples).to(W2.dtype)
+        if ctx.needs_input_grad[1]:
+            if inplace and mfma_gemm.supported(I, O, B * T, W2, G):
+                dX = torch.empty((I, B * T), device=G.device, dtype=torch.float32)
+                mfma_gemm.gemm_tokens(W2, G, dX, I, O, T, B, T, O * T, B * T, T, transposed_weight=True)
+            else:
+                if G2 is None:
+                    G2 = G.permute(1, 0, 2).reshape(O, -1)
+                if mfma_gemm.supported(I, O, G2.shape[1], W2, G2) and W2.stride(1) == 1 and G2.is_contiguous():
+                    NT = G2.shape[1]
+                    dX = torch.empty((I, NT), device=G2.device, dtype=torch.float32)
+                    mfma_gemm.gemm_tokens(W2, G2, dX, I, O, NT, 1, NT, 0, NT, 0, transposed_weight=True)
+                else:
+                    dX = W2.t() @ G2
         return dW, dX, None
 
 
