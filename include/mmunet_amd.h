@@ -374,6 +374,29 @@ typedef struct {
 size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);
 int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream);
 
+/* ---- nn.Conv2d(C, 1, kernel_size=1): one output channel (RCG's gate, the side outputs) --------------------------- */
+/* src/UM_Net/MMUNet.py:346,386: out[b, p] = bias + sum_c weight[c] * input[b, c, p] over hw pixels; float32, contiguous
+ * NCHW, channels in {16, 64}, hw % 4 == 0.  bwd: dinput[b, c, p] = dout[b, p] weight[c] (optional), dweight [C] and
+ * dbias [1] (optional) as ordered sums of per-workgroup partials (deterministic).
+ * workspace (bwd): mmu_conv1x1_one_workspace_floats() floats. */
+typedef struct {
+    int32_t batch, channels;
+    int64_t hw;
+    const float *input;    /* [batch, channels, hw] */
+    const float *weight;   /* [channels] */
+    const float *bias;     /* [1] or NULL (fwd) */
+    float *out;            /* fwd: [batch, hw] */
+    const float *dout;     /* bwd: [batch, hw] */
+    float *dinput;         /* bwd, optional */
+    float *dweight;        /* bwd, optional */
+    float *dbias;          /* bwd, optional */
+    float *workspace;      /* bwd */
+} mmu_conv1x1_one_params;
+
+size_t mmu_conv1x1_one_workspace_floats(int batch, int channels, long hw);
+int mmu_conv1x1_one_fwd(const mmu_conv1x1_one_params *p, void *stream);
+int mmu_conv1x1_one_bwd(const mmu_conv1x1_one_params *p, void *stream);
+
 /* ---- conv1d + SiLU + x_proj + dt_proj of a small Mamba block in one kernel (a5/a6 glue, MMConv's blocks) ---- */
 /* mamba_ssm/ops/selective_scan_interface.py:173-210 for inner width dim in {2, 6}, conv width 4, dt_rank 1,
  * float32:  conv_out = silu(causal_conv1d(x)),  x_dbl[j] = sum_d x_proj_weight[j][d] conv_out[d]  (rows = dt_rank

@@ -117,6 +117,11 @@ class GemmNtParams(ctypes.Structure):
                 ("c", _vp), ("workspace", _vp)]
 
 
+class Conv1x1OneParams(ctypes.Structure):
+    _fields_ = [("batch", _i32), ("channels", _i32), ("hw", _i64)] + \
+               [(n, _vp) for n in ("input", "weight", "bias", "out", "dout", "dinput", "dweight", "dbias", "workspace")]
+
+
 class MambaPreParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("dim", _i32), ("seqlen", _i32), ("rows", _i32),
                 ("x", _vp), ("x_bs", _i64), ("x_ds", _i64), ("conv_weight", _vp), ("conv_bias", _vp),
@@ -149,6 +154,7 @@ EXPORTS = (
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
+    "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_debug_wave_scan",
 )
 
@@ -186,7 +192,8 @@ def lib():
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
                      ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams),
-                     ("mmu_gemm_nt_splitk", GemmNtParams)):
+                     ("mmu_gemm_nt_splitk", GemmNtParams),
+                     ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -198,6 +205,8 @@ def lib():
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_gemm_tokens_workspace_bytes.restype = ctypes.c_size_t
     L.mmu_gemm_tokens_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mmu_conv1x1_one_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_conv1x1_one_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
     L.mmu_gemm_nt_splitk_workspace_floats.restype = ctypes.c_size_t
     L.mmu_gemm_nt_splitk_workspace_floats.argtypes = [ctypes.c_int] * 4
     L.mmu_conv3x3_wgrad_mfma_workspace_floats.restype = ctypes.c_size_t

@@ -23,6 +23,7 @@ from .mamba_simple import Mamba, neg_exp, precomputed_A
 from . import conv3x3_mfma, conv3x3_small, morph_coords, norm_fused
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
+from . import pointwise
 from .tall_gemm import dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
@@ -299,7 +300,7 @@ class SideoutBlock(nn.Module):
         self.conv2 = nn.Conv2d(in_channels // 4, out_channels, kernel_size=1)
 
     def forward(self, x):
-        return self.conv2(self.dropout(run_fused(self.conv1, x)))
+        return pointwise.conv_module(self.conv2, self.dropout(run_fused(self.conv1, x)))
 
 
 class RCG(nn.Module):
@@ -325,7 +326,8 @@ class RCG(nn.Module):
         # (B, L, C) round trip -- 134 MB transposing copies each way at 256 x 256)
         out, _, _, _ = self.mamba.forward_bcl(x0.reshape(B, C, H * W))
         x0 = self.downsample(out.reshape(B, C, H, W))
-        return x0 * self.mlp(x2) * x2 + f
+        gate = torch.sigmoid(pointwise.conv_module(self.mlp[0], x2))       # mlp = Conv2d(64, 1, 1) -> Sigmoid
+        return x0 * gate * x2 + f
 
 
 class DecoderBlock(nn.Module):

@@ -1,0 +1,74 @@
+"""``conv1x1_one`` -- ``nn.Conv2d(C, 1, kernel_size=1)`` (one output channel) as streaming HIP kernels
+(csrc/pointwise_one.hip): RCG's gate ``mlp`` (src/UM_Net/MMUNet.py:386-387,414) and the side outputs' ``conv2``
+(MMUNet.py:346,350).  float32 contiguous NCHW, C in {16, 64}, H*W % 4 == 0; anything else is the caller's ``F.conv2d``.
+"""
+import torch
+
+from . import _lib
+
+ENABLED = True   # False: callers use F.conv2d (tests compare the two)
+
+
+def supported(x, weight):
+    return (ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and tuple(weight.shape[2:]) == (1, 1) and weight.shape[0] == 1 and weight.shape[1] == x.shape[1]
+            and x.shape[1] in (16, 64) and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] < 65536
+            and not torch.is_autocast_enabled())
+
+
+def module_supported(m, x):
+    return (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)
+            and m.groups == 1 and m.dilation == (1, 1) and supported(x, m.weight)
+            and (m.bias is None or m.bias.dtype == torch.float32))
+
+
+class Conv1x1OneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_gpu(x, weight)
+        if not supported(x, weight) or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != 1)):
+            raise RuntimeError("conv1x1_one: float32 NCHW input with 16 or 64 channels and H*W % 4 == 0, a [1, C, 1, 1] "
+                               "float32 weight and a float32 bias of one element required")
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+        p = _lib.Conv1x1OneParams()
+        p.batch, p.channels, p.hw = B, C, H * W
+        p.input, p.weight, p.bias, p.out = x.data_ptr(), weight.data_ptr(), _lib.ptr(bias), out.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_conv1x1_one_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.float().contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if not (need_x or need_w or need_b):
+            return None, None, None
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(1, device=x.device, dtype=torch.float32) if need_b else None
+        L = _lib.lib()
+        ws = torch.empty(L.mmu_conv1x1_one_workspace_floats(B, C, H * W), device=x.device, dtype=torch.float32)
+        p = _lib.Conv1x1OneParams()
+        p.batch, p.channels, p.hw = B, C, H * W
+        p.input, p.weight, p.dout = x.data_ptr(), weight.data_ptr(), g.data_ptr()
+        p.dinput, p.dweight, p.dbias, p.workspace = _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(L.mmu_conv1x1_one_bwd(p, _lib.stream_of(x)))
+        return dx, dw, db
+
+
+def conv1x1_one(x, weight, bias=None):
+    return Conv1x1OneFn.apply(x, weight, bias)
+
+
+def conv_module(m, x):
+    """``m(x)`` for an ``nn.Conv2d``: the HIP kernels when :func:`module_supported`, the module itself otherwise."""
+    return conv1x1_one(x, m.weight, m.bias) if module_supported(m, x) else m(x)

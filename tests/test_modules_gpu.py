@@ -994,3 +994,37 @@ def test_graph_replays_of_forward_backward_agree():
         assert float(rel.median()) < 0.25, f"replay {r}: median relative change of the gradient norms {float(rel.median()):.3f}"
         assert float((snaps[r]["line_predict.weight"] - snaps[0]["line_predict.weight"]).abs().max()) <= \
             1e-3 * float(snaps[0]["line_predict.weight"].abs().max())
+
+
+@pytest.mark.parametrize("case", [(8, 64, 128, 128), (2, 16, 20, 10), (1, 64, 6, 6), (3, 16, 64, 64)])
+def test_conv1x1_one_vs_conv2d(case):
+    """csrc/pointwise_one.hip == nn.Conv2d(C, 1, 1) (RCG's gate, MMUNet.py:386,414; side outputs, MMUNet.py:346): forward,
+    input / weight / bias gradients against ATen on the same GPU; reproducible; unsupported shapes refused."""
+    import torch.nn.functional as F
+    from mm_unet_amd import pointwise
+    B, C, H, W = case
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(B, C, H, W, device=DEV, generator=gen)
+    w = torch.randn(1, C, 1, 1, device=DEV, generator=gen)
+    b = torch.randn(1, device=DEV, generator=gen)
+    g = torch.randn(B, 1, H, W, device=DEV, generator=gen)
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    ref = F.conv2d(xr, wr, br)
+    ref.backward(g)
+    xo, wo, bo = (t.clone().requires_grad_() for t in (x, w, b))
+    assert pointwise.supported(xo, wo)
+    out = pointwise.conv1x1_one(xo, wo, bo)
+    out.backward(g)
+    close(out, ref, 1e-5, 1e-5, "forward")
+    close(xo.grad, xr.grad, 1e-5, 1e-5, "d input")     # (a single product here; the library sums a padded GEMM)
+    close(wo.grad, wr.grad, 1e-4, 1e-4 * (B * H * W) ** 0.5 / 30, "d weight")
+    close(bo.grad, br.grad, 1e-4, 1e-4 * (B * H * W) ** 0.5 / 30, "d bias")
+    xo2, wo2 = x.clone().requires_grad_(), w.clone().requires_grad_()
+    pointwise.conv1x1_one(xo2, wo2, None).backward(g)
+    assert torch.equal(wo2.grad, wo.grad) and torch.equal(xo2.grad, xo.grad)
+    # the conv module hook falls back to the module for what the kernel does not cover
+    m = torch.nn.Conv2d(C, 2, 1).to(DEV)
+    assert not pointwise.module_supported(m, x)
+    close(pointwise.conv_module(m, x), m(x), 0, 0, "fallback")
+    with pytest.raises(RuntimeError):
+        pointwise.conv1x1_one(x[:, :3].contiguous(), w[:, :3].contiguous(), None)
