@@ -68,7 +68,7 @@ __device__ __forceinline__ void block_sum_many_atomic(const float (&v)[NV], floa
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV4; i += 4) {
-        const float r = wave_sum4(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
+        const float r = wave_sum4_swap(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
                                   i + 3 < NV ? v[i + 3] : 0.f);
         if (lane >= 12 && lane < 16) lds[w * NV4 + i + lane - 12] = r;
     }
