@@ -24,7 +24,7 @@ from . import conv3x3_mfma, conv3x3_small, morph_coords, norm_fused
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
 from . import pointwise
-from .tall_gemm import dsc_gemm
+from .tall_gemm import conv1x1_stride2, conv1x1_stride2_supported, dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
 
@@ -232,6 +232,8 @@ def run_fused(seq, x, residual=None):
                 x = x + m.bias.view(1, -1, 1, 1)
             else:
                 x = conv3x3_mfma.conv3x3_mfma(x, m.weight, m.bias)
+        elif conv1x1_stride2_supported(m, x):     # shortcut of a down-sampling residual block
+            x = conv1x1_stride2(x, m.weight)
         else:
             x = m(x)
         i += 1

@@ -206,3 +206,61 @@ class _ProjBclFn(torch.autograd.Function):
 
 def proj_bcl(W, X, to_cb):
     return _ProjBclFn.apply(W, X, to_cb)
+
+
+class _Conv1x1Stride2Fn(torch.autograd.Function):
+    """``nn.Conv2d(I, O, kernel_size=1, stride=2, bias=False)`` -- the shortcut of the down-sampling residual blocks
+    (src/UM_Net/MMUNet.py:448) -- as a strided gather + ``W @ tokens`` per batch item.  The library runs it as an
+    implicit GEMM behind layout transposes (30 us forward, 86-99 us backward per call) and, like its 3 x 3 stride-2
+    kernels, not run-to-run reproducibly (tools/dbg/fwd_determinism.py); this path is deterministic: ordered GEMMs,
+    token-contraction weight gradient, plain strided scatter for the input gradient."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight):
+        B, I, H, W = x.shape
+        O = weight.shape[0]
+        xs = x[:, :, ::2, ::2].contiguous()
+        Ho, Wo = xs.shape[2], xs.shape[3]
+        T = Ho * Wo
+        W2 = weight.view(O, I)
+        out = torch.empty((B, O, T), device=x.device, dtype=torch.float32)
+        xs3 = xs.view(B, I, T)
+        if mfma_gemm.supported(O, I, B * T, W2, xs3, out) and T % 4 == 0:
+            mfma_gemm.gemm_tokens(W2, xs3, out, O, I, T, B, T, I * T, T, O * T)
+        else:
+            torch.matmul(W2, xs3, out=out)
+        ctx.save_for_backward(W2, xs3)
+        ctx.in_hw = (H, W)
+        return out.view(B, O, Ho, Wo)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, G):
+        W2, xs3 = ctx.saved_tensors
+        B, I, T = xs3.shape
+        O = W2.shape[0]
+        H, W = ctx.in_hw
+        G3 = G.float().contiguous().view(B, O, T)
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dxs = torch.matmul(W2.t(), G3)                                     # (B, I, T)
+            dx = torch.zeros((B, I, H, W), device=G.device, dtype=torch.float32)
+            dx[:, :, ::2, ::2] = dxs.view(B, I, (H + 1) // 2, (W + 1) // 2)
+        if ctx.needs_input_grad[1]:
+            if T % 32 == 0 and B * T >= 4 * _SLAB and mfma_gemm.nt_supported(G3, xs3, T):
+                dW = mfma_gemm.gemm_nt(G3, xs3, O, I, B, T, T, O * T, T, I * T)
+            else:
+                dW = torch.einsum("bot,bit->oi", G3, xs3)
+            dW = dW.view(O, I, 1, 1)
+        return dx, dW
+
+
+def conv1x1_stride2(x, weight):
+    return _Conv1x1Stride2Fn.apply(x, weight)
+
+
+def conv1x1_stride2_supported(m, x):
+    return (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
+            and m.bias is None and m.groups == 1 and m.dilation == (1, 1) and x.is_cuda and x.dim() == 4
+            and x.dtype == torch.float32 and m.weight.dtype == torch.float32 and not torch.is_autocast_enabled())

@@ -957,8 +957,8 @@ def test_graph_replays_of_forward_backward_agree():
     captured, those memset nodes did not clear the buffers on replays, and from the second replay on the gradients of
     the small sizes (sliced d(row) of the sampler, the Mamba projections of every MMConv) were garbage / NaN.  Three
     replays of the captured forward + backward on fixed weights and inputs must give finite gradients that agree.
-    They do not agree bit for bit: the library's strided 1 x 1 convolution of the encoder shortcuts is not run-to-run
-    reproducible (1 ulp, tools/dbg/fwd_determinism.py: every module before encoder3.0.block2.0 is), the backward adds
+    They do not agree bit for bit: the library's stride-2 convolutions of the encoder are not run-to-run reproducible
+    (1 ulp, tools/dbg/fwd_determinism.py: every module before encoder3.0.block1.0 is), the backward adds
     with float atomics, and at this input size the deepest BatchNorms see 2 x 2 pixels, which amplifies both: the
     median change of the gradient norms between replays is 1e-3..2e-2 (tools/dbg/replay_drift.py), garbage from
     unzeroed buffers was orders of magnitude / NaN.  Loose bound on well-conditioned tensors only."""
@@ -1028,3 +1028,30 @@ def test_conv1x1_one_vs_conv2d(case):
     close(pointwise.conv_module(m, x), m(x), 0, 0, "fallback")
     with pytest.raises(RuntimeError):
         pointwise.conv1x1_one(x[:, :3].contiguous(), w[:, :3].contiguous(), None)
+
+
+@pytest.mark.parametrize("case", [(8, 64, 128, 64, 64), (2, 16, 24, 10, 14), (1, 128, 256, 7, 9), (8, 256, 512, 32, 32)])
+def test_conv1x1_stride2_vs_conv2d(case):
+    """tall_gemm.conv1x1_stride2 == nn.Conv2d(I, O, 1, stride=2, bias=False) (MMUNet.py:448, the down-sampling shortcut):
+    forward, input and weight gradients against ATen; bit-reproducible (the library's forward is not)."""
+    import torch.nn.functional as F
+    from mm_unet_amd.tall_gemm import conv1x1_stride2
+    B, I, O, H, W = case
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(B, I, H, W, device=DEV, generator=gen)
+    w = torch.randn(O, I, 1, 1, device=DEV, generator=gen) / I ** 0.5
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, stride=2)
+    g = torch.randn(ref.shape, device=DEV, generator=gen)
+    ref.backward(g)
+    outs = []
+    for _ in range(2):
+        xo, wo = x.clone().requires_grad_(), w.clone().requires_grad_()
+        out = conv1x1_stride2(xo, wo)
+        out.backward(g)
+        outs.append((out.detach(), xo.grad, wo.grad))
+    out, gx, gw = outs[0]
+    close(out, ref, 1e-4, 1e-4, "forward")
+    close(gx, xr.grad, 1e-4, 1e-4, "d input")
+    close(gw, wr.grad, 1e-3, 2e-4 * (B * ref.shape[2] * ref.shape[3]) ** 0.5, "d weight")
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
