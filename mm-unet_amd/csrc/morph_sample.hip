@@ -29,6 +29,7 @@ namespace {
 struct MorphArgs {
     int B, C, H, W, K, cs;  // cs = channel slices (grid.z = B * cs)
     int reach;              // gather window in rows (< 0: scatter everything, din pre-zeroed)
+    int xcd_swizzle;        // gather: workgroups re-numbered so that an XCD owns a band of rows
     long so_b, so_c, so_h, so_k;  // element strides of out / dout (unit stride along w)
     const void *in;         // [B, C, H, W], in_t (float or bf16_t: activations under autocast)
     const float *y;         // [B, K, H, W]  row coordinate in pixels (unclamped)
@@ -151,7 +152,12 @@ __global__ __launch_bounds__(256) void morph_sample_bwd_kernel(MorphArgs p) {
 // d input as a gather (see the header).  grid (ceil(H*W / 256), 1, B * ceil(C / CS)); thread = (yy, col).
 template <int CS, typename in_t>
 __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups go round-robin over the 8 XCDs, each with its own L2; a pixel reads the gradient rows yy - 2 .. yy + 2, so
+    // with the natural order every XCD fetches (nearly) every row.  Re-numbered so that an XCD owns a contiguous band of
+    // rows, the 5x row reuse stays inside one L2.
+    int bx = blockIdx.x;
+    if (p.xcd_swizzle) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    const int pos = bx * blockDim.x + threadIdx.x;
     const int HW = p.H * p.W;
     if (pos >= HW) return;
     const int yy = pos / p.W, col = pos - yy * p.W;
@@ -263,6 +269,8 @@ extern "C" int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream) {
     {
         constexpr int CS = 16;
         dim3 gg((a.H * a.W + 255) / 256, 1, a.B * ((a.C + CS - 1) / CS));
+        static const bool swz = []() { const char *e = getenv("MMU_MORPH_XCD"); return !e || e[0] != '0'; }();
+        a.xcd_swizzle = (swz && gg.x % 8 == 0 && gg.x >= 64) ? 1 : 0;
         if (p->in_dtype == MMU_DTYPE_BF16)
             morph_gather_din_kernel<CS, bf16_t><<<gg, 256, 0, st>>>(a);
         else
