@@ -57,8 +57,13 @@ __device__ __forceinline__ void din_add(bf16_t *p, float v) {
 }
 
 __device__ __forceinline__ bool decode(const MorphArgs &p, int &b, int &k, int &h, int &w, int &c0, int &c1) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const int HW = p.H * p.W;
+    int bx = blockIdx.x;
+    if (p.xcd_swizzle) {   // per tap: an XCD owns a band of rows (the taps and neighbouring rows share input rows)
+        const int nbk = HW >> 8, kk = bx / nbk, r = bx - kk * nbk;
+        bx = kk * nbk + (r & 7) * (nbk >> 3) + (r >> 3);
+    }
+    const int pos = bx * blockDim.x + threadIdx.x;
     if (pos >= p.K * HW) return false;
     k = pos / HW;
     const int r = pos - k * HW;
@@ -212,6 +217,13 @@ int channel_slices(int B, int C, int positions) {
     return cs;
 }
 
+// sampler kernels: blocks per tap a multiple of 8 (and enough of them) for the per-tap XCD banding of decode()
+int sampler_swizzle(const MorphArgs &a) {
+    static const bool on = []() { const char *e = getenv("MMU_MORPH_XCD"); return !e || e[0] != '0'; }();
+    const long HW = (long)a.H * a.W;
+    return (on && HW % 2048 == 0 && HW / 256 >= 64) ? 1 : 0;
+}
+
 void set_out_strides(MorphArgs &a, int layout) {
     const long HW = (long)a.H * a.W;
     if (layout == MMU_MORPH_TOKENS_LAST) {  // [C][K][B][H][W]
@@ -246,6 +258,7 @@ extern "C" int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream) {
     const int positions = a.K * a.H * a.W;
     a.cs = channel_slices(a.B, a.C, positions);
     dim3 grid((positions + 255) / 256, 1, a.B * a.cs);
+    a.xcd_swizzle = 0;   // (banding measured on the forward: no change -- it is bound by its K-times larger output)
     if (p->in_dtype == MMU_DTYPE_BF16)
         morph_sample_fwd_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     else
@@ -282,6 +295,7 @@ extern "C" int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream) {
         if (e != hipSuccess) return mmu_fail("morph_sample_bwd: memset: %s", hipGetErrorString(e));
     }
     dim3 grid((positions + 255) / 256, 1, a.B * a.cs);
+    a.xcd_swizzle = sampler_swizzle(a);
     if (p->in_dtype == MMU_DTYPE_BF16)
         morph_sample_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
     else
