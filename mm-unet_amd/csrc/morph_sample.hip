@@ -30,6 +30,7 @@ struct MorphArgs {
     int B, C, H, W, K, cs;  // cs = channel slices (grid.z = B * cs)
     int reach;              // gather window in rows (< 0: scatter everything, din pre-zeroed)
     int xcd_swizzle;        // gather: workgroups re-numbered so that an XCD owns a band of rows
+    int zero_dy;            // gather: also clears dy (the sampler backward that follows adds into it)
     long so_b, so_c, so_h, so_k;  // element strides of out / dout (unit stride along w)
     const void *in;         // [B, C, H, W], in_t (float or bf16_t: activations under autocast)
     const float *y;         // [B, K, H, W]  row coordinate in pixels (unclamped)
@@ -207,6 +208,10 @@ __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
 #pragma unroll
     for (int c = 0; c < CS; ++c)
         if (c < nc) dst[(long)c * HW] = from_f32<in_t>(acc[c]);
+    // d(row) is summed with float atomics by the channel slices of the kernel that runs next: its zero fill rides along
+    // here (slice 0), one launch less per MMConv backward
+    if (p.zero_dy && c0 == 0)
+        for (int k = 0; k < p.K; ++k) p.dy[((long)(b * p.K + k) * p.H + yy) * p.W + col] = 0.f;
 }
 
 int channel_slices(int B, int C, int positions) {
@@ -284,16 +289,14 @@ extern "C" int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream) {
         dim3 gg((a.H * a.W + 255) / 256, 1, a.B * ((a.C + CS - 1) / CS));
         static const bool swz = []() { const char *e = getenv("MMU_MORPH_XCD"); return !e || e[0] != '0'; }();
         a.xcd_swizzle = (swz && gg.x % 8 == 0 && gg.x >= 64) ? 1 : 0;
+        a.zero_dy = a.cs > 1 ? 1 : 0;
         if (p->in_dtype == MMU_DTYPE_BF16)
             morph_gather_din_kernel<CS, bf16_t><<<gg, 256, 0, st>>>(a);
         else
             morph_gather_din_kernel<CS, float><<<gg, 256, 0, st>>>(a);
         MMU_HIP_LAUNCH_CHECK("morph_gather_din");
     }
-    if (a.cs > 1) {
-        hipError_t e = mmu_zero_async(a.dy, (size_t)a.B * positions, st);
-        if (e != hipSuccess) return mmu_fail("morph_sample_bwd: memset: %s", hipGetErrorString(e));
-    }
+    a.zero_dy = 0;
     dim3 grid((positions + 255) / 256, 1, a.B * a.cs);
     a.xcd_swizzle = sampler_swizzle(a);
     if (p->in_dtype == MMU_DTYPE_BF16)
