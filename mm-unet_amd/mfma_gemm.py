@@ -65,7 +65,9 @@ def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False, narr
         raise RuntimeError("gemm_nt: seqlen must be a multiple of 32 and the strides multiples of 4")
     L = _lib.lib()
     c = torch.empty((m, n), device=a.device, dtype=torch.float32)
-    ws = torch.empty(L.mmu_gemm_nt_splitk_workspace_floats(m, n, batch, seqlen), device=a.device, dtype=torch.float32)
+    with torch.cuda.device(a.device):   # the slab count follows the CU count of the device that runs the kernel
+        nws = L.mmu_gemm_nt_splitk_workspace_floats(m, n, batch, seqlen)
+    ws = torch.empty(nws, device=a.device, dtype=torch.float32)
     p = _lib.GemmNtParams()
     p.m, p.n, p.batch, p.seqlen, p.exact_products, p.narrow_steps = m, n, batch, seqlen, int(exact), int(narrow)
     p.a, p.a_rs, p.a_bs = a.data_ptr(), a_rs, a_bs
