@@ -1055,3 +1055,43 @@ def test_conv1x1_stride2_vs_conv2d(case):
     close(gx, xr.grad, 1e-4, 1e-4, "d input")
     close(gw, wr.grad, 1e-3, 2e-4 * (B * ref.shape[2] * ref.shape[3]) ** 0.5, "d weight")
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+def test_validation_path_on_the_gpu_vs_oracle_windows():
+    """f3 on the device (train.py:83-139): ``validate`` -- sliding-window inference with the HIP MM_Net as predictor,
+    post-transform, metrics, loss -- against the same windows pushed through the CPU oracle model
+    (oracle/model_ref.py) and averaged by hand.  128 x 160 image, 96 x 96 windows, overlap 0.5: 2 x 3 windows."""
+    from oracle import model_ref
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    from mm_unet_amd.validate import SegmentationMetrics, _starts, post_trans, validate
+    import mm_unet_amd.mmunet as pm
+    torch.manual_seed(50)
+    model = pm.MM_Net(num_classes=1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    gen = torch.Generator().manual_seed(21)
+    img = torch.randn(1, 3, 128, 160, generator=gen)
+    lab = (torch.rand(1, 1, 128, 160, generator=gen) > 0.85).float()
+    loss_fn = DICE_BCE_Loss()
+    metrics, loss = validate(model, [(img.to(DEV), lab.to(DEV))], (96, 96), loss_fn=loss_fn, overlap=0.5)
+    assert not model.training
+    ys, xs = _starts(128, 96, 0.5), _starts(160, 96, 0.5)
+    assert len(ys) * len(xs) == 6
+    ref, cnt = torch.zeros(1, 1, 128, 160), torch.zeros(1, 1, 128, 160)
+    with torch.no_grad():
+        for y in ys:
+            for x in xs:
+                ref[:, :, y:y + 96, x:x + 96] += model_ref.mm_net(sd, img[:, :, y:y + 96, x:x + 96], training=False)
+                cnt[:, :, y:y + 96, x:x + 96] += 1
+    ref = ref / cnt
+    from mm_unet_amd.validate import sliding_window_inference
+    with torch.no_grad():
+        logits = sliding_window_inference(img.to(DEV), (96, 96), model, 0.5).cpu()
+    close(logits, ref, 0.0, 1e-3, "sliding-window logits")
+    assert abs(loss - float(loss_fn(ref, lab))) < 1e-3
+    m_ref = SegmentationMetrics()
+    m_ref(post_trans(ref), lab)
+    want = m_ref.aggregate()
+    # a logit within 1e-3 of the threshold may flip a pixel: metrics agree to a few pixels of 20,480
+    for k, v in want.items():
+        assert abs(metrics[k] - v) < 5e-3, (k, metrics[k], v)
