@@ -722,3 +722,30 @@ def test_gemm_nt_splitk_vs_float64(case):
         assert torch.equal(c1, c2)
         err = float((c1.double().cpu() - ref).abs().max())
         assert err <= tol * (b * l) ** 0.5, f"exact={exact} narrow={narrow}: max abs err {err:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(256, 64), (36, 128), (64, 192)])
+def test_gemm_nt_full_size_properties(shape):
+    """csrc/gemm_nt_splitk.hip at the headline token count (B * L = 8 * 65,536, the slab plans of the real calls): against
+    the library's batched split-K on the same operands, batch-major vs channel-major addressing of the same data
+    (identical bits: same contraction order), and linearity in the first operand."""
+    from mm_unet_amd import mfma_gemm
+    from mm_unet_amd.tall_gemm import nt_splitk
+    m, n = shape
+    B, L = 8, 65536
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    a = torch.randn(m, B, L, device=DEV, generator=gen)          # storage [m][B][L]
+    b = torch.randn(n, B, L, device=DEV, generator=gen)
+    c = mfma_gemm.gemm_nt(a, b, m, n, B, L, B * L, L, B * L, L)
+    mfma_gemm.NT_ENABLED = False
+    try:
+        ref = nt_splitk(a.view(m, B * L), b.view(n, B * L))
+    finally:
+        mfma_gemm.NT_ENABLED = True
+    scale = (B * L) ** 0.5
+    assert float((c - ref).abs().max()) <= 3e-5 * scale
+    a_bm = a.permute(1, 0, 2).contiguous()                        # the same values stored [B][m][L]
+    c_bm = mfma_gemm.gemm_nt(a_bm, b, m, n, B, L, L, m * L, B * L, L)
+    assert torch.equal(c_bm, c)
+    c2 = mfma_gemm.gemm_nt(2.0 * a, b, m, n, B, L, B * L, L, B * L, L)
+    assert torch.equal(c2, 2.0 * c)                               # powers of two commute with every rounding
