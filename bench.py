@@ -15,6 +15,8 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   "roofline_bwd", "roofline_d6", "roofline_bwd_d6", "roofline_conv1d", "roofline_conv1d_bwd":
                   the same for the scan backward (bytes s*B*L*(8D+2N) + 4*B*L*2N), for both at the 6-channel census
                   shape of MMConv's Mamba blocks (B=8, D=6, L=65536), and for causal conv1d (2 / 3 * s*B*D*L);
+  "roofline_gemm_nt": the token-contraction weight-gradient product (csrc/gemm_nt_splitk.hip) at out_proj's shape of the
+                  128-channel Mamba blocks (128 x 64 over B*L = 524,288 tokens), bytes s*(M+N)*B*L, same timing method;
   "roofline_conv": the MFMA-bound kernel of the path (csrc/conv3x3_mfma.hip at CBAM's shape [8,64,256,256] 64->64 and
                   at a Unet shape [8,256,64,64] 256->256), same timing method; achieved = bf16 MFMA FLOP/s actually
                   issued (3 passes of 2*B*Cout*H*W*Cin*9 for the hi/lo split); peak = 2.5 PFLOP/s dense bf16;
@@ -144,6 +146,19 @@ def scan_rooflines(dev, iters=20):
                 "HBM (streaming)")
             leg("roofline_conv1d_bwd", "mmu_causal_conv1d_bwd (dx, dW, db)", cshape, 3 * s_ * b * d * l, ms_cb,
                 "HBM (streaming) + per-block reductions for dW / db")
+            # the projections' weight gradients: dW = G . X^T contracted over all B * L tokens;
+            # out_proj's shape of the 128-channel Mamba blocks, operands as the model holds them ([C][B][L] storage)
+            from mm_unet_amd import mfma_gemm
+            gm, gn = 128, 64
+            ga = torch.randn(gm, b, l, device=dev)
+            gb = torch.randn(gn, b, l, device=dev)
+            ms_nt = _timed(dev, lambda: mfma_gemm.gemm_nt(ga, gb, gm, gn, b, l, b * l, l, b * l, l), iters)
+            leg("roofline_gemm_nt", "mmu_gemm_nt_splitk = gemm_nt_wide_kernel (128-token steps, bf16 hi/lo split on the "
+                "matrix cores, fp32 accumulate) + gemm_nt_reduce_kernel (ordered slab sums)",
+                {"m": gm, "n": gn, "tokens": b * l, "dtype": "f32"}, s_ * (gm + gn) * b * l, ms_nt,
+                "HBM (streaming: both operands read once, 512 contiguous bytes per row and load)",
+                _traffic("gemm_nt_traffic.json"))
+            del ga, gb
     return legs
 
 
