@@ -54,7 +54,9 @@ def test_param_structs_match_header_field_order():
                         ("mmu_mamba_pre_params", _lib.MambaPreParams),
                         ("mmu_mamba_post_params", _lib.MambaPostParams),
                         ("mmu_conv3x3_mfma_params", _lib.Conv3x3MfmaParams),
-                        ("mmu_gemm_tokens_params", _lib.GemmTokensParams)):
+                        ("mmu_gemm_tokens_params", _lib.GemmTokensParams),
+                        ("mmu_gemm_nt_params", _lib.GemmNtParams),
+                        ("mmu_conv1x1_one_params", _lib.Conv1x1OneParams)):
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 
 
