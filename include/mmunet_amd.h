@@ -374,6 +374,19 @@ typedef struct {
 size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);
 int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream);
 
+/* ---- out = sum of up to four float32 tensors, as float32 or bfloat16 (the state-group sums of a d_state > 16 scan) -- */
+/* selective_scan_hip._fwd_groups / _bwd_groups: the per-token outputs of a d_state-64 scan are the sums of its four
+ * dstate-16 launches' float32 partial outputs (selective_scan_fwd_kernel.cuh:147-298 computes them in one pass over 64
+ * states); contiguous tensors of n elements, 16-byte aligned. */
+typedef struct {
+    int64_t n;
+    int32_t nparts, out_dtype;   /* 1..4; MMU_DTYPE_F32 or MMU_DTYPE_BF16 */
+    const float *parts[4];
+    void *out;
+} mmu_sum_parts_params;
+
+int mmu_sum_parts(const mmu_sum_parts_params *p, void *stream);
+
 /* ---- nn.Conv2d(C, 1, kernel_size=1): one output channel (RCG's gate, the side outputs) --------------------------- */
 /* src/UM_Net/MMUNet.py:346,386: out[b, p] = bias + sum_c weight[c] * input[b, c, p] over hw pixels; float32, contiguous
  * NCHW, channels in {16, 64}, hw % 4 == 0.  bwd: dinput[b, c, p] = dout[b, p] weight[c] (optional), dweight [C] and

@@ -217,6 +217,35 @@ def _acc(total, part):
     return part if total is None else total.add_(part)
 
 
+def _sum_parts(parts, dtype, out=None):
+    """Sum of the groups' float32 partial outputs in the I/O type: one pass (csrc/sum_parts.hip) instead of three in-place
+    adds and a cast.  ``out``: optional destination (contiguous, ``dtype``)."""
+    parts = [t for t in parts if t is not None]
+    if not parts:
+        return None
+    ok = (all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in parts)
+          and dtype in (torch.float32, torch.bfloat16) and len(parts) <= 4
+          and (out is None or (out.is_contiguous() and out.dtype == dtype and out.data_ptr() % 16 == 0)))
+    if not ok:
+        total = parts[0]
+        for t in parts[1:]:
+            total = total.add_(t) if total.dtype == torch.float32 else total + t
+        if out is not None:
+            return out.copy_(total)
+        return total.to(dtype)
+    if len(parts) == 1 and dtype == torch.float32 and out is None:
+        return parts[0]
+    res = out if out is not None else torch.empty(parts[0].shape, device=parts[0].device, dtype=dtype)
+    p = _lib.SumPartsParams()
+    p.n, p.nparts, p.out_dtype = parts[0].numel(), len(parts), _lib.dtype_code(res)
+    for k, t in enumerate(parts):
+        p.parts[k] = t.data_ptr()
+    p.out = res.data_ptr()
+    with torch.cuda.device(res.device):
+        _lib.check(_lib.lib().mmu_sum_parts(p, _lib.stream_of(res)))
+    return res
+
+
 def _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
     """Everything the kernel computes per token is LINEAR in the group's y -- out = y, out_z = y silu(z) -- so every
     group launch gets z (and group 0 gets D) and the outputs are simply added up."""
@@ -228,17 +257,16 @@ def _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out
     _check(T == chunk_len(16, u.dtype), "selective_scan: group split needs equal chunk lengths")
     n_chunks = (seqlen + T - 1) // T
     x = torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device, dtype=torch.float32)
-    out = out_z = None
+    outs, out_zs = [], []
     for g, sl, Ag, Bg, Cg in _groups(A, B, C):
         r = _fwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, z_, delta_bias_, delta_softplus,
                      want_out=want_out or z_ is None)
         x[..., 32 * g:32 * g + 32] = r[1]
-        if r[0] is not None:
-            out = _acc(out, r[0])
+        outs.append(r[0])
         if z_ is not None:
-            out_z = _acc(out_z, r[2])
-    out = out.to(io_dtype) if out is not None else None
-    return [out, x] if z_ is None else [out, x, out_z.to(io_dtype)]
+            out_zs.append(r[2])
+    out = _sum_parts(outs, io_dtype)
+    return [out, x] if z_ is None else [out, x, _sum_parts(out_zs, io_dtype)]
 
 
 def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_softplus, recompute_out_z,
@@ -255,32 +283,35 @@ def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_sof
     dB = dB_out if dB_out is not None else torch.empty((batch, g_, dstate, seqlen), **f32)
     dC = dC_out if dC_out is not None else torch.empty((batch, g_, dstate, seqlen), **f32)
     dA = torch.empty((dim, dstate), **f32)
-    du = ddelta = dbias = dD = dz = out_z = None
+    dbias = dD = None
+    dus, ddeltas, dzs, out_zs = [], [], [], []
     for g, sl, Ag, Bg, Cg in _groups(A, B, C):
         r = _bwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, z_, delta_bias_, dout,
                      x_[..., 32 * g:32 * g + 32].contiguous(), None, None, delta_softplus, recompute_out_z,
                      dB_out=dB[:, :, sl], dC_out=dC[:, :, sl])
         dA[:, sl] = r[2]
-        du, ddelta = _acc(du, r[0]), _acc(ddelta, r[1])
+        dus.append(r[0])
+        ddeltas.append(r[1])
         if g == 0:
             dD = r[5]
         if r[6] is not None:
             dbias = _acc(dbias, r[6])
         if z_ is not None:
-            dz = _acc(dz, r[7])
+            dzs.append(r[7])
             if recompute_out_z:
-                out_z = _acc(out_z, r[8])
-    result = [du.to(io_dtype), ddelta.to(io_dtype), dA, dB if dB.dtype == bc_dtype else dB.to(bc_dtype),
+                out_zs.append(r[8])
+    result = [_sum_parts(dus, io_dtype), _sum_parts(ddeltas, io_dtype), dA, dB if dB.dtype == bc_dtype else dB.to(bc_dtype),
               dC if dC.dtype == bc_dtype else dC.to(bc_dtype), dD, dbias]
     if z_ is not None:
-        if dz_ is not None:
-            dz_.copy_(dz)
-            dz = dz_
+        if dz_ is not None and dz_.is_contiguous():
+            dz = _sum_parts(dzs, dz_.dtype, out=dz_)
+        elif dz_ is not None:
+            dz = dz_.copy_(_sum_parts(dzs, torch.float32))
         else:
-            dz = dz.to(io_dtype)
+            dz = _sum_parts(dzs, io_dtype)
         result.append(dz)
         if recompute_out_z:
-            result.append(out_z.to(io_dtype))
+            result.append(_sum_parts(out_zs, io_dtype))
     return result
 
 
