@@ -249,16 +249,17 @@ int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream);
 /* ---- token re-orderings of the tri-directional Mamba block (first step) ---- */
 /* requirements/mamba_simple.py:212-270: the "v3" block scans xz as is, token-reversed and slice-interleaved
  * (token i of slice s -> position i*nslices + s) and adds the three results after undoing the re-orderings.
- * Tensors are float32 [rows][seqlen] with dense rows.
+ * Tensors are [rows][seqlen] with dense rows, float32 -- or bfloat16 (dtype) for 5..64 slices, float32 arithmetic.
  *   split   : a -> flip[L-1-t] = a[t],  slice[i*nslices + s] = a[s*(L/nslices) + i]
  *   combine : out[t] = a[t] + flip[L-1-t] + slice[i*nslices + s]     (t = s*(L/nslices) + i)
  * Each is the adjoint of the other (so each serves as the other's backward). */
 typedef struct {
     int32_t rows, seqlen, nslices;
-    const float *a;   /* split: input;  combine: first addend (original token order) */
-    float *flip;      /* split: output; combine: input (token-reversed order) */
-    float *slice;     /* split: output; combine: input (slice-interleaved order) */
-    float *out;       /* combine: output */
+    const void *a;    /* split: input;  combine: first addend (original token order) */
+    void *flip;       /* split: output; combine: input (token-reversed order) */
+    void *slice;      /* split: output; combine: input (slice-interleaved order) */
+    void *out;        /* combine: output */
+    int32_t dtype;    /* MMU_DTYPE_F32 (0) or MMU_DTYPE_BF16 */
 } mmu_tri_params;
 
 int mmu_tri_split(const mmu_tri_params *p, void *stream);

@@ -85,7 +85,8 @@ class Conv3x3sParams(ctypes.Structure):
 
 
 class TriParams(ctypes.Structure):
-    _fields_ = ([(n, _i32) for n in ("rows", "seqlen", "nslices")] + [(n, _vp) for n in ("a", "flip", "slice", "out")])
+    _fields_ = ([(n, _i32) for n in ("rows", "seqlen", "nslices")] + [(n, _vp) for n in ("a", "flip", "slice", "out")]
+                + [("dtype", _i32)])
 
 
 class NormParams(ctypes.Structure):

@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void tri_combine_kernel(const float *__restric
 // nslices in 5..64: the slice interleave is a transpose of the [nslices][L/nslices] view of a row.  A workgroup
 // takes 64 positions i of every slice: reads are contiguous along i per slice, the interleaved side is one
 // contiguous run of 64*nslices floats, the transpose happens in a padded LDS tile (conflict-free both ways).
-__global__ __launch_bounds__(256) void tri_split_tiled_kernel(const float *__restrict__ x, float *__restrict__ xf,
-                                                              float *__restrict__ xs, int L, int ns) {
+template <typename io_t>
+__global__ __launch_bounds__(256) void tri_split_tiled_kernel(const io_t *__restrict__ x, io_t *__restrict__ xf,
+                                                              io_t *__restrict__ xs, int L, int ns) {
     __shared__ float tile[64][65];
     const int Ls = L / ns;
     const int i0 = blockIdx.x * 64;
@@ -81,18 +82,19 @@ __global__ __launch_bounds__(256) void tri_split_tiled_kernel(const float *__res
     for (int sl = ry; sl < ns; sl += 4) {
         if (tx < ni) {
             const int t = sl * Ls + i0 + tx;
-            const float v = x[base + t];
-            xf[base + L - 1 - t] = v;
-            tile[sl][tx] = v;
+            const io_t raw = x[base + t];
+            xf[base + L - 1 - t] = raw;
+            tile[sl][tx] = to_f32(raw);
         }
     }
     __syncthreads();
-    float *dst = xs + base + (long)i0 * ns;
-    for (int j = threadIdx.x; j < ni * ns; j += 256) dst[j] = tile[j % ns][j / ns];
+    io_t *dst = xs + base + (long)i0 * ns;
+    for (int j = threadIdx.x; j < ni * ns; j += 256) dst[j] = from_f32<io_t>(tile[j % ns][j / ns]);
 }
 
-__global__ __launch_bounds__(256) void tri_combine_tiled_kernel(const float *__restrict__ a, const float *__restrict__ bf,
-                                                                const float *__restrict__ cs, float *__restrict__ out,
+template <typename io_t>
+__global__ __launch_bounds__(256) void tri_combine_tiled_kernel(const io_t *__restrict__ a, const io_t *__restrict__ bf,
+                                                                const io_t *__restrict__ cs, io_t *__restrict__ out,
                                                                 int L, int ns) {
     __shared__ float tile[64][65];
     const int Ls = L / ns;
@@ -100,13 +102,13 @@ __global__ __launch_bounds__(256) void tri_combine_tiled_kernel(const float *__r
     const long base = (long)blockIdx.y * L;
     const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int ni = Ls - i0 < 64 ? Ls - i0 : 64;
-    const float *src = cs + base + (long)i0 * ns;
-    for (int j = threadIdx.x; j < ni * ns; j += 256) tile[j % ns][j / ns] = src[j];
+    const io_t *src = cs + base + (long)i0 * ns;
+    for (int j = threadIdx.x; j < ni * ns; j += 256) tile[j % ns][j / ns] = to_f32(src[j]);
     __syncthreads();
     for (int sl = ry; sl < ns; sl += 4) {
         if (tx < ni) {
             const int t = sl * Ls + i0 + tx;
-            out[base + t] = a[base + t] + bf[base + L - 1 - t] + tile[sl][tx];
+            out[base + t] = from_f32<io_t>(to_f32(a[base + t]) + to_f32(bf[base + L - 1 - t]) + tile[sl][tx]);
         }
     }
 }
@@ -116,6 +118,8 @@ int check(const mmu_tri_params *p, const char *name) {
     MMU_CHECK(p->rows > 0 && p->seqlen > 0 && p->nslices > 0, "%s: empty tensor", name);
     MMU_CHECK(p->seqlen % p->nslices == 0, "%s: seqlen %d must be divisible by nslices %d", name, p->seqlen, p->nslices);
     MMU_CHECK(p->rows < 65536, "%s: more than 65535 rows", name);
+    MMU_CHECK(p->dtype == MMU_DTYPE_F32 || (p->dtype == MMU_DTYPE_BF16 && p->nslices > 4 && p->nslices <= 64),
+              "%s: float32, or bfloat16 with 5..64 slices (got dtype %d, %d slices)", name, p->dtype, p->nslices);
     return 0;
 }
 
@@ -127,13 +131,17 @@ extern "C" int mmu_tri_split(const mmu_tri_params *p, void *stream) {
     const int Ls = p->seqlen / p->nslices;
     dim3 grid((Ls + 255) / 256, p->rows);
     hipStream_t st = (hipStream_t)stream;
-    if (p->nslices == 4 && ((uintptr_t)p->slice & 15) == 0 && p->seqlen % 4 == 0)
-        tri_split_kernel<4><<<grid, 256, 0, st>>>(p->a, p->flip, p->slice, p->seqlen, 4);
+    const float *a = (const float *)p->a;
+    float *fl = (float *)p->flip, *sl = (float *)p->slice;
+    if (p->dtype == MMU_DTYPE_BF16)
+        tri_split_tiled_kernel<bf16_t><<<dim3((Ls + 63) / 64, p->rows), 256, 0, st>>>(
+            (const bf16_t *)p->a, (bf16_t *)p->flip, (bf16_t *)p->slice, p->seqlen, p->nslices);
+    else if (p->nslices == 4 && ((uintptr_t)p->slice & 15) == 0 && p->seqlen % 4 == 0)
+        tri_split_kernel<4><<<grid, 256, 0, st>>>(a, fl, sl, p->seqlen, 4);
     else if (p->nslices > 4 && p->nslices <= 64)
-        tri_split_tiled_kernel<<<dim3((Ls + 63) / 64, p->rows), 256, 0, st>>>(p->a, p->flip, p->slice, p->seqlen,
-                                                                               p->nslices);
+        tri_split_tiled_kernel<float><<<dim3((Ls + 63) / 64, p->rows), 256, 0, st>>>(a, fl, sl, p->seqlen, p->nslices);
     else
-        tri_split_kernel<0><<<grid, 256, 0, st>>>(p->a, p->flip, p->slice, p->seqlen, p->nslices);
+        tri_split_kernel<0><<<grid, 256, 0, st>>>(a, fl, sl, p->seqlen, p->nslices);
     MMU_HIP_LAUNCH_CHECK("tri_split");
     return 0;
 }
@@ -144,13 +152,17 @@ extern "C" int mmu_tri_combine(const mmu_tri_params *p, void *stream) {
     const int Ls = p->seqlen / p->nslices;
     dim3 grid((Ls + 255) / 256, p->rows);
     hipStream_t st = (hipStream_t)stream;
-    if (p->nslices == 4 && ((uintptr_t)p->slice & 15) == 0 && p->seqlen % 4 == 0)
-        tri_combine_kernel<4><<<grid, 256, 0, st>>>(p->a, p->flip, p->slice, p->out, p->seqlen, 4);
+    const float *a = (const float *)p->a, *fl = (const float *)p->flip, *sl = (const float *)p->slice;
+    float *out = (float *)p->out;
+    if (p->dtype == MMU_DTYPE_BF16)
+        tri_combine_tiled_kernel<bf16_t><<<dim3((Ls + 63) / 64, p->rows), 256, 0, st>>>(
+            (const bf16_t *)p->a, (const bf16_t *)p->flip, (const bf16_t *)p->slice, (bf16_t *)p->out, p->seqlen, p->nslices);
+    else if (p->nslices == 4 && ((uintptr_t)p->slice & 15) == 0 && p->seqlen % 4 == 0)
+        tri_combine_kernel<4><<<grid, 256, 0, st>>>(a, fl, sl, out, p->seqlen, 4);
     else if (p->nslices > 4 && p->nslices <= 64)
-        tri_combine_tiled_kernel<<<dim3((Ls + 63) / 64, p->rows), 256, 0, st>>>(p->a, p->flip, p->slice, p->out,
-                                                                                 p->seqlen, p->nslices);
+        tri_combine_tiled_kernel<float><<<dim3((Ls + 63) / 64, p->rows), 256, 0, st>>>(a, fl, sl, out, p->seqlen, p->nslices);
     else
-        tri_combine_kernel<0><<<grid, 256, 0, st>>>(p->a, p->flip, p->slice, p->out, p->seqlen, p->nslices);
+        tri_combine_kernel<0><<<grid, 256, 0, st>>>(a, fl, sl, out, p->seqlen, p->nslices);
     MMU_HIP_LAUNCH_CHECK("tri_combine");
     return 0;
 }

@@ -19,6 +19,7 @@ Not provided (never reached from MM-UNet): ``step`` / inference cache, the ``Blo
 The compute goes through the HIP kernels only (no CPU path).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -82,6 +83,9 @@ def neg_exp(param):
     """``-exp(param.float())`` (mamba_simple.py:209,230,251,304), from the per-forward cache when there is one."""
     a = _A_CACHE.get(id(param))
     return a if a is not None else -torch.exp(param.float())
+
+
+BCL_LOWP = os.environ.get("MMUNET_BCL_LOWP", "1") != "0"   # 0: under autocast the tri-directional block takes the (B, L, C) route
 
 
 class Mamba(nn.Module):
@@ -184,7 +188,7 @@ class Mamba(nn.Module):
         if seqlen % self.nslices != 0:
             raise RuntimeError(f"Mamba v3: seqlen {seqlen} must be divisible by nslices {self.nslices}")
         ns = self.nslices
-        fused = tri_order.supported(xz)
+        fused = tri_order.supported(xz, nslices=ns)
         if fused:   # flip + slice-interleave in one pass; the three input gradients meet in one kernel
             xz_a, xz_f, xz_s = tri_order.tri_split(xz, ns)
         else:
@@ -198,7 +202,7 @@ class Mamba(nn.Module):
         unslice = lambda t: t.reshape(batch, self.d_inner, seqlen // ns, ns).permute(0, 1, 3, 2).flatten(-2)  # noqa: E731
         if self.return_branch_outputs:             # (out, o_1, o_2, o_3) of mamba_simple.py:267-270,362
             o_1, o_2, o_3 = out, out_b, unslice(out_sp)
-        if fused and tri_order.supported(out, out_b, out_sp):
+        if fused and tri_order.supported(out, out_b, out_sp, nslices=ns):
             total = tri_order.tri_combine(out, out_b, out_sp, ns)
         else:
             total = out + out_b.flip([-1]) + (o_3 if o_3 is not None else unslice(out_sp))
@@ -208,8 +212,14 @@ class Mamba(nn.Module):
         """Channels-first variant for callers that hold feature maps: x (B, d_model, L) contiguous ->
         (out (B, d_model, L) contiguous, o_1, o_2, o_3).  Same computation as ``forward(x.transpose(1, 2))``
         followed by ``.transpose(1, 2)``, without the transposing copies (see tall_gemm.proj_bcl)."""
+        lowp = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and
+                                             torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        # bf16 activations (autocast): the same channels-first route with bf16 tensors between the kernels, when the slice
+        # count is one the re-ordering kernels take in bf16 (MM-UNet: 16 / 32 / 64)
         ok = (self.use_fast_path and self.bimamba_type == "v3" and self.in_proj.bias is None and x.is_cuda
-              and self.out_proj.bias is None and x.dtype == torch.float32 and not torch.is_autocast_enabled())
+              and self.out_proj.bias is None and x.dtype in (torch.float32, torch.bfloat16)
+              and (not lowp or (BCL_LOWP and 4 < self.nslices <= 64))
+              and (lowp or not torch.is_autocast_enabled()))
         if not ok:
             res = self.forward(x.transpose(1, 2))
             return (res[0].transpose(1, 2),) + tuple(res[1:])

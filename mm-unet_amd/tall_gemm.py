@@ -204,7 +204,51 @@ class _ProjBclFn(torch.autograd.Function):
         return dW, dX, None
 
 
+class _ProjBclLowpFn(torch.autograd.Function):
+    """``_ProjBclFn`` for bfloat16 activations (autocast): the same two layouts and no transposing copies -- each batch
+    item is one library GEMM whose strided operand / result is addressed in place -- with bf16 operands and float32
+    accumulation; the weight gradient is the split-K product over all tokens, summed in float32."""
+
+    @staticmethod
+    def forward(ctx, W, X, to_cb):
+        with torch.autocast("cuda", enabled=False):
+            B, I, L = X.shape
+            O = W.shape[0]
+            Wc, Xc = W.to(torch.bfloat16), X.to(torch.bfloat16)
+            if to_cb:
+                out = torch.empty((O, B, L), device=X.device, dtype=torch.bfloat16).permute(1, 0, 2)   # [O][B][L]
+            else:
+                out = torch.empty((B, O, L), device=X.device, dtype=torch.bfloat16)
+            for b in range(B):
+                torch.mm(Wc, Xc[b], out=out[b])
+        ctx.save_for_backward(Wc, Xc)
+        ctx.to_cb, ctx.w_dtype, ctx.x_dtype = to_cb, W.dtype, X.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        Wc, Xc = ctx.saved_tensors
+        with torch.autocast("cuda", enabled=False):
+            G = G.to(torch.bfloat16)
+            B, I, L = Xc.shape
+            dW = dX = None
+            if ctx.needs_input_grad[1]:
+                if ctx.to_cb:
+                    dX = torch.empty((B, I, L), device=G.device, dtype=torch.bfloat16)
+                else:
+                    dX = torch.empty((I, B, L), device=G.device, dtype=torch.bfloat16).permute(1, 0, 2)
+                Wt = Wc.t()
+                for b in range(B):
+                    torch.mm(Wt, G[b], out=dX[b])
+                dX = dX.to(ctx.x_dtype)
+            if ctx.needs_input_grad[0]:
+                dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(Xc)).to(ctx.w_dtype)
+        return dW, dX, None
+
+
 def proj_bcl(W, X, to_cb):
+    if X.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return _ProjBclLowpFn.apply(W, X, to_cb)
     return _ProjBclFn.apply(W, X, to_cb)
 
 

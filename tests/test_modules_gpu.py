@@ -1095,3 +1095,39 @@ def test_validation_path_on_the_gpu_vs_oracle_windows():
     # a logit within 1e-3 of the threshold may flip a pixel: metrics agree to a few pixels of 20,480
     for k, v in want.items():
         assert abs(metrics[k] - v) < 5e-3, (k, metrics[k], v)
+
+
+def test_tri_block_channels_first_bf16_route_vs_bld_route():
+    """Under bf16 autocast ``Mamba.forward_bcl`` keeps the channels-first route (bf16 tensors between the kernels:
+    in_proj / out_proj addressed in place, tri_order's re-orderings in bf16) -- against the (B, L, C) route of the same
+    block (``BCL_LOWP = False``) on the same input: outputs and all parameter gradients within bf16 tolerance."""
+    import mm_unet_amd.mamba_simple as ms
+    torch.manual_seed(3)
+    m = ms.Mamba(d_model=64, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=16).to(DEV)
+    m.return_branch_outputs = False
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(2, 64, 1024, device=DEV, generator=gen)
+    g = torch.randn(2, 64, 1024, device=DEV, generator=gen)
+
+    def run(lowp):
+        ms.BCL_LOWP = lowp
+        try:
+            m.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m.forward_bcl(xi.bfloat16())[0]
+            out.float().backward(g)
+            return out.float(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ms.BCL_LOWP = True
+
+    o1, gx1, gp1 = run(True)
+    o0, gx0, gp0 = run(False)
+    assert o1.shape == o0.shape
+    scale = float(o0.abs().max())
+    assert float((o1 - o0).abs().max()) <= 3e-2 * scale
+    assert float((gx1 - gx0).norm() / gx0.norm()) <= 3e-2
+    assert gp1.keys() == gp0.keys()
+    for k in gp0:
+        rel = float((gp1[k].float() - gp0[k].float()).norm() / (gp0[k].float().norm() + 1e-12))
+        assert rel <= 6e-2, (k, rel)
