@@ -16,6 +16,8 @@ Differences a caller can observe:
     MM-UNet uses; complex ``A`` / constant ``B``,``C`` raise ``RuntimeError``;
   * float32 and bfloat16 I/O (no float16); dstate <= 128.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -191,7 +193,7 @@ def _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_
 # LDS float atomics (137 of 212 GPU-ms per training step of config 5, profiles/r02_config5_before.txt).
 # Worth it only when the scan is large; small scans (MMConv's 6-channel blocks) keep the single generic launch.
 GROUP_SPLIT = True
-GROUP_SPLIT_MIN_ELEMENTS = 1 << 22   # batch * dim * seqlen
+GROUP_SPLIT_MIN_ELEMENTS = int(os.environ.get("MMUNET_GROUP_SPLIT_MIN", str(1 << 19)))   # batch * dim * seqlen (1 << 22 until the small-block kernels of round 2: 93.9 vs 86.1 ms on config 5)
 
 
 def group_split(dstate, u):
@@ -223,9 +225,14 @@ def _sum_parts(parts, dtype, out=None):
     parts = [t for t in parts if t is not None]
     if not parts:
         return None
-    ok = (all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in parts)
+    # element-wise over the storage: the parts (and out) only have to be dense with the SAME strides -- the fused Mamba path
+    # hands over [D][B][L]-ordered tensors, which are not "contiguous" as (B, D, L)
+    order = sorted(range(parts[0].dim()), key=lambda i: -parts[0].stride(i))
+    same = lambda t: t.shape == parts[0].shape and t.stride() == parts[0].stride()   # noqa: E731
+    ok = (parts[0].permute(order).is_contiguous() and all(t.dtype == torch.float32 and same(t) and t.data_ptr() % 16 == 0
+                                                          for t in parts)
           and dtype in (torch.float32, torch.bfloat16) and len(parts) <= 4
-          and (out is None or (out.is_contiguous() and out.dtype == dtype and out.data_ptr() % 16 == 0)))
+          and (out is None or (same(out) and out.dtype == dtype and out.data_ptr() % 16 == 0)))
     if not ok:
         total = parts[0]
         for t in parts[1:]:
@@ -235,7 +242,7 @@ def _sum_parts(parts, dtype, out=None):
         return total.to(dtype)
     if len(parts) == 1 and dtype == torch.float32 and out is None:
         return parts[0]
-    res = out if out is not None else torch.empty(parts[0].shape, device=parts[0].device, dtype=dtype)
+    res = out if out is not None else torch.empty_like(parts[0], dtype=dtype)    # (keeps the parts' strides)
     p = _lib.SumPartsParams()
     p.n, p.nparts, p.out_dtype = parts[0].numel(), len(parts), _lib.dtype_code(res)
     for k, t in enumerate(parts):
@@ -303,7 +310,7 @@ def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_sof
     result = [_sum_parts(dus, io_dtype), _sum_parts(ddeltas, io_dtype), dA, dB if dB.dtype == bc_dtype else dB.to(bc_dtype),
               dC if dC.dtype == bc_dtype else dC.to(bc_dtype), dD, dbias]
     if z_ is not None:
-        if dz_ is not None and dz_.is_contiguous():
+        if dz_ is not None and dz_.shape == dzs[0].shape and dz_.stride() == dzs[0].stride():
             dz = _sum_parts(dzs, dz_.dtype, out=dz_)
         elif dz_ is not None:
             dz = dz_.copy_(_sum_parts(dzs, torch.float32))

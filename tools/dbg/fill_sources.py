@@ -18,10 +18,12 @@ dev = "cuda:0"
 torch.manual_seed(0)
 BF16 = os.environ.get("BF16") == "1"        # BASELINE config 3: bf16 autocast, batch 16
 BATCH = int(os.environ.get("BATCH", "16" if BF16 else "8"))
-m = MM_Net(num_classes=1).to(dev).train()
+SIZE = int(os.environ.get("SIZE", "512"))
+DSTATE = int(os.environ.get("DSTATE", "16"))
+m = MM_Net(num_classes=1, d_state=DSTATE).to(dev).train()
 step = TrainStep(m, DICE_BCE_Loss(), make_optimizer(m), use_graph=False, amp_dtype=torch.bfloat16 if BF16 else None)
-x = torch.randn(BATCH, 3, 512, 512, device=dev)
-t = (torch.rand(BATCH, 1, 512, 512, device=dev) > 0.88).float()
+x = torch.randn(BATCH, 3, SIZE, SIZE, device=dev)
+t = (torch.rand(BATCH, 1, SIZE, SIZE, device=dev) > 0.88).float()
 for _ in range(2):
     step(x, t)
 torch.cuda.synchronize()
