@@ -191,7 +191,8 @@ def _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_
 # straight into their rows) and the per-token results -- all linear in the group's y, the gate included -- are added
 # up in float32, instead of the generic-dstate kernels, whose backward adds dB / dC with
 # LDS float atomics (137 of 212 GPU-ms per training step of config 5, profiles/r02_config5_before.txt).
-# Worth it only when the scan is large; small scans (MMConv's 6-channel blocks) keep the single generic launch.
+# Worth it from 512 K elements (batch * dim * seqlen) on: since round 2's small-block kernels four dstate-16 launches also
+# beat the generic kernel on MMConv's 6-channel blocks at 256 x 256 and up; tiny scans keep the single generic launch.
 GROUP_SPLIT = True
 GROUP_SPLIT_MIN_ELEMENTS = int(os.environ.get("MMUNET_GROUP_SPLIT_MIN", str(1 << 19)))   # batch * dim * seqlen (1 << 22 until the small-block kernels of round 2: 93.9 vs 86.1 ms on config 5)
 
