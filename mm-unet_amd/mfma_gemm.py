@@ -8,7 +8,7 @@ import torch
 from . import _lib
 
 ENABLED = True   # False: callers use their ATen GEMMs (tests compare the two)
-MIN_TILES = 192   # measured break-even against hipBLASLt on the DSC shapes (csrc/gemm_tokens_mfma.hip header)
+MIN_TILES = int(os.environ.get("MMUNET_GEMM_TOKENS_MIN_TILES", "192"))   # measured break-even against hipBLASLt on the DSC shapes (csrc/gemm_tokens_mfma.hip header)
 
 
 def supported(rows, inner, tokens, *tensors):

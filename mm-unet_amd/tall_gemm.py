@@ -7,18 +7,21 @@ per call (measured on MI355X; 44 MMConv blocks x 3 such products per step).  flo
 token-contraction matrix-core kernel (csrc/gemm_nt_splitk.hip: both layouts read in place, ordered slab sums);
 other dtypes split T into slabs as one strided batched GEMM + a small sum.
 """
+import os
+
 import torch
 
 from . import mfma_gemm
 
 _SLAB = 2048
+_NT_MIN = int(os.environ.get("MMUNET_GEMM_NT_MIN_TOKENS", str(4 * _SLAB)))   # fewer tokens: one library GEMM
 
 
 def nt_splitk(X, Y):
     """X (I, T), Y (J, T), both with unit stride along T  ->  X @ Y^T  (I, J), fp32-accumulated."""
     I, T = X.shape
     J = Y.shape[0]
-    if T < 4 * _SLAB:
+    if T < _NT_MIN:
         return X @ Y.t()
     if X.dtype == Y.dtype and mfma_gemm.nt_supported(X, Y, T) and X.stride(0) % 4 == 0 and Y.stride(0) % 4 == 0:
         return mfma_gemm.gemm_nt(X, Y, I, J, 1, T, X.stride(0), 0, Y.stride(0), 0)   # one kernel + its slab sum
@@ -100,7 +103,7 @@ class _DscGemmFn(torch.autograd.Function):
         inplace = G.is_contiguous() and samples.is_contiguous() and T % 4 == 0 and W2.stride(1) == 1
         G2 = None
         if ctx.needs_input_grad[0]:
-            if inplace and T % 32 == 0 and B * T >= 4 * _SLAB and mfma_gemm.nt_supported(G, samples, T):
+            if inplace and T % 32 == 0 and B * T >= _NT_MIN and mfma_gemm.nt_supported(G, samples, T):
                 dW = mfma_gemm.gemm_nt(G, samples, O, I, B, T, T, O * T, B * T, T).to(W2.dtype)
             else:
                 G2 = G.permute(1, 0, 2).reshape(O, -1)                         # (O, B*T): one small copy
@@ -194,7 +197,7 @@ class _ProjBclFn(torch.autograd.Function):
             # one split-K product over all (batch, token) pairs: both operands as (channels, B*L) matrices.  One of the
             # two is batch-major by construction (the layouts meet here); it is brought to channel-major with one
             # transposing copy -- 2-3 launches instead of three per batch item (24 -> 4 for B = 8)
-            if (G.stride(2) == 1 and X.stride(2) == 1 and mfma_gemm.nt_supported(G, X, L) and B * L >= 4 * _SLAB
+            if (G.stride(2) == 1 and X.stride(2) == 1 and mfma_gemm.nt_supported(G, X, L) and B * L >= _NT_MIN
                     and all(t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 for t in (G, X))):
                 # both layouts addressed in place: no transposing copy of the batch-major operand
                 dW = mfma_gemm.gemm_nt(G, X, W.shape[0], I, B, L, G.stride(1), G.stride(0), X.stride(1),
@@ -292,7 +295,7 @@ class _Conv1x1Stride2Fn(torch.autograd.Function):
             dx = torch.zeros((B, I, H, W), device=G.device, dtype=torch.float32)
             dx[:, :, ::2, ::2] = dxs.view(B, I, (H + 1) // 2, (W + 1) // 2)
         if ctx.needs_input_grad[1]:
-            if T % 32 == 0 and B * T >= 4 * _SLAB and mfma_gemm.nt_supported(G3, xs3, T):
+            if T % 32 == 0 and B * T >= _NT_MIN and mfma_gemm.nt_supported(G3, xs3, T):
                 dW = mfma_gemm.gemm_nt(G3, xs3, O, I, B, T, T, O * T, T, I * T)
             else:
                 dW = torch.einsum("bot,bit->oi", G3, xs3)
