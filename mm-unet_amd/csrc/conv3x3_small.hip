@@ -416,8 +416,9 @@ bool wgrad_rows_plan(int B, int Cin, int H, int W, int &lwq, int &rs, int &nrb) 
 // how many input-channel slices so that the chip sees >= ~8192 waves (8 per SIMD: the channel loop is a
 // load -> FMA chain per iteration, latency hiding comes from other waves)
 int channel_splits(long threads, int cin) {
+    static const long target = []() { const char *e = getenv("MMU_CONV3X3S_SPLIT_THREADS"); return e ? atol(e) : 524288L; }();
     int s = 1;
-    while (threads * s < 524288 && cin / (s * 2) >= 4) s *= 2;
+    while (threads * s < target && cin / (s * 2) >= 4) s *= 2;
     return s;
 }
 
