@@ -375,6 +375,19 @@ typedef struct {
 size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);
 int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream);
 
+/* ---- backward of nn.MaxPool2d(3, stride=2, padding=1) as a gather (MM_Net's stem pooling) ----------------------- */
+/* dinput[b, c, y, x] = sum of dout over the (at most four) windows whose recorded arg-max (indices: int64, flat y*W + x
+ * per plane, as F.max_pool2d(..., return_indices=True) returns them) is (y, x).  float32, contiguous NCHW. */
+typedef struct {
+    int64_t planes;                       /* batch * channels */
+    int32_t height, width, out_height, out_width;
+    const float *dout;                    /* [planes, out_height, out_width] */
+    const void *indices;                  /* int64, same shape as dout */
+    float *dinput;                        /* [planes, height, width] */
+} mmu_maxpool_params;
+
+int mmu_maxpool3s2_bwd(const mmu_maxpool_params *p, void *stream);
+
 /* ---- out = sum of up to four float32 tensors, as float32 or bfloat16 (the state-group sums of a d_state > 16 scan) -- */
 /* selective_scan_hip._fwd_groups / _bwd_groups: the per-token outputs of a d_state-64 scan are the sums of its four
  * dstate-16 launches' float32 partial outputs (selective_scan_fwd_kernel.cuh:147-298 computes them in one pass over 64

@@ -118,6 +118,11 @@ class GemmNtParams(ctypes.Structure):
                 ("c", _vp), ("workspace", _vp)]
 
 
+class MaxPoolParams(ctypes.Structure):
+    _fields_ = [("planes", _i64)] + [(n, _i32) for n in ("height", "width", "out_height", "out_width")] + \
+               [(n, _vp) for n in ("dout", "indices", "dinput")]
+
+
 class SumPartsParams(ctypes.Structure):
     _fields_ = [("n", _i64), ("nparts", _i32), ("out_dtype", _i32), ("parts", _vp * 4), ("out", _vp)]
 
@@ -159,7 +164,7 @@ EXPORTS = (
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
-    "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
+    "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_debug_wave_scan",
 )
 
@@ -198,7 +203,7 @@ def lib():
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
                      ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams),
                      ("mmu_gemm_nt_splitk", GemmNtParams),
-                     ("mmu_sum_parts", SumPartsParams), ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams)):
+                     ("mmu_maxpool3s2_bwd", MaxPoolParams), ("mmu_sum_parts", SumPartsParams), ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]

@@ -23,7 +23,7 @@ from .mamba_simple import Mamba, neg_exp, precomputed_A
 from . import conv3x3_mfma, conv3x3_small, morph_coords, norm_fused
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
-from . import pointwise
+from . import maxpool as maxpool_op, pointwise
 from .tall_gemm import conv1x1_stride2, conv1x1_stride2_supported, dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
@@ -420,7 +420,7 @@ class MM_Net(nn.Module):
         size = x.size()[2:]
         up = lambda t: bilinear_resize(t, size=size)  # noqa: E731
         e1 = run_fused(self.encoder1, x)
-        e2 = self.encoder2(self.maxpool(e1))
+        e2 = self.encoder2(maxpool_op.pool_module(self.maxpool, e1))
         e3 = self.encoder3(e2)
         e4 = self.encoder4(e3)
         e5 = self.encoder5(e4)

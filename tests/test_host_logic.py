@@ -56,7 +56,8 @@ def test_param_structs_match_header_field_order():
                         ("mmu_conv3x3_mfma_params", _lib.Conv3x3MfmaParams),
                         ("mmu_gemm_tokens_params", _lib.GemmTokensParams),
                         ("mmu_gemm_nt_params", _lib.GemmNtParams),
-                        ("mmu_conv1x1_one_params", _lib.Conv1x1OneParams)):
+                        ("mmu_conv1x1_one_params", _lib.Conv1x1OneParams),
+                        ("mmu_maxpool_params", _lib.MaxPoolParams)):
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 
 

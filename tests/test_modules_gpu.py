@@ -1131,3 +1131,28 @@ def test_tri_block_channels_first_bf16_route_vs_bld_route():
     for k in gp0:
         rel = float((gp1[k].float() - gp0[k].float()).norm() / (gp0[k].float().norm() + 1e-12))
         assert rel <= 6e-2, (k, rel)
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 256, 256), (2, 3, 17, 23), (1, 5, 8, 6), (3, 2, 33, 64)])
+def test_max_pool3s2_vs_module(shape):
+    """maxpool.max_pool3s2 == nn.MaxPool2d(3, 2, 1) (MMUNet.py:493,537): same output, the gather backward against
+    ATen's scatter backward (ties included: values on a coarse grid), bit-reproducible."""
+    from mm_unet_amd import maxpool
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    x = (torch.randn(*shape, device=DEV, generator=gen) * 4).round() / 4          # many equal values: ties
+    m = torch.nn.MaxPool2d(3, 2, 1)
+    xr = x.clone().requires_grad_()
+    ref = m(xr)
+    g = torch.randn(ref.shape, device=DEV, generator=gen)
+    ref.backward(g)
+    grads = []
+    for _ in range(2):
+        xo = x.clone().requires_grad_()
+        assert maxpool.module_supported(m, xo)
+        out = maxpool.pool_module(m, xo)
+        out.backward(g)
+        grads.append(xo.grad)
+    assert torch.equal(out, ref)
+    close(grads[0], xr.grad, 1e-6, 1e-6, "d input")
+    assert torch.equal(grads[0], grads[1])
+    assert not maxpool.module_supported(torch.nn.MaxPool2d(2, 2), x)
