@@ -375,6 +375,25 @@ typedef struct {
 size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);
 int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream);
 
+/* ---- nn.Conv2d(2, 1, kernel_size=7, padding=3, bias=False): CBAM's spatial-attention convolution -------------------- */
+/* src/UM_Net/MMUNet.py:323: float32, contiguous; input [batch, 2, H, W], weight [1, 2, 7, 7], out / dout [batch, 1, H, W].
+ * bwd: dinput (optional) and dweight (optional; needs input and workspace: per-workgroup partial rows, ordered sum).
+ * workspace: mmu_conv7x7_2to1_workspace_floats() floats. */
+typedef struct {
+    int32_t batch, height, width;
+    const float *input;
+    const float *weight;
+    float *out;             /* fwd */
+    const float *dout;      /* bwd */
+    float *dinput;          /* bwd, optional */
+    float *dweight;         /* bwd, optional */
+    float *workspace;       /* bwd with dweight */
+} mmu_conv7x7_params;
+
+size_t mmu_conv7x7_2to1_workspace_floats(int batch, int height, int width);
+int mmu_conv7x7_2to1_fwd(const mmu_conv7x7_params *p, void *stream);
+int mmu_conv7x7_2to1_bwd(const mmu_conv7x7_params *p, void *stream);
+
 /* ---- backward of nn.MaxPool2d(3, stride=2, padding=1) as a gather (MM_Net's stem pooling) ----------------------- */
 /* dinput[b, c, y, x] = sum of dout over the (at most four) windows whose recorded arg-max (indices: int64, flat y*W + x
  * per plane, as F.max_pool2d(..., return_indices=True) returns them) is (y, x).  float32, contiguous NCHW. */

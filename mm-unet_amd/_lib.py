@@ -118,6 +118,11 @@ class GemmNtParams(ctypes.Structure):
                 ("c", _vp), ("workspace", _vp)]
 
 
+class Conv7x7Params(ctypes.Structure):
+    _fields_ = [(n, _i32) for n in ("batch", "height", "width")] + \
+               [(n, _vp) for n in ("input", "weight", "out", "dout", "dinput", "dweight", "workspace")]
+
+
 class MaxPoolParams(ctypes.Structure):
     _fields_ = [("planes", _i64)] + [(n, _i32) for n in ("height", "width", "out_height", "out_width")] + \
                [(n, _vp) for n in ("dout", "indices", "dinput")]
@@ -164,7 +169,7 @@ EXPORTS = (
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
-    "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
+    "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_debug_wave_scan",
 )
 
@@ -203,6 +208,7 @@ def lib():
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
                      ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams),
                      ("mmu_gemm_nt_splitk", GemmNtParams),
+                     ("mmu_conv7x7_2to1_fwd", Conv7x7Params), ("mmu_conv7x7_2to1_bwd", Conv7x7Params),
                      ("mmu_maxpool3s2_bwd", MaxPoolParams), ("mmu_sum_parts", SumPartsParams), ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
@@ -215,6 +221,8 @@ def lib():
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_gemm_tokens_workspace_bytes.restype = ctypes.c_size_t
     L.mmu_gemm_tokens_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mmu_conv7x7_2to1_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_conv7x7_2to1_workspace_floats.argtypes = [ctypes.c_int] * 3
     L.mmu_conv1x1_one_workspace_floats.restype = ctypes.c_size_t
     L.mmu_conv1x1_one_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
     L.mmu_gemm_nt_splitk_workspace_floats.restype = ctypes.c_size_t

@@ -288,7 +288,7 @@ class CBAM(nn.Module):
         y1 = c_out * x
         s_avg = torch.mean(y1, dim=1, keepdim=True)
         s_max, _ = torch.max(y1, dim=1, keepdim=True)
-        s_out = self.sigmoid(self.conv(torch.cat((s_max, s_avg), 1)))
+        s_out = self.sigmoid(pointwise.conv7_module(self.conv, torch.cat((s_max, s_avg), 1)))
         return s_out * y1
 
 

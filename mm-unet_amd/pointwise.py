@@ -72,3 +72,53 @@ def conv1x1_one(x, weight, bias=None):
 def conv_module(m, x):
     """``m(x)`` for an ``nn.Conv2d``: the HIP kernels when :func:`module_supported`, the module itself otherwise."""
     return conv1x1_one(x, m.weight, m.bias) if module_supported(m, x) else m(x)
+
+
+# ---- nn.Conv2d(2, 1, 7, padding=3, bias=False): CBAM's spatial-attention convolution (MMUNet.py:323,335) --------------
+def conv7_supported(m, x):
+    return (ENABLED and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (7, 7) and m.stride == (1, 1)
+            and m.padding == (3, 3) and m.dilation == (1, 1) and m.groups == 1 and m.bias is None
+            and m.in_channels == 2 and m.out_channels == 1 and m.padding_mode == "zeros" and x.is_cuda and x.dim() == 4
+            and x.dtype == torch.float32 and m.weight.dtype == torch.float32 and not torch.is_autocast_enabled())
+
+
+class Conv7x7SmallFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        _lib.require_gpu(x, weight)
+        if x.dim() != 4 or x.shape[1] != 2 or tuple(weight.shape) != (1, 2, 7, 7) or x.dtype != torch.float32 \
+                or weight.dtype != torch.float32:
+            raise RuntimeError("conv7x7_2to1: float32 (B, 2, H, W) input and a float32 (1, 2, 7, 7) weight required")
+        x, weight = x.contiguous(), weight.contiguous()
+        B, _, H, W = x.shape
+        out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+        p = _lib.Conv7x7Params()
+        p.batch, p.height, p.width = B, H, W
+        p.input, p.weight, p.out = x.data_ptr(), weight.data_ptr(), out.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_conv7x7_2to1_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        B, _, H, W = x.shape
+        g = g.float().contiguous()
+        need_x, need_w = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        L = _lib.lib()
+        ws = torch.empty(L.mmu_conv7x7_2to1_workspace_floats(B, H, W), device=x.device, dtype=torch.float32) if need_w else None
+        p = _lib.Conv7x7Params()
+        p.batch, p.height, p.width = B, H, W
+        p.input, p.weight, p.dout = x.data_ptr(), weight.data_ptr(), g.data_ptr()
+        p.dinput, p.dweight, p.workspace = _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(ws)
+        with torch.cuda.device(x.device):
+            _lib.check(L.mmu_conv7x7_2to1_bwd(p, _lib.stream_of(x)))
+        return dx, dw
+
+
+def conv7_module(m, x):
+    """``m(x)`` for CBAM's 7 x 7 convolution: the HIP kernels when :func:`conv7_supported`, the module otherwise."""
+    return Conv7x7SmallFn.apply(x, m.weight) if conv7_supported(m, x) else m(x)

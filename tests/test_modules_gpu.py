@@ -1156,3 +1156,33 @@ def test_max_pool3s2_vs_module(shape):
     close(grads[0], xr.grad, 1e-6, 1e-6, "d input")
     assert torch.equal(grads[0], grads[1])
     assert not maxpool.module_supported(torch.nn.MaxPool2d(2, 2), x)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 256), (2, 13, 9), (1, 5, 40), (3, 64, 64)])
+def test_conv7x7_2to1_vs_conv2d(shape):
+    """csrc/conv7x7_small.hip == nn.Conv2d(2, 1, 7, padding=3, bias=False) (CBAM's spatial attention, MMUNet.py:323,335):
+    forward, input and weight gradients against ATen on the same GPU (maps smaller than the kernel included);
+    bit-reproducible."""
+    import torch.nn.functional as F
+    from mm_unet_amd import pointwise
+    B, H, W = shape
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(B, 2, H, W, device=DEV, generator=gen)
+    m = torch.nn.Conv2d(2, 1, 7, padding=3, bias=False).to(DEV)
+    g = torch.randn(B, 1, H, W, device=DEV, generator=gen)
+    xr = x.clone().requires_grad_()
+    ref = F.conv2d(xr, m.weight, padding=3)
+    gw_ref, = torch.autograd.grad(ref, m.weight, g, retain_graph=True)
+    gx_ref, = torch.autograd.grad(ref, xr, g)
+    assert pointwise.conv7_supported(m, x)
+    res = []
+    for _ in range(2):
+        xo = x.clone().requires_grad_()
+        out = pointwise.conv7_module(m, xo)
+        gx, gw = torch.autograd.grad(out, (xo, m.weight), g)
+        res.append((out.detach(), gx, gw))
+    out, gx, gw = res[0]
+    close(out, ref, 1e-5, 1e-5, "forward")
+    close(gx, gx_ref, 1e-5, 1e-5, "d input")
+    close(gw, gw_ref, 1e-4, 1e-5 * (B * H * W) ** 0.5, "d weight")
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
