@@ -375,6 +375,27 @@ typedef struct {
 size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);
 int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream);
 
+/* ---- out = input * gate, gate constant over a channel's pixels or over a pixel's channels; backward in one pass ------- */
+/* CBAM's `c_out * x` and `s_out * y1` (src/UM_Net/MMUNet.py:330,336), RCG's gate product (MMUNet.py:415).  float32,
+ * contiguous [batch, channels, hw], hw % 4 == 0.  gate / dgate: [batch, channels] (MMU_GATE_CHANNEL) or [batch, hw]
+ * (MMU_GATE_SPATIAL).  bwd: dinput = dout * gate (optional), dgate = sum of dout * input over the broadcast axis
+ * (optional); no atomics. */
+#define MMU_GATE_CHANNEL 0
+#define MMU_GATE_SPATIAL 1
+typedef struct {
+    int32_t batch, channels, mode;
+    int64_t hw;
+    const float *input;
+    const float *gate;
+    float *out;            /* fwd */
+    const float *dout;     /* bwd */
+    float *dinput;         /* bwd, optional */
+    float *dgate;          /* bwd, optional */
+} mmu_gated_mul_params;
+
+int mmu_gated_mul_fwd(const mmu_gated_mul_params *p, void *stream);
+int mmu_gated_mul_bwd(const mmu_gated_mul_params *p, void *stream);
+
 /* ---- nn.Conv2d(2, 1, kernel_size=7, padding=3, bias=False): CBAM's spatial-attention convolution -------------------- */
 /* src/UM_Net/MMUNet.py:323: float32, contiguous; input [batch, 2, H, W], weight [1, 2, 7, 7], out / dout [batch, 1, H, W].
  * bwd: dinput (optional) and dweight (optional; needs input and workspace: per-workgroup partial rows, ordered sum).

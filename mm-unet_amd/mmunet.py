@@ -285,11 +285,11 @@ class CBAM(nn.Module):
         # op the gradient goes to one arg-max element.
         x_max = x.flatten(2).max(dim=2)[0].unsqueeze(-1).unsqueeze(-1)
         c_out = self.sigmoid(self.mlp(self.avg_pool(x)) + self.mlp(x_max))
-        y1 = c_out * x
+        y1 = pointwise.gated_mul(x, c_out)
         s_avg = torch.mean(y1, dim=1, keepdim=True)
         s_max, _ = torch.max(y1, dim=1, keepdim=True)
         s_out = self.sigmoid(pointwise.conv7_module(self.conv, torch.cat((s_max, s_avg), 1)))
-        return s_out * y1
+        return pointwise.gated_mul(y1, s_out)
 
 
 class SideoutBlock(nn.Module):
@@ -329,7 +329,7 @@ class RCG(nn.Module):
         out, _, _, _ = self.mamba.forward_bcl(x0.reshape(B, C, H * W))
         x0 = self.downsample(out.reshape(B, C, H, W))
         gate = torch.sigmoid(pointwise.conv_module(self.mlp[0], x2))       # mlp = Conv2d(64, 1, 1) -> Sigmoid
-        return x0 * gate * x2 + f
+        return pointwise.gated_mul(x0 * x2, gate) + f
 
 
 class DecoderBlock(nn.Module):

@@ -2,6 +2,8 @@
 (csrc/pointwise_one.hip): RCG's gate ``mlp`` (src/UM_Net/MMUNet.py:386-387,414) and the side outputs' ``conv2``
 (MMUNet.py:346,350).  float32 contiguous NCHW, C in {16, 64}, H*W % 4 == 0; anything else is the caller's ``F.conv2d``.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -122,3 +124,61 @@ class Conv7x7SmallFn(torch.autograd.Function):
 def conv7_module(m, x):
     """``m(x)`` for CBAM's 7 x 7 convolution: the HIP kernels when :func:`conv7_supported`, the module otherwise."""
     return Conv7x7SmallFn.apply(x, m.weight) if conv7_supported(m, x) else m(x)
+
+
+# ---- x * gate with a per-channel ([B, C, 1, 1]) or per-pixel ([B, 1, H, W]) gate (MMUNet.py:330,336,415) --------------
+GATED_MUL = os.environ.get("MMUNET_GATED_MUL", "1") != "0"
+
+
+def _gate_mode(x, gate):
+    if not (ENABLED and GATED_MUL and x.is_cuda and x.dim() == 4 and gate.dim() == 4 and x.dtype == torch.float32
+            and gate.dtype == torch.float32 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] < 65536
+            and not torch.is_autocast_enabled()):
+        return None
+    B, C, H, W = x.shape
+    if tuple(gate.shape) == (B, C, 1, 1):
+        return 0
+    if tuple(gate.shape) == (B, 1, H, W) and C > 1:
+        return 1
+    return None
+
+
+class GatedMulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gate, mode):
+        _lib.require_gpu(x, gate)
+        x, gate = x.contiguous(), gate.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        p = _lib.GatedMulParams()
+        p.batch, p.channels, p.mode, p.hw = B, C, mode, H * W
+        p.input, p.gate, p.out = x.data_ptr(), gate.data_ptr(), out.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_gated_mul_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, gate)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gate = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.float().contiguous()
+        need_x, need_g = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_x or need_g):
+            return None, None, None
+        dx = torch.empty_like(x) if need_x else None
+        dgate = torch.empty_like(gate) if need_g else None
+        p = _lib.GatedMulParams()
+        p.batch, p.channels, p.mode, p.hw = B, C, ctx.mode, H * W
+        p.input, p.gate, p.dout = x.data_ptr(), gate.data_ptr(), g.data_ptr()
+        p.dinput, p.dgate = _lib.ptr(dx), _lib.ptr(dgate)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_gated_mul_bwd(p, _lib.stream_of(x)))
+        return dx, dgate, None
+
+
+def gated_mul(x, gate):
+    """``x * gate`` (broadcast); the one-pass HIP form for channel / spatial gates of a float32 NCHW tensor, else ATen."""
+    mode = _gate_mode(x, gate)
+    return GatedMulFn.apply(x, gate, mode) if mode is not None else x * gate

@@ -58,7 +58,8 @@ def test_param_structs_match_header_field_order():
                         ("mmu_gemm_nt_params", _lib.GemmNtParams),
                         ("mmu_conv1x1_one_params", _lib.Conv1x1OneParams),
                         ("mmu_maxpool_params", _lib.MaxPoolParams),
-                        ("mmu_conv7x7_params", _lib.Conv7x7Params)):
+                        ("mmu_conv7x7_params", _lib.Conv7x7Params),
+                        ("mmu_gated_mul_params", _lib.GatedMulParams)):
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 
 

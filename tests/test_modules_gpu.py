@@ -1186,3 +1186,33 @@ def test_conv7x7_2to1_vs_conv2d(shape):
     close(gx, gx_ref, 1e-5, 1e-5, "d input")
     close(gw, gw_ref, 1e-4, 1e-5 * (B * H * W) ** 0.5, "d weight")
     assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+
+
+@pytest.mark.parametrize("case", [(8, 64, 256, 256, "channel"), (8, 64, 256, 256, "spatial"), (2, 5, 6, 10, "channel"),
+                                  (3, 7, 12, 3, "spatial"), (1, 64, 16, 16, "spatial")])
+def test_gated_mul_vs_broadcast_multiply(case):
+    """csrc/gated_mul.hip == ``x * gate`` for CBAM's channel / spatial gates and RCG's gate (MMUNet.py:330,336,415):
+    forward bit-equal to the broadcast multiply, dx bit-equal, d gate against ATen's multiply + reduction;
+    bit-reproducible; other gate shapes fall back to ATen."""
+    from mm_unet_amd import pointwise
+    B, C, H, W, kind = case
+    gen = torch.Generator(device=DEV).manual_seed(14)
+    x = torch.randn(B, C, H, W, device=DEV, generator=gen)
+    gate = torch.rand(*((B, C, 1, 1) if kind == "channel" else (B, 1, H, W)), device=DEV, generator=gen)
+    g = torch.randn(B, C, H, W, device=DEV, generator=gen)
+    xr, gr = x.clone().requires_grad_(), gate.clone().requires_grad_()
+    (xr * gr).backward(g)
+    res = []
+    for _ in range(2):
+        xo, go = x.clone().requires_grad_(), gate.clone().requires_grad_()
+        assert pointwise._gate_mode(xo, go) is not None
+        out = pointwise.gated_mul(xo, go)
+        out.backward(g)
+        res.append((out.detach(), xo.grad, go.grad))
+    out, gx, gg = res[0]
+    assert torch.equal(out, x * gate) and torch.equal(gx, xr.grad)
+    n = (H * W if kind == "channel" else C) ** 0.5
+    close(gg, gr.grad, 1e-4, 2e-6 * n, "d gate")
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    odd = torch.rand(B, C, H, 1, device=DEV, generator=gen)
+    assert pointwise._gate_mode(x, odd) is None and torch.equal(pointwise.gated_mul(x, odd), x * odd)
