@@ -63,7 +63,7 @@ def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     return batch, dim, seqlen, dstate, g
 
 
-def _fwd_one(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
+def _fwd_one(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True, x_out=None):
     """selective_scan_cuda.fwd: returns ``[out, x]`` or ``[out, x, out_z]`` (selective_scan.cpp:226-336).
 
     ``want_out=False`` (extension over the reference signature, only valid with ``z_``): do not
@@ -76,7 +76,10 @@ def _fwd_one(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=Tr
     _check(want_out or z_ is not None, "selective_scan_fwd: want_out=False needs z")
     out = torch.empty_like(delta) if want_out else None
     out_z = torch.empty_like(z_) if z_ is not None else None
-    x = torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device, dtype=torch.float32)
+    x = x_out if x_out is not None else torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device,
+                                                    dtype=torch.float32)
+    _check(x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape) == (batch, dim, n_chunks, 2 * dstate),
+           "selective_scan_fwd: x_out must be a contiguous float32 (batch, dim, n_chunks, 2 * dstate) tensor")
     p = _lib.ScanFwdParams()
     p.batch, p.dim, p.seqlen, p.dstate, p.ngroups = batch, dim, seqlen, dstate, g
     p.dtype = _lib.dtype_code(u)
@@ -254,7 +257,7 @@ def _sum_parts(parts, dtype, out=None):
     return res
 
 
-def _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
+def _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True, group_major_x=False):
     """Everything the kernel computes per token is LINEAR in the group's y -- out = y, out_z = y silu(z) -- so every
     group launch gets z (and group 0 gets D) and the outputs are simply added up."""
     io_dtype = u.dtype
@@ -264,12 +267,18 @@ def _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out
     T = chunk_len(dstate, u.dtype)
     _check(T == chunk_len(16, u.dtype), "selective_scan: group split needs equal chunk lengths")
     n_chunks = (seqlen + T - 1) // T
-    x = torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device, dtype=torch.float32)
+    # group_major_x (internal callers that only hand x back to bwd): the groups' chunk states stay where their launches
+    # wrote them, [group][batch][dim][chunk][32]; the reference's layout needs one strided copy per group and direction
+    if group_major_x:
+        x = torch.empty((dstate // 16, batch, dim, n_chunks, 32), device=u.device, dtype=torch.float32)
+    else:
+        x = torch.empty((batch, dim, n_chunks, 2 * dstate), device=u.device, dtype=torch.float32)
     outs, out_zs = [], []
     for g, sl, Ag, Bg, Cg in _groups(A, B, C):
         r = _fwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, z_, delta_bias_, delta_softplus,
-                     want_out=want_out or z_ is None)
-        x[..., 32 * g:32 * g + 32] = r[1]
+                     want_out=want_out or z_ is None, x_out=x[g] if group_major_x else None)
+        if not group_major_x:
+            x[..., 32 * g:32 * g + 32] = r[1]
         outs.append(r[0])
         if z_ is not None:
             out_zs.append(r[2])
@@ -285,7 +294,7 @@ def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_sof
     batch, dim, seqlen = u.shape
     dstate, g_ = A.shape[1], B.shape[1]
     if x_ is None:
-        x_ = _fwd_groups(u, delta, A, B, C, D_, None, delta_bias_, delta_softplus)[1]
+        x_ = _fwd_groups(u, delta, A, B, C, D_, None, delta_bias_, delta_softplus, group_major_x=True)[1]
     u, delta, z_, dout, B, C = _f32(u, delta, z_, dout, B, C)
     f32 = dict(device=u.device, dtype=torch.float32)
     dB = dB_out if dB_out is not None else torch.empty((batch, g_, dstate, seqlen), **f32)
@@ -295,7 +304,8 @@ def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_sof
     dus, ddeltas, dzs, out_zs = [], [], [], []
     for g, sl, Ag, Bg, Cg in _groups(A, B, C):
         r = _bwd_one(u, delta, Ag, Bg, Cg, D_ if g == 0 else None, z_, delta_bias_, dout,
-                     x_[..., 32 * g:32 * g + 32].contiguous(), None, None, delta_softplus, recompute_out_z,
+                     x_[g] if x_.dim() == 5 else x_[..., 32 * g:32 * g + 32].contiguous(), None, None, delta_softplus,
+                     recompute_out_z,
                      dB_out=dB[:, :, sl], dC_out=dC[:, :, sl])
         dA[:, sl] = r[2]
         dus.append(r[0])
@@ -323,13 +333,15 @@ def _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_sof
     return result
 
 
-def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True):
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True, opaque_x=False):
     """selective_scan_cuda.fwd (selective_scan.cpp:226-336): ``[out, x]`` or ``[out, x, out_z]``; see ``_fwd_one``.
-    ``want_out=False`` (extension, only with ``z_``): ``None`` in place of the un-gated ``out``."""
+    ``want_out=False`` (extension, only with ``z_``): ``None`` in place of the un-gated ``out``.
+    ``opaque_x=True`` (extension): the caller only hands ``x`` back to :func:`bwd`; a state-group call may then keep it
+    group-major (5-D) instead of the reference's (batch, dim, n_chunks, 2 * dstate) layout."""
     if A.dim() == 2 and u.dim() == 3 and group_split(A.shape[1], u):
         _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
         _check(want_out or z_ is not None, "selective_scan_fwd: want_out=False needs z")
-        return _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out)
+        return _fwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out, group_major_x=opaque_x)
     return _fwd_one(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out)
 
 

@@ -256,7 +256,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         D = D.contiguous()
     # the un-gated `out` is not kept: this backward recomputes y from the states it rebuilds
     _, scan_intermediates, out_z = selective_scan_hip.fwd(conv1d_out, delta, A, B, C, D, z, delta_bias,
-                                                          delta_softplus, want_out=False)
+                                                          delta_softplus, want_out=False, opaque_x=True)
     ctx.delta_softplus = delta_softplus
     ctx.checkpoint_lvl = checkpoint_lvl
     ctx.with_out_proj = with_out_proj
