@@ -216,9 +216,10 @@ __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
 
 int channel_slices(int B, int C, int positions) {
     // enough threads to fill the chip, but never fewer than 8 channels per slice
+    static const long target = []() { const char *e = getenv("MMU_MORPH_SLICE_THREADS"); return e ? atol(e) : 131072L; }();
     long threads = (long)B * positions;
     int cs = 1;
-    while (threads * cs < 131072 && C / (cs * 2) >= 8) cs *= 2;
+    while (threads * cs < target && C / (cs * 2) >= 8) cs *= 2;
     return cs;
 }
 
