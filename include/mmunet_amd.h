@@ -375,6 +375,29 @@ typedef struct {
 size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);
 int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream);
 
+/* ---- CBAM's pooled statistics: mean and max (with arg-max) in one pass, one-pass backward ----------------------------- */
+/* src/UM_Net/MMUNet.py:327-333.  float32, contiguous [batch, channels, hw], hw % 4 == 0; ties go to the first maximum.
+ *   MMU_STATS_PIXELS  : mean / max / argmax [batch * channels] over the pixels of a (b, c) row (avg_pool, max_pool);
+ *                       bwd: dinput = dmean / hw + [p == argmax] dmax
+ *   MMU_STATS_CHANNELS: out [batch, 2, hw] = (max, mean) over the channels of a pixel, argmax [batch, hw] (int32);
+ *                       bwd: dinput[c] = dout[:, 1] / channels + [c == argmax] dout[:, 0] */
+#define MMU_STATS_PIXELS 0
+#define MMU_STATS_CHANNELS 1
+typedef struct {
+    int32_t batch, channels, mode;
+    int64_t hw;
+    const float *input;    /* fwd */
+    float *mean, *max;     /* fwd, MMU_STATS_PIXELS */
+    float *out;            /* fwd, MMU_STATS_CHANNELS */
+    int32_t *argmax;       /* fwd: written; bwd: read */
+    const float *dmean, *dmax;   /* bwd, MMU_STATS_PIXELS */
+    const float *dout;     /* bwd, MMU_STATS_CHANNELS */
+    float *dinput;         /* bwd */
+} mmu_cbam_stats_params;
+
+int mmu_cbam_stats_fwd(const mmu_cbam_stats_params *p, void *stream);
+int mmu_cbam_stats_bwd(const mmu_cbam_stats_params *p, void *stream);
+
 /* ---- out = input * gate, gate constant over a channel's pixels or over a pixel's channels; backward in one pass ------- */
 /* CBAM's `c_out * x` and `s_out * y1` (src/UM_Net/MMUNet.py:330,336), RCG's gate product (MMUNet.py:415).  float32,
  * contiguous [batch, channels, hw], hw % 4 == 0.  gate / dgate: [batch, channels] (MMU_GATE_CHANNEL) or [batch, hw]

@@ -118,6 +118,11 @@ class GemmNtParams(ctypes.Structure):
                 ("c", _vp), ("workspace", _vp)]
 
 
+class CbamStatsParams(ctypes.Structure):
+    _fields_ = [("batch", _i32), ("channels", _i32), ("mode", _i32), ("hw", _i64)] + \
+               [(n, _vp) for n in ("input", "mean", "max", "out", "argmax", "dmean", "dmax", "dout", "dinput")]
+
+
 class GatedMulParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("channels", _i32), ("mode", _i32), ("hw", _i64)] + \
                [(n, _vp) for n in ("input", "gate", "out", "dout", "dinput", "dgate")]
@@ -174,7 +179,7 @@ EXPORTS = (
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
-    "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
+    "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_debug_wave_scan",
 )
 
@@ -213,6 +218,7 @@ def lib():
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
                      ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams),
                      ("mmu_gemm_nt_splitk", GemmNtParams),
+                     ("mmu_cbam_stats_fwd", CbamStatsParams), ("mmu_cbam_stats_bwd", CbamStatsParams),
                      ("mmu_gated_mul_fwd", GatedMulParams), ("mmu_gated_mul_bwd", GatedMulParams),
                      ("mmu_conv7x7_2to1_fwd", Conv7x7Params), ("mmu_conv7x7_2to1_bwd", Conv7x7Params),
                      ("mmu_maxpool3s2_bwd", MaxPoolParams), ("mmu_sum_parts", SumPartsParams), ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams)):

@@ -283,12 +283,21 @@ class CBAM(nn.Module):
         # global max as a flat reduction: ATen's adaptive_max_pool2d kernel takes 6 ms on the
         # [8, 64, 256, 256] stem map (one thread per output element); same value, and like the pooling
         # op the gradient goes to one arg-max element.
-        x_max = x.flatten(2).max(dim=2)[0].unsqueeze(-1).unsqueeze(-1)
-        c_out = self.sigmoid(self.mlp(self.avg_pool(x)) + self.mlp(x_max))
+        fused = pointwise.stats_supported(x)
+        if fused:    # mean and max (+ arg-max) in one pass each way (csrc/cbam_stats.hip)
+            x_avg, x_max = pointwise.pixel_mean_max(x)
+        else:
+            x_avg = self.avg_pool(x)
+            x_max = x.flatten(2).max(dim=2)[0].unsqueeze(-1).unsqueeze(-1)
+        c_out = self.sigmoid(self.mlp(x_avg) + self.mlp(x_max))
         y1 = pointwise.gated_mul(x, c_out)
-        s_avg = torch.mean(y1, dim=1, keepdim=True)
-        s_max, _ = torch.max(y1, dim=1, keepdim=True)
-        s_out = self.sigmoid(pointwise.conv7_module(self.conv, torch.cat((s_max, s_avg), 1)))
+        if fused:
+            s_cat = pointwise.channel_max_mean(y1)
+        else:
+            s_avg = torch.mean(y1, dim=1, keepdim=True)
+            s_max, _ = torch.max(y1, dim=1, keepdim=True)
+            s_cat = torch.cat((s_max, s_avg), 1)
+        s_out = self.sigmoid(pointwise.conv7_module(self.conv, s_cat))
         return pointwise.gated_mul(y1, s_out)
 
 

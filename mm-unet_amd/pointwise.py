@@ -182,3 +182,90 @@ def gated_mul(x, gate):
     """``x * gate`` (broadcast); the one-pass HIP form for channel / spatial gates of a float32 NCHW tensor, else ATen."""
     mode = _gate_mode(x, gate)
     return GatedMulFn.apply(x, gate, mode) if mode is not None else x * gate
+
+
+# ---- CBAM's pooled statistics (MMUNet.py:327-333): mean and max in one pass, one-pass backward ---------------------------
+STATS = os.environ.get("MMUNET_CBAM_STATS", "1") != "0"
+
+
+def stats_supported(x):
+    return (ENABLED and STATS and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] < 65536 and x.shape[1] > 1
+            and not torch.is_autocast_enabled())
+
+
+class _PixelStatsFn(torch.autograd.Function):
+    """x (B, C, H, W) -> (mean, max) over the pixels, each (B, C, 1, 1)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_gpu(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        mean = torch.empty((B, C, 1, 1), device=x.device, dtype=torch.float32)
+        mx = torch.empty_like(mean)
+        am = torch.empty((B, C), device=x.device, dtype=torch.int32)
+        p = _lib.CbamStatsParams()
+        p.batch, p.channels, p.mode, p.hw = B, C, 0, H * W
+        p.input, p.mean, p.max, p.argmax = x.data_ptr(), mean.data_ptr(), mx.data_ptr(), am.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_cbam_stats_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(am)
+        ctx.shape = x.shape
+        return mean, mx
+
+    @staticmethod
+    def backward(ctx, gmean, gmax):
+        am, = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        gmean, gmax = gmean.float().contiguous(), gmax.float().contiguous()
+        dx = torch.empty(ctx.shape, device=am.device, dtype=torch.float32)
+        p = _lib.CbamStatsParams()
+        p.batch, p.channels, p.mode, p.hw = B, C, 0, H * W
+        p.argmax, p.dmean, p.dmax, p.dinput = am.data_ptr(), gmean.data_ptr(), gmax.data_ptr(), dx.data_ptr()
+        with torch.cuda.device(am.device):
+            _lib.check(_lib.lib().mmu_cbam_stats_bwd(p, _lib.stream_of(am)))
+        return dx
+
+
+class _ChannelStatsFn(torch.autograd.Function):
+    """x (B, C, H, W) -> (B, 2, H, W): max over the channels, then their mean (the order of MMUNet.py:333)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_gpu(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty((B, 2, H, W), device=x.device, dtype=torch.float32)
+        am = torch.empty((B, H, W), device=x.device, dtype=torch.int32)
+        p = _lib.CbamStatsParams()
+        p.batch, p.channels, p.mode, p.hw = B, C, 1, H * W
+        p.input, p.out, p.argmax = x.data_ptr(), out.data_ptr(), am.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_cbam_stats_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(am)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        am, = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        g = g.float().contiguous()
+        dx = torch.empty(ctx.shape, device=am.device, dtype=torch.float32)
+        p = _lib.CbamStatsParams()
+        p.batch, p.channels, p.mode, p.hw = B, C, 1, H * W
+        p.argmax, p.dout, p.dinput = am.data_ptr(), g.data_ptr(), dx.data_ptr()
+        with torch.cuda.device(am.device):
+            _lib.check(_lib.lib().mmu_cbam_stats_bwd(p, _lib.stream_of(am)))
+        return dx
+
+
+def pixel_mean_max(x):
+    """(avg_pool(x), max_pool(x)) of CBAM's channel attention, each (B, C, 1, 1)."""
+    return _PixelStatsFn.apply(x)
+
+
+def channel_max_mean(x):
+    """cat((max over channels, mean over channels), 1) of CBAM's spatial attention, (B, 2, H, W)."""
+    return _ChannelStatsFn.apply(x)

@@ -1216,3 +1216,42 @@ def test_gated_mul_vs_broadcast_multiply(case):
     assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
     odd = torch.rand(B, C, H, 1, device=DEV, generator=gen)
     assert pointwise._gate_mode(x, odd) is None and torch.equal(pointwise.gated_mul(x, odd), x * odd)
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 256, 256), (2, 5, 6, 10), (3, 16, 12, 12), (1, 64, 16, 16)])
+def test_cbam_stats_vs_aten(shape):
+    """csrc/cbam_stats.hip: (avg_pool, max_pool) over the pixels and cat(max, mean) over the channels of CBAM
+    (MMUNet.py:327-333) against the ATen ops, forward and input gradient, ties included (values on a coarse grid: the
+    first maximum takes the gradient, as torch.max does); bit-reproducible."""
+    from mm_unet_amd import pointwise
+    B, C, H, W = shape
+    gen = torch.Generator(device=DEV).manual_seed(23)
+    x = (torch.randn(B, C, H, W, device=DEV, generator=gen) * 3).round() / 3
+    assert pointwise.stats_supported(x)
+    # pixels
+    ga, gm = torch.randn(B, C, 1, 1, device=DEV, generator=gen), torch.randn(B, C, 1, 1, device=DEV, generator=gen)
+    xr = x.clone().requires_grad_()
+    avg_ref = xr.mean(dim=(2, 3), keepdim=True)
+    max_ref = xr.flatten(2).max(dim=2)[0].unsqueeze(-1).unsqueeze(-1)
+    (avg_ref * ga + max_ref * gm).sum().backward()
+    res = []
+    for _ in range(2):
+        xo = x.clone().requires_grad_()
+        avg, mx = pointwise.pixel_mean_max(xo)
+        (avg * ga + mx * gm).sum().backward()
+        res.append((avg.detach(), mx.detach(), xo.grad))
+    close(res[0][0], avg_ref, 1e-5, 1e-6, "mean over pixels")
+    assert torch.equal(res[0][1], max_ref)
+    close(res[0][2], xr.grad, 1e-6, 1e-7, "d input (pixels)")
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    # channels
+    g = torch.randn(B, 2, H, W, device=DEV, generator=gen)
+    xr = x.clone().requires_grad_()
+    ref = torch.cat((torch.max(xr, dim=1, keepdim=True)[0], torch.mean(xr, dim=1, keepdim=True)), 1)
+    ref.backward(g)
+    xo = x.clone().requires_grad_()
+    out = pointwise.channel_max_mean(xo)
+    out.backward(g)
+    assert torch.equal(out[:, 0], ref[:, 0])
+    close(out[:, 1], ref[:, 1], 1e-5, 1e-6, "mean over channels")
+    close(xo.grad, xr.grad, 1e-6, 1e-7, "d input (channels)")
