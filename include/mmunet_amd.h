@@ -48,6 +48,11 @@ extern "C" {
 #define MMU_DTYPE_BF16 1
 
 /* ---- library info ------------------------------------------------------ */
+/* Version of the parameter-struct layouts below.  Bumped whenever a struct changes (fields are only ever appended);
+ * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
+ *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
+ *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
+#define MMU_ABI_VERSION 3
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -563,6 +568,53 @@ int mmu_zigzag_inproj_fwd(const mmu_coords_params *p, void *stream);
 int mmu_zigzag_inproj_bwd(const mmu_coords_params *p, void *stream);
 int mmu_coords_outproj_fwd(const mmu_coords_params *p, void *stream);
 int mmu_coords_outproj_bwd(const mmu_coords_params *p, void *stream);
+
+/* ---- the whole K-channel Mamba chain of an MMConv block on a small map, one kernel each way (rows f1 + f2) ---- */
+/* Replaces, for height * width = 64 T nw tokens (T in {1, 2, 4} tokens per lane, nw <= 8 waves: 64 .. 2,048 tokens,
+ * MM-UNet's 16 x 16 and 32 x 32 maps), the six forward launches zigzag_inproj -> mamba_pre_small -> selective scan
+ * (3 kernels) -> coords_outproj and their eleven backward launches:
+ *   src/UM_Net/MMUNet.py:176-188 (zig-zag flatten, self.mamba, inverse zig-zag, coordinate arithmetic),
+ *   requirements/mamba_simple.py:201-205,303-318,365 (in_proj, uni-directional branch, out_proj),
+ *   mamba_ssm/ops/selective_scan_interface.py:173-215 (MambaInnerFn.forward) and :238-289,387-394 (backward),
+ *   csrc/selective_scan/selective_scan_{fwd,bwd}_kernel.cuh, causal-conv1d/csrc/causal_conv1d_{fwd,bwd}.cu.
+ * One workgroup per batch item; taps K in {1, 3}, inner width 2K, conv width 4, dt_rank 1, d_state <= 64, float32,
+ * every tensor contiguous.
+ *   fwd: offset [B, 2K, H, W] (only channels 0..K-1 are read) -> y [B, K, H, W] (row coordinates);
+ *        hstate (optional, mmu_mamba_small_state_floats() floats) receives the scan state entering every lane's
+ *        token group -- the backward needs it.
+ *   bwd: dy [B, K, H, W], hstate -> doffset [B, 2K, H, W] (channels K..2K-1 = 0) and dweights
+ *        (mmu_mamba_small_grad_floats() floats: in_proj [4K][K] | conv weight [2K][4] | conv bias [2K] |
+ *        x_proj [1+2N][2K] | dt_proj [2K] | dt bias [2K] | A [2K][N] | D [2K] | out_proj [K][2K] | altho);
+ *        workspace: batch * mmu_mamba_small_grad_floats() floats (per-batch-item partials, summed in fixed order:
+ *        deterministic, no atomics, nothing to zero). */
+typedef struct {
+    int32_t batch, height, width, taps, dstate;
+    float extend_scope;
+    const float *offset;
+    const float *in_proj_weight;   /* [4K][K] */
+    const float *conv_weight;      /* [2K][4] */
+    const float *conv_bias;        /* [2K] or NULL */
+    const float *x_proj_weight;    /* [1 + 2N][2K] */
+    const float *dt_proj_weight;   /* [2K] */
+    const float *dt_bias;          /* [2K] or NULL */
+    const float *A;                /* [2K][N], = -exp(A_log) */
+    const float *D;                /* [2K] or NULL */
+    const float *out_proj_weight;  /* [K][2K] */
+    const float *altho;            /* scalar */
+    float *y;
+    float *hstate;
+    const float *dy;
+    float *doffset;
+    float *workspace;
+    float *dweights;
+} mmu_mamba_small_params;
+
+int mmu_mamba_small_supported(int taps, int height, int width, int dstate);
+int mmu_mamba_small_tokens_per_lane(int height, int width);
+size_t mmu_mamba_small_state_floats(int batch, int taps, int height, int width, int dstate);
+size_t mmu_mamba_small_grad_floats(int taps, int dstate);
+int mmu_mamba_small_fwd(const mmu_mamba_small_params *p, void *stream);
+int mmu_mamba_small_bwd(const mmu_mamba_small_params *p, void *stream);
 
 /* ---- test hooks (exercise the wave-level primitives on the GPU) -------- */
 /* Runs the in-wave affine-pair scan on n_waves*64 (P,S) pairs, one wave per 64.

@@ -167,6 +167,13 @@ class CoordsParams(ctypes.Structure):
                                       "daltho")])
 
 
+class MambaSmallParams(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps", "dstate")] + [("extend_scope", ctypes.c_float)]
+                + [(n, _vp) for n in ("offset", "in_proj_weight", "conv_weight", "conv_bias", "x_proj_weight",
+                                      "dt_proj_weight", "dt_bias", "A", "D", "out_proj_weight", "altho", "y", "hstate",
+                                      "dy", "doffset", "workspace", "dweights")])
+
+
 # every symbol include/mmunet_amd.h declares (tests check that the library exports all of them)
 EXPORTS = (
     "mmu_abi_version", "mmu_last_error", "mmu_scan_chunk_len", "mmu_scan_bwd_workspace_bytes",
@@ -180,10 +187,13 @@ EXPORTS = (
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
+    "mmu_mamba_small_supported", "mmu_mamba_small_tokens_per_lane", "mmu_mamba_small_state_floats",
+    "mmu_mamba_small_grad_floats", "mmu_mamba_small_fwd", "mmu_mamba_small_bwd",
     "mmu_debug_wave_scan",
 )
 
 _lib = None
+ABI_VERSION = 3   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():
@@ -200,6 +210,9 @@ def lib():
     except OSError as e:  # e.g. no ROCm runtime on this host
         raise RuntimeError(f"mm-unet_amd: cannot load {LIB_PATH}: {e}.  There is no CPU fallback.") from e
     L.mmu_abi_version.restype = ctypes.c_int
+    if L.mmu_abi_version() != ABI_VERSION:   # struct layouts below are those of include/mmunet_amd.h at this version
+        raise RuntimeError(f"mm-unet_amd: {LIB_PATH} has ABI version {L.mmu_abi_version()}, this binding was written "
+                           f"against {ABI_VERSION} (include/mmunet_amd.h: MMU_ABI_VERSION); rebuild with csrc/build.sh")
     L.mmu_last_error.restype = ctypes.c_char_p
     L.mmu_scan_chunk_len.restype = ctypes.c_int
     L.mmu_scan_chunk_len.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -221,7 +234,8 @@ def lib():
                      ("mmu_cbam_stats_fwd", CbamStatsParams), ("mmu_cbam_stats_bwd", CbamStatsParams),
                      ("mmu_gated_mul_fwd", GatedMulParams), ("mmu_gated_mul_bwd", GatedMulParams),
                      ("mmu_conv7x7_2to1_fwd", Conv7x7Params), ("mmu_conv7x7_2to1_bwd", Conv7x7Params),
-                     ("mmu_maxpool3s2_bwd", MaxPoolParams), ("mmu_sum_parts", SumPartsParams), ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams)):
+                     ("mmu_maxpool3s2_bwd", MaxPoolParams), ("mmu_sum_parts", SumPartsParams), ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams),
+                     ("mmu_mamba_small_fwd", MambaSmallParams), ("mmu_mamba_small_bwd", MambaSmallParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -247,6 +261,14 @@ def lib():
     L.mmu_mamba_post_small_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
     L.mmu_norm_fused_workspace_floats.restype = ctypes.c_size_t
     L.mmu_norm_fused_workspace_floats.argtypes = [ctypes.c_int] * 3
+    L.mmu_mamba_small_supported.restype = ctypes.c_int
+    L.mmu_mamba_small_supported.argtypes = [ctypes.c_int] * 4
+    L.mmu_mamba_small_tokens_per_lane.restype = ctypes.c_int
+    L.mmu_mamba_small_tokens_per_lane.argtypes = [ctypes.c_int] * 2
+    L.mmu_mamba_small_state_floats.restype = ctypes.c_size_t
+    L.mmu_mamba_small_state_floats.argtypes = [ctypes.c_int] * 5
+    L.mmu_mamba_small_grad_floats.restype = ctypes.c_size_t
+    L.mmu_mamba_small_grad_floats.argtypes = [ctypes.c_int] * 2
     L.mmu_debug_wave_scan.restype = ctypes.c_int
     L.mmu_debug_wave_scan.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]
     _lib = L

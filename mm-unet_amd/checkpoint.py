@@ -22,6 +22,21 @@ def _load_model_file(path):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
+def _load_obj_state(obj, state):
+    """``obj.load_state_dict(state)``; for an optimizer whose learning rate is a DEVICE TENSOR
+    (``train_step.make_optimizer(capturable=True)``: a captured optimizer step reads it at replay time) the tensor
+    object is kept and the loaded value is written into it.  ``Optimizer.load_state_dict`` replaces each group's
+    ``lr`` with what the file holds -- a Python float from a reference-written ``optimizer.bin``, a CPU tensor from
+    this package's own -- and either would be baked into (or break) the captured step."""
+    groups = getattr(obj, "param_groups", None)
+    kept = [g["lr"] if isinstance(g.get("lr"), torch.Tensor) else None for g in groups] if groups is not None else []
+    obj.load_state_dict(state)
+    for g, lr in zip(getattr(obj, "param_groups", []), kept):
+        if lr is not None:
+            lr.fill_(float(g["lr"]))
+            g["lr"] = lr
+
+
 def load_state(directory, model, optimizer=None, scheduler=None, strict=True):
     """Loads an ``accelerator.save_state`` directory: model weights (required), optimizer / scheduler state when the
     objects are passed and their files exist.  Returns the contents of ``epoch.pth.tar`` ({} when absent)."""
@@ -35,7 +50,7 @@ def load_state(directory, model, optimizer=None, scheduler=None, strict=True):
     for obj, name in ((optimizer, "optimizer.bin"), (scheduler, "scheduler.bin")):
         path = os.path.join(directory, name)
         if obj is not None and os.path.exists(path):
-            obj.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+            _load_obj_state(obj, torch.load(path, map_location="cpu", weights_only=False))
     epoch_file = os.path.join(directory, "epoch.pth.tar")
     return torch.load(epoch_file, map_location="cpu", weights_only=False) if os.path.exists(epoch_file) else {}
 

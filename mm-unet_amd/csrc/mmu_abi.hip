@@ -13,4 +13,4 @@ int mmu_fail(const char *fmt, ...) {
 }
 
 extern "C" const char *mmu_last_error(void) { return g_mmu_err; }
-extern "C" int mmu_abi_version(void) { return 1; }
+extern "C" int mmu_abi_version(void) { return MMU_ABI_VERSION; }

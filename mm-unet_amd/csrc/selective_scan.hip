@@ -1704,7 +1704,7 @@ int launch_bwd(ScanArgs a, bool have_x, float *ws, hipStream_t st, bool *w8_layo
     };
     if (fast) {   // 512-token tiles, one state pair per wave (selective_scan_bwd_w8.hip), when the launch fills the chip
         const int r = mmu_scan_bwd_apply_w8(a, sizeof(io_t) == 4 ? MMU_DTYPE_F32 : MMU_DTYPE_BF16, st);
-        if (r < 0) return r;
+        if (r < 0) return 1;   // the message is already in mmu_last_error()
         if (r == 1) {
             *w8_layout = true;
             return join_splits();

@@ -496,8 +496,17 @@ int mmu_scan_bwd_apply_w8(const ScanArgs &a, int dtype, hipStream_t st) {
             }
         });
     });
-    if (err != hipSuccess) return mmu_fail("chunk_apply_bwd_w8: hipFuncSetAttribute: %s", hipGetErrorString(err));
-    MMU_HIP_LAUNCH_CHECK("chunk_apply_bwd_w8");
+    // contract: 1 = taken, 0 = not taken, < 0 = error (mmu_fail() itself returns 1 = "an error", which would read as
+    // "taken" here)
+    if (err != hipSuccess) {
+        mmu_fail("chunk_apply_bwd_w8: hipFuncSetAttribute: %s", hipGetErrorString(err));
+        return -1;
+    }
+    err = hipGetLastError();
+    if (err != hipSuccess) {
+        mmu_fail("chunk_apply_bwd_w8: %s", hipGetErrorString(err));
+        return -1;
+    }
     return 1;
 }
 

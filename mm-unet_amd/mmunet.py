@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba, neg_exp, precomputed_A
-from . import conv3x3_mfma, conv3x3_small, morph_coords, norm_fused
+from . import conv3x3_mfma, conv3x3_small, mamba_small_fused, morph_coords, norm_fused
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
 from . import maxpool as maxpool_op, pointwise
@@ -140,6 +140,9 @@ class MMConv(nn.Module):
         Mamba branch, mamba_simple.py:303-318] -> out_proj + inverse zig-zag + coordinate arithmetic."""
         m = self.mamba
         with torch.autocast("cuda", enabled=False):  # a 2K-channel fp32 scan; grid_sample is fp32 anyway
+            if mamba_small_fused.supported(offset, self.kernel_size, m):
+                # small maps (16 x 16, 32 x 32): the whole chain below as ONE kernel each way
+                return mamba_small_fused.mamba_rows(offset, m, self.altho, self.extend_scope, A=neg_exp(m.A_log))
             xz = morph_coords.zigzag_inproj(offset, m.in_proj.weight)
             out_z = mamba_inner_fn_no_out_proj(xz, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
                                                m.dt_proj.weight, neg_exp(m.A_log), None, None,

@@ -126,6 +126,14 @@ def conv7_module(m, x):
     return Conv7x7SmallFn.apply(x, m.weight) if conv7_supported(m, x) else m(x)
 
 
+def _need_f32_nchw(name, t, hw_mult=4):
+    """Raw-pointer rule: a wrapper takes ``data_ptr()`` only of tensors it has itself checked to be
+    float32 with the expected rank; anything else raises instead of being read as float32 out of bounds."""
+    if t.dtype != torch.float32 or t.dim() != 4 or (t.shape[2] * t.shape[3]) % hw_mult != 0 or t.shape[0] >= 65536:
+        raise RuntimeError(f"{name}: expected a float32 (B, C, H, W) tensor with H*W % {hw_mult} == 0 and B < 65536, got "
+                           f"{t.dtype} {tuple(t.shape)}")
+
+
 # ---- x * gate with a per-channel ([B, C, 1, 1]) or per-pixel ([B, 1, H, W]) gate (MMUNet.py:330,336,415) --------------
 GATED_MUL = os.environ.get("MMUNET_GATED_MUL", "1") != "0"
 
@@ -147,6 +155,11 @@ class GatedMulFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gate, mode):
         _lib.require_gpu(x, gate)
+        _need_f32_nchw("gated_mul", x)
+        if gate.dtype != torch.float32 or mode not in (0, 1) or tuple(gate.shape) != (
+                (x.shape[0], x.shape[1], 1, 1) if mode == 0 else (x.shape[0], 1, x.shape[2], x.shape[3])):
+            raise RuntimeError(f"gated_mul: gate must be float32 (B, C, 1, 1) [mode 0] or (B, 1, H, W) [mode 1], got "
+                               f"{gate.dtype} {tuple(gate.shape)} for mode {mode} and input {tuple(x.shape)}")
         x, gate = x.contiguous(), gate.contiguous()
         B, C, H, W = x.shape
         out = torch.empty_like(x)
@@ -200,6 +213,7 @@ class _PixelStatsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _lib.require_gpu(x)
+        _need_f32_nchw("pixel_mean_max", x)
         x = x.contiguous()
         B, C, H, W = x.shape
         mean = torch.empty((B, C, 1, 1), device=x.device, dtype=torch.float32)
@@ -234,6 +248,7 @@ class _ChannelStatsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _lib.require_gpu(x)
+        _need_f32_nchw("channel_max_mean", x)
         x = x.contiguous()
         B, C, H, W = x.shape
         out = torch.empty((B, 2, H, W), device=x.device, dtype=torch.float32)

@@ -202,8 +202,12 @@ GROUP_SPLIT_MIN_ELEMENTS = int(os.environ.get("MMUNET_GROUP_SPLIT_MIN", str(1 <<
 
 def group_split(dstate, u):
     """True when fwd / bwd run this call as dstate // 16 launches of the dstate-16 kernels."""
-    return (GROUP_SPLIT and dstate > 16 and dstate % 16 == 0 and u.numel() >= GROUP_SPLIT_MIN_ELEMENTS
-            and u.shape[-1] % 512 == 0)
+    if not (GROUP_SPLIT and dstate > 16 and dstate % 16 == 0 and u.numel() >= GROUP_SPLIT_MIN_ELEMENTS
+            and u.shape[-1] % 512 == 0):
+        return False
+    # the groups' chunk states are laid out with the dstate-16 kernels' chunk length: only states whose own chunk
+    # length is the same (48, 64 today) can be split; 32 and 80..128 stay on the generic kernels (_fwd_one / _bwd_one)
+    return chunk_len(dstate, torch.float32) == chunk_len(16, torch.float32)
 
 
 def _groups(A, B, C):

@@ -134,3 +134,34 @@ def test_optimizer_bin_in_timm_group_order_round_trips_through_make_optimizer(tm
     load_state(d2, m3, opt3)
     for n, p in named3:
         assert torch.equal(opt3.state[p]["exp_avg"], moments[n]), n
+
+
+def test_load_state_keeps_a_tensor_learning_rate(tmp_path):
+    """``make_optimizer(capturable=True)`` keeps the learning rate in a tensor that a captured optimizer
+    step reads at replay time.  ``Optimizer.load_state_dict`` swaps each group's ``lr`` for the saved value (a float from
+    a reference-written ``optimizer.bin``, a CPU tensor from our own): load_state must write the value INTO the
+    existing tensor instead, so that ``set_lr`` / schedulers still drive what the step reads."""
+    from mm_unet_amd.checkpoint import load_state, save_state
+    from mm_unet_amd.train_step import set_lr
+    m = _model()
+    # (a) float-lr file, as the reference's accelerate writes it; (b) tensor-lr file, as save_state writes ours
+    for tensor_lr_in_file in (False, True):
+        lr_saved = torch.tensor(3e-4) if tensor_lr_in_file else 3e-4
+        opt = torch.optim.AdamW(m.parameters(), lr=lr_saved, foreach=False)
+        sch = torch.optim.lr_scheduler.StepLR(opt, 10)
+        _train_a_little(m, opt, sch)
+        d = str(tmp_path / f"ck{int(tensor_lr_in_file)}")
+        save_state(d, m, opt)
+        m2 = _model()
+        lr_live = torch.tensor(1e-3)
+        opt2 = torch.optim.AdamW(m2.parameters(), lr=lr_live, foreach=False)
+        load_state(d, m2, opt2)
+        for g in opt2.param_groups:
+            assert g["lr"] is lr_live, "load_state replaced the live learning-rate tensor"
+        assert abs(float(lr_live) - 3e-4) < 1e-9, "the loaded value did not reach the live tensor"
+        set_lr(opt2, 0.0)
+        assert float(lr_live) == 0.0
+        before = [p.detach().clone() for p in m2.parameters()]
+        m2(torch.randn(2, 3, 32, 32)).mean().backward()
+        opt2.step()
+        assert all(torch.equal(a, b.detach()) for a, b in zip(before, m2.parameters())), "lr = 0 did not reach the step"

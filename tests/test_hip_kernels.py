@@ -375,6 +375,32 @@ def test_scan_state_groups_dstate64_vs_golden_and_generic(monkeypatch):
             close(ga[i], gb[i], rt * 3, at * 3 * (sc if nm in ("dA", "dD", "ddelta_bias") else 1.0), f"{nm} {dt}")
 
 
+@pytest.mark.parametrize("dstate", [32, 128])
+def test_scan_large_dstate_without_equal_chunk_length_stays_on_generic_kernels(monkeypatch, dstate):
+    """d_state 32 and 80..128 have a different chunk length from the dstate-16 kernels (256 / 64 vs 128), so
+    they cannot run as state groups; group_split() must say so and fwd / bwd must take the generic kernels instead of
+    raising 'group split needs equal chunk lengths'.  Checked against the oracle."""
+    import oracle
+    from mm_unet_amd import selective_scan_hip as ss
+    monkeypatch.setattr(ss, "GROUP_SPLIT_MIN_ELEMENTS", 1)
+    c = _rand_case(1, 4, 1024, dstate, seed=9, device="cpu")
+    assert not ss.group_split(dstate, c["u"].to(DEV))
+    d = {k: v.to(DEV) for k, v in c.items()}
+    res = ss.fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], True)
+    _, ref_z, ref_last = oracle.selective_scan_fwd(c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"],
+                                                   c["delta_bias"], True)
+    close(res[2], ref_z, RTOL, ATOL, "out_z")
+    close(res[1][:, :, -1, 1::2], ref_last, RTOL, ATOL, "last_state")
+    r = ss.bwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["delta_bias"], d["dout"], res[1], res[0],
+               None, True, False)
+    ref = oracle.selective_scan_bwd(c["u"], c["delta"], c["A"], c["B"], c["C"], c["D"], c["z"], c["delta_bias"],
+                                    c["dout"], True)
+    close(r[0], ref["du"], RTOL * 2, ATOL * 2, "du")
+    close(r[1], ref["ddelta"], RTOL * 5, ATOL * 10, "ddelta")
+    close(r[3].reshape(ref["dB"].shape), ref["dB"], RTOL, ATOL, "dB")
+    close(r[4].reshape(ref["dC"].shape), ref["dC"], RTOL, ATOL, "dC")
+
+
 def test_scan_bwd_reproducibility():
     """Every gradient of the dstate-16 backward (K4p / K4s: register dB/dC sums, no atomics anywhere) is
     bit-identical run to run; the reference uses global float atomics for dA/dB/dC/dD/dbias

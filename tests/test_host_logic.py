@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"libmmunet_hip.so does not export {name}"
     lib = _lib.lib()
-    assert lib.mmu_abi_version() == 1
+    assert lib.mmu_abi_version() == _lib.ABI_VERSION
     assert lib.mmu_scan_chunk_len(16, 0) == 128 and lib.mmu_scan_chunk_len(32, 0) == 256
     assert lib.mmu_scan_chunk_len(64, 0) == 128
     assert lib.mmu_scan_chunk_len(300, 0) == 0
@@ -59,7 +59,8 @@ def test_param_structs_match_header_field_order():
                         ("mmu_conv1x1_one_params", _lib.Conv1x1OneParams),
                         ("mmu_maxpool_params", _lib.MaxPoolParams),
                         ("mmu_conv7x7_params", _lib.Conv7x7Params),
-                        ("mmu_gated_mul_params", _lib.GatedMulParams)):
+                        ("mmu_gated_mul_params", _lib.GatedMulParams),
+                        ("mmu_mamba_small_params", _lib.MambaSmallParams)):
         # (mmu_cbam_stats_params declares two pointers per line: not parsed by this check)
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 

@@ -1255,3 +1255,44 @@ def test_cbam_stats_vs_aten(shape):
     assert torch.equal(out[:, 0], ref[:, 0])
     close(out[:, 1], ref[:, 1], 1e-5, 1e-6, "mean over channels")
     close(xo.grad, xr.grad, 1e-6, 1e-7, "d input (channels)")
+
+
+@pytest.mark.parametrize("cfg", [(2, 3, 16, 16, 16), (3, 3, 32, 32, 16), (2, 1, 32, 32, 16), (1, 3, 8, 8, 16),
+                                 (2, 3, 32, 64, 16), (2, 3, 16, 32, 64), (8, 3, 8, 24, 16), (2, 1, 16, 16, 64)])
+def test_mamba_small_fused_vs_kernel_chain(cfg):
+    """csrc/mamba_small_fused.hip (one kernel each way: zig-zag + in_proj + conv1d + x_proj / dt_proj + selective scan +
+    out_proj + inverse zig-zag + coordinates, MMUNet.py:176-188) against the six-/eleven-launch chain it replaces
+    (morph_coords + mamba_pre + selective_scan kernels, each pinned by reference fixtures): row coordinates, d offset and
+    every parameter gradient; T = 1, 2 and 4 tokens per lane, 1..8 waves, both tap counts, d_state 16 and 64."""
+    from mm_unet_amd import mamba_small_fused as msf
+    from mm_unet_amd.mmunet import MMConv
+    B, K, H, W, N = cfg
+    torch.manual_seed(7)
+    m = MMConv(8, 8, kernel_size=K, num_slices=4, d_state=N).to(DEV).train()
+    with torch.no_grad():   # off the init's symmetric points: every gradient path carries signal
+        m.mamba.D.add_(0.3 * torch.randn_like(m.mamba.D))
+        m.mamba.A_log.add_(0.2 * torch.randn_like(m.mamba.A_log))
+        m.mamba.conv1d.bias.add_(0.2 * torch.randn_like(m.mamba.conv1d.bias))
+    gen = torch.Generator().manual_seed(11)
+    off0 = torch.tanh(torch.randn(B, 2 * K, H, W, generator=gen)).to(DEV)
+    dy = torch.randn(B, K, H, W, generator=gen).to(DEV)
+    assert msf.supported(off0, K, m.mamba)
+    res = {}
+    for fused in (True, False):
+        msf.ENABLED = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            off = off0.clone().requires_grad_()
+            y = m._rows_fused(off)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            res[fused] = (y.detach().clone(), off.grad.clone(),
+                          {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None})
+        finally:
+            msf.ENABLED = True
+    (ya, da, ga), (yb, db, gb) = res[True], res[False]
+    close(ya, yb, 1e-4, 1e-4, "rows")
+    close(da, db, 1e-3, 1e-4, "d offset")
+    assert set(ga) == set(gb), set(ga) ^ set(gb)
+    for k in sorted(ga):
+        close(ga[k], gb[k], 2e-3, 2e-3 * max(1.0, float(gb[k].abs().max())), k)

@@ -253,3 +253,51 @@ def test_bf16_activations_are_read_and_written_natively():
     assert torch.allclose(ob16.float(), ref16, atol=2e-2)
     ob16.backward(gref.bfloat16())
     assert xb16.grad.dtype == torch.bfloat16 and torch.isfinite(xb16.grad.float()).all()
+
+
+def test_pointwise_maxpool_gemm_nt_sum_parts_guards():
+    """the round-2 wrappers (CBAM statistics, gated products, max-pool backward, token-contraction GEMM, the
+    state groups' partial sums) under the same rule: bf16 / wrong-rank / wrong-gate inputs raise (or give the float32
+    result), never reach a float32 kernel as they are."""
+    from mm_unet_amd import maxpool, mfma_gemm, pointwise
+    from mm_unet_amd import selective_scan_hip as ss
+    x = _rnd(2, 8, 8, 8)
+    mean, mx = pointwise.pixel_mean_max(x)
+    torch.cuda.synchronize()
+    assert float((mean.flatten() - x.mean((2, 3)).flatten()).abs().max()) < 1e-5
+    assert float((mx.flatten() - x.amax((2, 3)).flatten()).abs().max()) == 0.0
+    for bad in (x.bfloat16(), x[0], _rnd(2, 8, 3, 5)):
+        with pytest.raises(RuntimeError):
+            pointwise.pixel_mean_max(bad)
+        with pytest.raises(RuntimeError):
+            pointwise.channel_max_mean(bad)
+    gate_c, gate_s = _rnd(2, 8, 1, 1, seed=1), _rnd(2, 1, 8, 8, seed=2)
+    out = pointwise.GatedMulFn.apply(x, gate_c, 0)
+    torch.cuda.synchronize()
+    assert float((out - x * gate_c).abs().max()) < 1e-6
+    for args in ((x.bfloat16(), gate_c, 0), (x, gate_c.bfloat16(), 0), (x, gate_s, 0), (x, gate_c, 1),
+                 (x, _rnd(2, 4, 1, 1), 0), (x[0], gate_c, 0)):
+        with pytest.raises(RuntimeError):
+            pointwise.GatedMulFn.apply(*args)
+    assert pointwise._gate_mode(x.bfloat16(), gate_c) is None and pointwise._gate_mode(x, _rnd(2, 4, 1, 1)) is None
+    with pytest.raises(RuntimeError):
+        maxpool.max_pool3s2(x.bfloat16())
+    with pytest.raises(RuntimeError):
+        maxpool.max_pool3s2(x[0])
+    a, b = _rnd(8, 256), _rnd(4, 256, seed=3)
+    c = mfma_gemm.gemm_nt(a, b, 8, 4, 1, 256, 256, 0, 256, 0)
+    torch.cuda.synchronize()
+    assert float((c - a @ b.t()).abs().max()) < 1e-3
+    with pytest.raises(RuntimeError):
+        mfma_gemm.gemm_nt(a.bfloat16(), b, 8, 4, 1, 256, 256, 0, 256, 0)
+    with pytest.raises(RuntimeError):
+        mfma_gemm.gemm_nt(a, b, 8, 4, 1, 250, 256, 0, 256, 0)
+    assert not mfma_gemm.nt_supported(a.bfloat16(), b, 256)
+    # partial sums: a bf16 part or parts with different strides take the tensor-op route and still give the sum
+    p0, p1 = _rnd(2, 4, 64), _rnd(2, 4, 64, seed=4)
+    ref = p0 + p1
+    for parts in ([p0, p1], [p0.bfloat16(), p1], [p0, p1.permute(1, 0, 2).contiguous().permute(1, 0, 2)]):
+        got = ss._sum_parts([t.clone() for t in parts], torch.float32)
+        torch.cuda.synchronize()
+        assert float((got.float() - ref).abs().max()) < 5e-2 if parts[0].dtype != torch.float32 else \
+            float((got - ref).abs().max()) < 1e-6
