@@ -196,6 +196,9 @@ typedef struct {
     void *dinput;        /* bwd: [batch, channels, height, width], in_dtype */
     float *dy;           /* bwd: [batch, taps, height, width] */
     int32_t in_dtype;    /* MMU_DTYPE_F32 (0, the default of a zeroed struct) or MMU_DTYPE_BF16 */
+    int32_t y_parts;     /* fwd: 0 / 1 = y is the row map; n > 1 = y holds n maps [n][batch, taps, height, width] whose
+                          * sum is the row map (mmu_mamba_small_fwd's state-range partials), summed in fixed order */
+    float *y_sum;        /* fwd, y_parts > 1: receives the summed map [batch, taps, height, width] (pass it as y to bwd) */
 } mmu_morph_params;
 
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
@@ -577,18 +580,21 @@ int mmu_coords_outproj_bwd(const mmu_coords_params *p, void *stream);
  *   requirements/mamba_simple.py:201-205,303-318,365 (in_proj, uni-directional branch, out_proj),
  *   mamba_ssm/ops/selective_scan_interface.py:173-215 (MambaInnerFn.forward) and :238-289,387-394 (backward),
  *   csrc/selective_scan/selective_scan_{fwd,bwd}_kernel.cuh, causal-conv1d/csrc/causal_conv1d_{fwd,bwd}.cu.
- * One workgroup per batch item; taps K in {1, 3}, inner width 2K, conv width 4, dt_rank 1, d_state <= 64, float32,
- * every tensor contiguous.
- *   fwd: offset [B, 2K, H, W] (only channels 0..K-1 are read) -> y [B, K, H, W] (row coordinates);
+ * `parts` workgroups per batch item, each scanning d_state / parts of the states (everything downstream of the scan is
+ * a sum over the states); taps K in {1, 3}, inner width 2K, conv width 4, dt_rank 1, d_state <= 64, float32, every
+ * tensor contiguous.
+ *   fwd: offset [B, 2K, H, W] (only channels 0..K-1 are read) -> y [parts][B, K, H, W]: partial row maps whose SUM is
+ *        the row coordinate map (mmu_morph_sample_fwd adds them while it reads them: mmu_morph_params.y_parts);
  *        hstate (optional, mmu_mamba_small_state_floats() floats) receives the scan state entering every lane's
  *        token group -- the backward needs it.
- *   bwd: dy [B, K, H, W], hstate -> doffset [B, 2K, H, W] (channels K..2K-1 = 0) and dweights
- *        (mmu_mamba_small_grad_floats() floats: in_proj [4K][K] | conv weight [2K][4] | conv bias [2K] |
+ *   bwd: dy [B, K, H, W] (gradient of the summed map), hstate -> doffset [B, 2K, H, W] (channels K..2K-1 = 0) and
+ *        dweights (mmu_mamba_small_grad_floats() floats: in_proj [4K][K] | conv weight [2K][4] | conv bias [2K] |
  *        x_proj [1+2N][2K] | dt_proj [2K] | dt bias [2K] | A [2K][N] | D [2K] | out_proj [K][2K] | altho);
- *        workspace: batch * mmu_mamba_small_grad_floats() floats (per-batch-item partials, summed in fixed order:
- *        deterministic, no atomics, nothing to zero). */
+ *        workspace: mmu_mamba_small_bwd_workspace_floats() floats (per-workgroup partials, summed in fixed order by a
+ *        second small kernel: deterministic, no atomics, nothing to zero). */
 typedef struct {
     int32_t batch, height, width, taps, dstate;
+    int32_t parts;                 /* state-range parts per batch item, divides dstate (mmu_mamba_small_parts()) */
     float extend_scope;
     const float *offset;
     const float *in_proj_weight;   /* [4K][K] */
@@ -610,6 +616,8 @@ typedef struct {
 } mmu_mamba_small_params;
 
 int mmu_mamba_small_supported(int taps, int height, int width, int dstate);
+int mmu_mamba_small_parts(int batch, int dstate);
+size_t mmu_mamba_small_bwd_workspace_floats(int batch, int taps, int height, int width, int dstate, int parts);
 int mmu_mamba_small_tokens_per_lane(int height, int width);
 size_t mmu_mamba_small_state_floats(int batch, int taps, int height, int width, int dstate);
 size_t mmu_mamba_small_grad_floats(int taps, int dstate);

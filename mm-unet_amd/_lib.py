@@ -68,7 +68,7 @@ class Conv1dUpdateParams(ctypes.Structure):
 class MorphParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "channels", "height", "width", "taps", "out_layout")]
                 + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")]
-                + [("in_dtype", _i32)])
+                + [("in_dtype", _i32), ("y_parts", _i32), ("y_sum", _vp)])
 
 
 class ResizeParams(ctypes.Structure):
@@ -168,7 +168,8 @@ class CoordsParams(ctypes.Structure):
 
 
 class MambaSmallParams(ctypes.Structure):
-    _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps", "dstate")] + [("extend_scope", ctypes.c_float)]
+    _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps", "dstate", "parts")]
+                + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "conv_weight", "conv_bias", "x_proj_weight",
                                       "dt_proj_weight", "dt_bias", "A", "D", "out_proj_weight", "altho", "y", "hstate",
                                       "dy", "doffset", "workspace", "dweights")])
@@ -187,7 +188,8 @@ EXPORTS = (
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
-    "mmu_mamba_small_supported", "mmu_mamba_small_tokens_per_lane", "mmu_mamba_small_state_floats",
+    "mmu_mamba_small_supported", "mmu_mamba_small_parts", "mmu_mamba_small_bwd_workspace_floats",
+    "mmu_mamba_small_tokens_per_lane", "mmu_mamba_small_state_floats",
     "mmu_mamba_small_grad_floats", "mmu_mamba_small_fwd", "mmu_mamba_small_bwd",
     "mmu_debug_wave_scan",
 )
@@ -263,6 +265,10 @@ def lib():
     L.mmu_norm_fused_workspace_floats.argtypes = [ctypes.c_int] * 3
     L.mmu_mamba_small_supported.restype = ctypes.c_int
     L.mmu_mamba_small_supported.argtypes = [ctypes.c_int] * 4
+    L.mmu_mamba_small_parts.restype = ctypes.c_int
+    L.mmu_mamba_small_parts.argtypes = [ctypes.c_int] * 2
+    L.mmu_mamba_small_bwd_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_mamba_small_bwd_workspace_floats.argtypes = [ctypes.c_int] * 6
     L.mmu_mamba_small_tokens_per_lane.restype = ctypes.c_int
     L.mmu_mamba_small_tokens_per_lane.argtypes = [ctypes.c_int] * 2
     L.mmu_mamba_small_state_floats.restype = ctypes.c_size_t

@@ -34,6 +34,9 @@ struct MorphArgs {
     long so_b, so_c, so_h, so_k;  // element strides of out / dout (unit stride along w)
     const void *in;         // [B, C, H, W], in_t (float or bf16_t: activations under autocast)
     const float *y;         // [B, K, H, W]  row coordinate in pixels (unclamped)
+    int y_parts;            // forward: y is the SUM of y_parts maps y + j * y_ps (mamba_small_fused's state-range partials)
+    long y_ps;
+    float *y_sum;           // forward, y_parts > 1: receives the summed map (what the backward kernels read)
     float *out;             // [B, C, H*K, W] or [C, K, B, H, W] (so_* strides)
     const float *dout;      // same layout as out
     void *din;              // [B, C, H, W], in_t
@@ -83,7 +86,12 @@ __global__ __launch_bounds__(256) void morph_sample_fwd_kernel(MorphArgs p) {
     int b, k, h, w, c0, c1;
     if (!decode(p, b, k, h, w, c0, c1)) return;
     const int HW = p.H * p.W;
-    const float yr = p.y[((long)(b * p.K + k) * p.H + h) * p.W + w];
+    const long yi = ((long)(b * p.K + k) * p.H + h) * p.W + w;
+    float yr = p.y[yi];
+    if (p.y_parts > 1) {   // the row map arrives as partial sums (fixed order: bit-reproducible); slice 0 keeps the total
+        for (int j = 1; j < p.y_parts; ++j) yr += p.y[yi + j * p.y_ps];
+        if (c0 == 0) p.y_sum[yi] = yr;
+    }
     const float yc = fminf(fmaxf(yr, 0.f), (float)(p.H - 1));
     const int y0 = (int)floorf(yc);
     const float wy = yc - (float)y0;
@@ -260,6 +268,10 @@ extern "C" int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream) {
     MorphArgs a = {};
     a.B = p->batch; a.C = p->channels; a.H = p->height; a.W = p->width; a.K = p->taps;
     a.in = p->input; a.y = p->y; a.out = p->out;
+    a.y_parts = p->y_parts > 1 ? p->y_parts : 1;
+    a.y_ps = (long)a.B * a.K * a.H * a.W;
+    a.y_sum = p->y_sum;
+    MMU_CHECK(a.y_parts == 1 || a.y_sum != nullptr, "morph_sample_fwd: y_sum is required when y comes in parts");
     set_out_strides(a, p->out_layout);
     const int positions = a.K * a.H * a.W;
     a.cs = channel_slices(a.B, a.C, positions);

@@ -77,12 +77,13 @@ class MambaSmallFusedFn(torch.autograd.Function):
         if altho.numel() != 1 or altho.dtype != torch.float32:
             raise RuntimeError("mamba_small_fused: altho must hold one float32 element")
         al = _c(altho.reshape(1))
-        y = torch.empty((B, K, H, W), device=offset.device, dtype=torch.float32)
+        parts = L.mmu_mamba_small_parts(B, N)
+        y = torch.empty((parts, B, K, H, W), device=offset.device, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad)
         hstate = (torch.empty(L.mmu_mamba_small_state_floats(B, K, H, W, N), device=offset.device, dtype=torch.float32)
                   if need_grad else None)
         p = _lib.MambaSmallParams()
-        p.batch, p.height, p.width, p.taps, p.dstate, p.extend_scope = B, H, W, K, N, float(scope)
+        p.batch, p.height, p.width, p.taps, p.dstate, p.parts, p.extend_scope = B, H, W, K, N, parts, float(scope)
         p.offset, p.in_proj_weight, p.conv_weight, p.conv_bias = offset.data_ptr(), w_in.data_ptr(), conv_w.data_ptr(), \
             _lib.ptr(conv_b)
         p.x_proj_weight, p.dt_proj_weight, p.dt_bias, p.A, p.D = w_x.data_ptr(), w_dt.data_ptr(), _lib.ptr(dt_bias), \
@@ -91,7 +92,7 @@ class MambaSmallFusedFn(torch.autograd.Function):
         with torch.cuda.device(offset.device):
             _lib.check(L.mmu_mamba_small_fwd(p, _lib.stream_of(offset)))
         ctx.save_for_backward(offset, w_in, conv_w, conv_b, w_x, w_dt, dt_bias, A, D, w_out, al, hstate)
-        ctx.scope = float(scope)
+        ctx.scope, ctx.parts = float(scope), parts
         ctx.altho_shape = altho.shape
         return y
 
@@ -102,15 +103,22 @@ class MambaSmallFusedFn(torch.autograd.Function):
         K = C2 // 2
         Dn, N = 2 * K, A.shape[1]
         L = _lib.lib()
-        g = _c(dy.float())
-        if tuple(g.shape) != (B, K, H, W):
-            raise RuntimeError(f"mamba_small_fused: gradient shape {tuple(g.shape)} != {(B, K, H, W)}")
+        parts = ctx.parts
+        if tuple(dy.shape) != (parts, B, K, H, W):
+            raise RuntimeError(f"mamba_small_fused: gradient shape {tuple(dy.shape)} != {(parts, B, K, H, W)}")
+        # every part's gradient is the gradient of the sum: the sampler hands back a stride-0 view of it (any other
+        # producer: the parts' gradients must agree, which a plain sum of the parts guarantees)
+        if parts > 1 and dy.stride(0) != 0:
+            raise RuntimeError("mamba_small_fused: the partial row maps may only be consumed through their sum "
+                               "(morph_sample / .sum(0)); got per-part gradients")
+        g = _c(dy[0].float())
         doff = torch.empty_like(offset)
         nv = L.mmu_mamba_small_grad_floats(K, N)
-        ws = torch.empty((B, nv), device=offset.device, dtype=torch.float32)
+        ws = torch.empty(L.mmu_mamba_small_bwd_workspace_floats(B, K, H, W, N, parts), device=offset.device,
+                         dtype=torch.float32)
         dw = torch.empty(nv, device=offset.device, dtype=torch.float32)
         p = _lib.MambaSmallParams()
-        p.batch, p.height, p.width, p.taps, p.dstate, p.extend_scope = B, H, W, K, N, ctx.scope
+        p.batch, p.height, p.width, p.taps, p.dstate, p.parts, p.extend_scope = B, H, W, K, N, parts, ctx.scope
         p.offset, p.in_proj_weight, p.conv_weight, p.conv_bias = offset.data_ptr(), w_in.data_ptr(), conv_w.data_ptr(), \
             _lib.ptr(conv_b)
         p.x_proj_weight, p.dt_proj_weight, p.dt_bias, p.A, p.D = w_x.data_ptr(), w_dt.data_ptr(), _lib.ptr(dt_bias), \
@@ -132,11 +140,16 @@ class MambaSmallFusedFn(torch.autograd.Function):
                 out["D"] if D is not None else None, out["w_out"], out["altho"], None)
 
 
-def mamba_rows(offset, mamba, altho, extend_scope, A=None):
+def mamba_rows(offset, mamba, altho, extend_scope, A=None, combine=True):
     """Row coordinates of MMConv's K taps through the fused kernels.  ``A``: ``-exp(A_log)`` when the caller has it
-    (``mamba_simple.neg_exp``: one batched launch for all blocks of a model), computed here otherwise."""
+    (``mamba_simple.neg_exp``: one batched launch for all blocks of a model), computed here otherwise.
+    ``combine=False`` returns the kernel's ``(parts, B, K, H, W)`` partial maps as they are -- ``morph_sample`` takes
+    them in that form and adds them up while it reads them; ``combine=True`` adds them here (one more launch)."""
     m = mamba
     if A is None:
         A = -torch.exp(m.A_log.float())
-    return MambaSmallFusedFn.apply(offset, m.in_proj.weight, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
-                                   m.dt_proj.weight, m.dt_proj.bias, A, m.D, m.out_proj.weight, altho, extend_scope)
+    y = MambaSmallFusedFn.apply(offset, m.in_proj.weight, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
+                                m.dt_proj.weight, m.dt_proj.bias, A, m.D, m.out_proj.weight, altho, extend_scope)
+    if not combine:
+        return y
+    return y[0] if y.shape[0] == 1 else y.sum(0)

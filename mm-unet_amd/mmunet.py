@@ -134,7 +134,7 @@ class MMConv(nn.Module):
         grid = torch.stack([xs, ys], dim=-1)  # (B, H*K, W, 2), last dim = (x, y)
         return F.grid_sample(input_feature, grid, mode=interpolate_mode, padding_mode="zeros", align_corners=True)
 
-    def _rows_fused(self, offset):
+    def _rows_fused(self, offset, combine=True):
         """get_coordinate_map_2D(rows_only=True) with the tensor glue in two HIP kernels
         (morph_coords): zig-zag + in_proj -> [conv1d, x_proj, dt_proj, selective scan: the uni-directional
         Mamba branch, mamba_simple.py:303-318] -> out_proj + inverse zig-zag + coordinate arithmetic."""
@@ -142,7 +142,8 @@ class MMConv(nn.Module):
         with torch.autocast("cuda", enabled=False):  # a 2K-channel fp32 scan; grid_sample is fp32 anyway
             if mamba_small_fused.supported(offset, self.kernel_size, m):
                 # small maps (16 x 16, 32 x 32): the whole chain below as ONE kernel each way
-                return mamba_small_fused.mamba_rows(offset, m, self.altho, self.extend_scope, A=neg_exp(m.A_log))
+                return mamba_small_fused.mamba_rows(offset, m, self.altho, self.extend_scope, A=neg_exp(m.A_log),
+                                                    combine=combine)
             xz = morph_coords.zigzag_inproj(offset, m.in_proj.weight)
             out_z = mamba_inner_fn_no_out_proj(xz, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
                                                m.dt_proj.weight, neg_exp(m.A_log), None, None,
@@ -177,7 +178,7 @@ class MMConv(nn.Module):
         # reference-shaped method and is what the fused op is tested against.
         if self.mamba.in_proj.bias is None and self.mamba.out_proj.bias is None and \
                 morph_coords.supported(offset, self.kernel_size):
-            y_rows = self._rows_fused(offset)
+            y_rows = self._rows_fused(offset, combine=False)   # (the sampler adds the fused kernel's partial maps)
         else:
             y_rows = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope, rows_only=True)
         if self.morph == 0:

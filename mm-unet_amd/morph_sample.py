@@ -27,12 +27,17 @@ class MorphSampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, y, tokens_last=False, slot=None):
         _lib.require_gpu(input, y)
-        if input.dim() != 4 or y.dim() != 4 or y.shape[0] != input.shape[0] or y.shape[2:] != input.shape[2:]:
-            raise RuntimeError("morph_sample: input must be (B, C, H, W) and y (B, K, H, W)")
-        if y.shape[1] % 2 != 1:
+        # y may come as (parts, B, K, H, W): partial row maps whose sum is the row map (mamba_small_fused); the kernel
+        # adds them up while it reads them and keeps the total for the backward
+        parts = y.shape[0] if y.dim() == 5 else 0
+        ys = y.shape[1:] if parts else y.shape
+        if input.dim() != 4 or len(ys) != 4 or ys[0] != input.shape[0] or ys[2:] != input.shape[2:]:
+            raise RuntimeError("morph_sample: input must be (B, C, H, W) and y (B, K, H, W) [or (parts, B, K, H, W)]")
+        if ys[1] % 2 != 1:
             raise RuntimeError("morph_sample: the number of taps K must be odd")
         x = (input if input.dtype in (torch.float32, torch.bfloat16) else input.float()).contiguous()
-        yy = y.float().contiguous()
+        yin = y.float().contiguous()
+        yy = torch.empty(tuple(ys), device=yin.device, dtype=torch.float32) if parts > 1 else (yin[0] if parts else yin)
         B, C, H, W = x.shape
         K = yy.shape[1]
         shape = (C * K, B * H * W) if tokens_last else (B, C, H * K, W)
@@ -40,11 +45,14 @@ class MorphSampleFn(torch.autograd.Function):
         p = _lib.MorphParams()
         p.batch, p.channels, p.height, p.width, p.taps = B, C, H, W, K
         p.out_layout = int(tokens_last)
-        p.input, p.y, p.out = x.data_ptr(), yy.data_ptr(), out.data_ptr()
+        p.input, p.y, p.out = x.data_ptr(), yin.data_ptr(), out.data_ptr()
+        if parts > 1:
+            p.y_parts, p.y_sum = parts, yy.data_ptr()
         p.in_dtype = _lib.dtype_code(x)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_morph_sample_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, yy)
+        ctx.parts = parts
         ctx.in_dtype, ctx.y_dtype, ctx.tokens_last = input.dtype, y.dtype, bool(tokens_last)
         ctx.slot = slot
         return out
@@ -72,7 +80,10 @@ class MorphSampleFn(torch.autograd.Function):
         if slot is not None and slot.armed and ctx.needs_input_grad[1] and slot.grad is None and x.dtype == ctx.in_dtype:
             slot.grad = dinput
             dinput = None
-        return dinput, dy.to(ctx.y_dtype), None, None
+        dy = dy.to(ctx.y_dtype)
+        if ctx.parts:   # every partial map receives the gradient of their sum: a stride-0 view, nothing is copied
+            dy = dy.unsqueeze(0).expand(ctx.parts, *dy.shape)
+        return dinput, dy, None, None
 
 
 def morph_sample(input, y, tokens_last=False, slot=None):
