@@ -573,21 +573,20 @@ int mmu_coords_outproj_fwd(const mmu_coords_params *p, void *stream);
 int mmu_coords_outproj_bwd(const mmu_coords_params *p, void *stream);
 
 /* ---- the whole K-channel Mamba chain of an MMConv block on a small map, one kernel each way (rows f1 + f2) ---- */
-/* Replaces, for height * width = 64 T nw tokens (T in {1, 2, 4} tokens per lane, nw <= 8 waves: 64 .. 2,048 tokens,
- * MM-UNet's 16 x 16 and 32 x 32 maps), the six forward launches zigzag_inproj -> mamba_pre_small -> selective scan
- * (3 kernels) -> coords_outproj and their eleven backward launches:
+/* Replaces, for power-of-two maps of 64 .. 1,024 tokens (MM-UNet's 16 x 16 and 32 x 32 maps), the six forward
+ * launches zigzag_inproj -> mamba_pre_small -> selective scan (3 kernels) -> coords_outproj and their eleven backward
+ * launches:
  *   src/UM_Net/MMUNet.py:176-188 (zig-zag flatten, self.mamba, inverse zig-zag, coordinate arithmetic),
  *   requirements/mamba_simple.py:201-205,303-318,365 (in_proj, uni-directional branch, out_proj),
  *   mamba_ssm/ops/selective_scan_interface.py:173-215 (MambaInnerFn.forward) and :238-289,387-394 (backward),
  *   csrc/selective_scan/selective_scan_{fwd,bwd}_kernel.cuh, causal-conv1d/csrc/causal_conv1d_{fwd,bwd}.cu.
  * `parts` workgroups per batch item, each scanning d_state / parts of the states (everything downstream of the scan is
- * a sum over the states); taps K in {1, 3}, inner width 2K, conv width 4, dt_rank 1, d_state <= 64, float32, every
- * tensor contiguous.
+ * a sum over the states); inside a workgroup a wave owns a channel, a lane a run of L / 64 tokens.  taps K in {1, 3},
+ * inner width 2K, conv width 4, dt_rank 1, d_state <= 64, float32, every tensor contiguous.
  *   fwd: offset [B, 2K, H, W] (only channels 0..K-1 are read) -> y [parts][B, K, H, W]: partial row maps whose SUM is
- *        the row coordinate map (mmu_morph_sample_fwd adds them while it reads them: mmu_morph_params.y_parts);
- *        hstate (optional, mmu_mamba_small_state_floats() floats) receives the scan state entering every lane's
- *        token group -- the backward needs it.
- *   bwd: dy [B, K, H, W] (gradient of the summed map), hstate -> doffset [B, 2K, H, W] (channels K..2K-1 = 0) and
+ *        the row coordinate map (mmu_morph_sample_fwd adds them while it reads them: mmu_morph_params.y_parts).
+ *        Nothing is saved for the backward (it recomputes the states by the same scan).
+ *   bwd: dy [B, K, H, W] (gradient of the summed map) -> doffset [B, 2K, H, W] (channels K..2K-1 = 0) and
  *        dweights (mmu_mamba_small_grad_floats() floats: in_proj [4K][K] | conv weight [2K][4] | conv bias [2K] |
  *        x_proj [1+2N][2K] | dt_proj [2K] | dt bias [2K] | A [2K][N] | D [2K] | out_proj [K][2K] | altho);
  *        workspace: mmu_mamba_small_bwd_workspace_floats() floats (per-workgroup partials, summed in fixed order by a
@@ -608,7 +607,6 @@ typedef struct {
     const float *out_proj_weight;  /* [K][2K] */
     const float *altho;            /* scalar */
     float *y;
-    float *hstate;
     const float *dy;
     float *doffset;
     float *workspace;
@@ -616,10 +614,8 @@ typedef struct {
 } mmu_mamba_small_params;
 
 int mmu_mamba_small_supported(int taps, int height, int width, int dstate);
-int mmu_mamba_small_parts(int batch, int dstate);
+int mmu_mamba_small_parts(int batch, int taps, int height, int width, int dstate);
 size_t mmu_mamba_small_bwd_workspace_floats(int batch, int taps, int height, int width, int dstate, int parts);
-int mmu_mamba_small_tokens_per_lane(int height, int width);
-size_t mmu_mamba_small_state_floats(int batch, int taps, int height, int width, int dstate);
 size_t mmu_mamba_small_grad_floats(int taps, int dstate);
 int mmu_mamba_small_fwd(const mmu_mamba_small_params *p, void *stream);
 int mmu_mamba_small_bwd(const mmu_mamba_small_params *p, void *stream);

@@ -171,7 +171,7 @@ class MambaSmallParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps", "dstate", "parts")]
                 + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "conv_weight", "conv_bias", "x_proj_weight",
-                                      "dt_proj_weight", "dt_bias", "A", "D", "out_proj_weight", "altho", "y", "hstate",
+                                      "dt_proj_weight", "dt_bias", "A", "D", "out_proj_weight", "altho", "y",
                                       "dy", "doffset", "workspace", "dweights")])
 
 
@@ -189,7 +189,6 @@ EXPORTS = (
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_mamba_small_supported", "mmu_mamba_small_parts", "mmu_mamba_small_bwd_workspace_floats",
-    "mmu_mamba_small_tokens_per_lane", "mmu_mamba_small_state_floats",
     "mmu_mamba_small_grad_floats", "mmu_mamba_small_fwd", "mmu_mamba_small_bwd",
     "mmu_debug_wave_scan",
 )
@@ -266,13 +265,9 @@ def lib():
     L.mmu_mamba_small_supported.restype = ctypes.c_int
     L.mmu_mamba_small_supported.argtypes = [ctypes.c_int] * 4
     L.mmu_mamba_small_parts.restype = ctypes.c_int
-    L.mmu_mamba_small_parts.argtypes = [ctypes.c_int] * 2
+    L.mmu_mamba_small_parts.argtypes = [ctypes.c_int] * 5
     L.mmu_mamba_small_bwd_workspace_floats.restype = ctypes.c_size_t
     L.mmu_mamba_small_bwd_workspace_floats.argtypes = [ctypes.c_int] * 6
-    L.mmu_mamba_small_tokens_per_lane.restype = ctypes.c_int
-    L.mmu_mamba_small_tokens_per_lane.argtypes = [ctypes.c_int] * 2
-    L.mmu_mamba_small_state_floats.restype = ctypes.c_size_t
-    L.mmu_mamba_small_state_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_mamba_small_grad_floats.restype = ctypes.c_size_t
     L.mmu_mamba_small_grad_floats.argtypes = [ctypes.c_int] * 2
     L.mmu_debug_wave_scan.restype = ctypes.c_int

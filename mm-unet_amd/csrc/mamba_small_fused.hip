@@ -11,27 +11,25 @@
 // 24 of MM-UNet's 38 three-tap blocks (and two of the three one-tap blocks) run on 16 x 16 or 32 x 32 maps: L = 256 or
 // 1,024 tokens, 6 channels, 16 states.  As separate kernels (zigzag_inproj, mamba_pre_small, chunk_reduce8, chunk_carry,
 // chunk_apply_fwd8, coords_outproj forward; eleven launches backward) every one of them is 1-8 workgroups at the
-// 4.6 us dependent-node floor of a replayed graph: ~44 us forward and ~90 us backward per block for microseconds of
-// arithmetic ("What's weak" 7).
+// dependent-node floor of a replayed graph ("What's weak" 7).
 //
-// Here ONE workgroup owns ONE batch item (a scan has no parallelism across its tokens that is worth a second
-// workgroup at L <= 2,048: the cross-workgroup hand-off costs more than the work).  A lane owns T consecutive
-// zig-zag tokens, a wave 64 T of them, nw = L / (64 T) <= 8 waves the whole sequence; everything between the offset map
-// and the row coordinates stays in registers:
-//   * stage y_off in zig-zag order in LDS (coalesced reads along the rows); in_proj, conv1d (+3 halo tokens from LDS),
-//     SiLU, the dt row of x_proj, dt_proj + softplus per lane;
-//   * scan: for every state n the B_n / C_n rows are formed from u on the fly (12 FMAs per token: they never exist as
-//     tensors), for every channel pair the lane composes its T tokens, wave_scan_affine_x2 (DPP) scans the 64 lanes,
-//     and the carry between WAVES travels through LDS as a systolic chain: wave w spins on a progress word of wave
-//     w - 1, adds its own aggregate and publishes -- no workgroup barrier inside the 96 (channel, state) steps, a wave
-//     lags its predecessor by one LDS round trip in total, not per step;
-//   * gate, out_proj, inverse zig-zag and the coordinate arithmetic in the epilogue.
-// Forward saves the state entering every lane's token group (`hstate`, [B][2K N][L / T]); the backward kernel maps its
-// lanes to the token groups in REVERSE order, so the adjoint recurrence g_t = C_t dy_t + a_{t+1} g_{t+1} is again a
-// forward scan over lanes and waves (same DPP scan, same systolic chain), recomputes h from `hstate`, and carries the
-// chain rule through x_proj / dt_proj / conv1d (neighbour tokens through LDS) / in_proj / the coordinate terms to
-// d offset.  Weight gradients: lane sums -> wave_sum4 -> per-wave LDS slots -> one partial vector per batch item;
-// mamba_small_reduce_kernel adds the batch items in fixed order (deterministic, no atomics, no zero fill).
+// Decomposition (the third one built; the first two are in HISTORY.md):
+//   * grid (batch, parts): a workgroup owns one batch item and a RANGE OF STATES n.  Everything behind the scan is a
+//     sum over n (y, and in the backward du / d delta / dz / every weight gradient), so the parts' results are partial
+//     sums that are added downstream: the sampler adds the partial row maps while it reads them
+//     (mmu_morph_params.y_parts), mamba_small_reduce_kernel adds the partial gradients in fixed order.  One workgroup per
+//     batch item kept 8 of 256 CUs busy and was bound by the instruction issue of that one CU.
+//   * inside a workgroup a WAVE owns a CHANNEL and a lane a contiguous run of TL = L / 64 tokens (<= 16).  A channel's
+//     scan then never leaves its wave: the lane composes its TL tokens, one DPP scan over the 64 lanes (two states
+//     interleaved), done -- no carry between waves, no barrier in the forward state loop, and the scan's fixed cost is
+//     spread over TL tokens.  (Lanes = token groups of ALL channels with a chain of carries between the waves: 33
+//     lane-instructions per (token, channel, state), 570 cycles per hop; this form: ~7.)
+//   * what crosses channels goes through LDS tables between workgroup barriers: u -> (dt, B_n, C_n) by all threads,
+//     out_z -> out_proj + coordinates by all threads; backward: per-channel dB_n / dC_n -> their sums, d dt, d xz ->
+//     d y_off.  A wave owns its channel's rows of every weight gradient: 18 + 3 per state wave sums instead of 110.
+//   * the backward recomputes h by the same lane scan (nothing is saved by the forward) and runs the adjoint
+//     recurrence g_t = C_t dy_t + a_{t+1} g_{t+1} as a scan over the lanes in reverse order (wave_reverse + the same DPP
+//     scan, interleaved with the forward one).
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
 
@@ -51,67 +49,50 @@ __device__ unsigned long long g_small_stamps[2 * 8 * 16];   // [fwd / bwd][wave]
 namespace {
 
 struct SmallArgs {
-    int B, H, W, L, N, nw;
+    int B, H, W, lw, N;  // lw = log2(W): H and W are powers of two (H * W = 64 * TL is one), no integer division anywhere
     int ns, npp;         // state-range parts per batch item (grid.y) and states per part (N = ns * npp)
     float scope;
     const float *off;    // [B, 2K, H, W]
-    const float *win;    // [4K][K]
-    const float *cw;     // [2K][4]
-    const float *cb;     // [2K] or null
-    const float *wx;     // [1 + 2N][2K]
-    const float *wdt;    // [2K]
-    const float *dtb;    // [2K] or null
-    const float *A;      // [2K][N]  (= -exp(A_log))
-    const float *Dp;     // [2K] or null
-    const float *wout;   // [K][2K]
-    const float *altho;  // scalar
     float *y;            // [ns][B, K, H, W]  partial row maps (their sum is the row map)
-    float *hstate;       // [B][2K*N][L/T] or null (forward: written; backward: read)
     const float *dy;     // [B, K, H, W]
     float *doff;         // [ns][B][K][H*W]  partial d offset (first K channels), pixel order
     float *part;         // [B * ns][NV] weight-gradient partials
 };
 
 // The weights are separate __restrict__ kernel parameters, not members of SmallArgs: only then can the compiler prove
-// that the kernel's own stores (hstate, y, d offset) do not clobber them and read them with scalar loads into SGPRs
-// (as struct members they became per-lane global_load_dword in the scan loop, each behind the stores' vmcnt).
+// that the kernel's own stores do not clobber them and read them with scalar loads into SGPRs (as struct members they
+// became per-lane global_load_dword in the middle of the kernel, each behind the stores' vmcnt).
 #define W_PARAMS                                                                                                      \
     const float *__restrict__ win, const float *__restrict__ cw, const float *__restrict__ cb,                       \
         const float *__restrict__ wx, const float *__restrict__ wdt, const float *__restrict__ dtb,                  \
         const float *__restrict__ Aw, const float *__restrict__ Dw, const float *__restrict__ wout,                  \
         const float *__restrict__ altho
-#define W_ARGS win, cw, cb, wx, wdt, dtb, Aw, Dw, wout, altho
 
-__device__ __forceinline__ int zig_of(int h, int w, int H, int W) {
+// zig-zag token of pixel (h, w) and back; W = 1 << lw
+__device__ __forceinline__ int zig_of(int h, int w, int H, int lw) {
     const int He = H & ~1;
-    return h < He ? (h >> 1) * (2 * W) + 2 * w + (h & 1) : He * W + w;
+    return h < He ? ((h >> 1) << (lw + 1)) + 2 * w + (h & 1) : (He << lw) + w;
 }
-__device__ __forceinline__ void unzig(int l, int H, int W, int &h, int &w) {
+__device__ __forceinline__ void unzig(int l, int H, int lw, int &h, int &w) {
     const int He = H & ~1;
-    if (l < He * W) {
-        const int p = l / (2 * W), r = l - p * 2 * W;
+    if (l < (He << lw)) {
+        const int p = l >> (lw + 1), r = l & ((2 << lw) - 1);
         h = 2 * p + (r & 1);
         w = r >> 1;
     } else {
         h = He;
-        w = l - He * W;
+        w = l - (He << lw);
     }
 }
 
+// max(softplus(altho), .01) and its derivative (MMUNet.py:186); hardware exp2 / log2 (softplus_thr)
 __device__ __forceinline__ float coord_weight(float altho, float &dwgt_daltho) {
-    const float sp = altho <= 20.f ? log1pf(expf(altho)) : altho;  // F.softplus (threshold 20)
-    const float sg = 1.f / (1.f + expf(-altho));
-    dwgt_daltho = sp >= 0.01f ? (altho <= 20.f ? sg : 1.f) : 0.f;  // d max(softplus, 0.01) / d altho
+    const float sp = softplus_thr(altho);
+    dwgt_daltho = sp >= 0.01f ? (altho <= 20.f ? sigmoidf_(altho) : 1.f) : 0.f;
     return fmaxf(sp, 0.01f);
 }
 
-typedef float v2f_ __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float readlane63(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// layout of the weight-gradient vector (one per batch item, then summed): offsets in floats
+// layout of the weight-gradient vector (one per workgroup, then summed): offsets in floats
 template <int K>
 struct GradLayout {
     static constexpr int D = 2 * K;
@@ -132,289 +113,277 @@ struct GradLayout {
     }
 };
 
-// ---- what both directions share: y_off in zig-zag order into LDS ------------------------------------------------
-// K L = K T blockDim values: exactly K T per thread, all loads issued before the first LDS store (a loop with a
-// runtime trip count waited for every load in turn: 2 us of the first version's 7).
-template <int K, int T>
-__device__ __forceinline__ void stage_yoff(const SmallArgs &p, int b, float *yoff) {
-    const int L = p.L;
-    const float *ob = p.off + (long)b * 2 * K * L;   // the first K channels of the batch item are contiguous
-    float v[K * T];
+// ---- a lane's run of TL consecutive tokens of an LDS row, as 16-byte accesses where TL allows (the dynamic LDS base is
+// declared 16-byte aligned and every table offset is a multiple of 4 floats).  Lane stride = TL floats: scalar accesses
+// would hit 64 / TL distinct banks only (16-way conflicts at TL = 16); the 16-byte form is 4-way at worst.
+template <int TL>
+__device__ __forceinline__ void run_load(const float *q, float (&v)[TL]) {
+    if constexpr (TL % 4 == 0) {
 #pragma unroll
-    for (int it = 0; it < K * T; ++it) v[it] = ob[it * blockDim.x + threadIdx.x];
+        for (int i = 0; i < TL; i += 4) {
+            const float4 f = *reinterpret_cast<const float4 *>(q + i);
+            v[i] = f.x; v[i + 1] = f.y; v[i + 2] = f.z; v[i + 3] = f.w;
+        }
+    } else if constexpr (TL == 2) {
+        const float2 f = *reinterpret_cast<const float2 *>(q);
+        v[0] = f.x; v[1] = f.y;
+    } else {
+        v[0] = q[0];
+    }
+}
+template <int TL>
+__device__ __forceinline__ void run_store(float *q, const float (&v)[TL]) {
+    if constexpr (TL % 4 == 0) {
 #pragma unroll
-    for (int it = 0; it < K * T; ++it) {
-        const int idx = it * blockDim.x + threadIdx.x;
-        const int k = idx / L, r = idx - k * L;
-        const int h = r / p.W, ww = r - h * p.W;
-        yoff[k * L + zig_of(h, ww, p.H, p.W)] = v[it];
+        for (int i = 0; i < TL; i += 4) *reinterpret_cast<float4 *>(q + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    } else if constexpr (TL == 2) {
+        *reinterpret_cast<float2 *>(q) = make_float2(v[0], v[1]);
+    } else {
+        q[0] = v[0];
     }
 }
 
-// in_proj, conv1d + SiLU, dt row, dt_proj + softplus for the T tokens l0 .. l0 + T - 1 of this lane
-template <int K, int T, bool KEEP_PRE>
-__device__ __forceinline__ void pre_phase(const SmallArgs &p, W_PARAMS, const float *yoff, int l0, float (&xs)[2 * K][T + 3],
-                                          float (&z)[2 * K][T], float (&pp)[2 * K][T], float (&u)[2 * K][T],
-                                          float (&dl)[2 * K][T], float (&dt)[T]) {
-    constexpr int D = 2 * K;
-    const int L = p.L;
+// ---- LDS staging: a [K][H][W] map of one batch item in zig-zag token order, all loads in flight before the first store
+template <int K, int TL>
+__device__ __forceinline__ void stage_zig(const SmallArgs &p, const float *__restrict__ src, float *dst) {
+    constexpr int NT = 128 * K;                    // threads: 64 per channel, 2K channels
+    constexpr int IT = (K * 64 * TL + NT - 1) / NT;  // values per thread
+    constexpr int L = 64 * TL;
+    float v[IT];
 #pragma unroll
-    for (int j = 0; j < T + 3; ++j) {
-        const int l = l0 - 3 + j;
-        float yo[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) yo[k] = l >= 0 ? yoff[k * L + l] : 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < K; ++k) a = fmaf(win[d * K + k], yo[k], a);
-            xs[d][j] = a;
-            if (j >= 3) {
-                float c = 0.f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) c = fmaf(win[(D + d) * K + k], yo[k], c);
-                z[d][j - 3] = c;
-            }
-        }
+    for (int it = 0; it < IT; ++it) {
+        const int idx = it * NT + threadIdx.x;
+        v[it] = idx < K * L ? src[idx] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < T; ++i) dt[i] = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float bv = cb ? cb[d] : 0.f;
-        const float w0 = wx[d];
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            float acc = bv;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc = fmaf(cw[d * 4 + m], xs[d][i + m], acc);
-            if (KEEP_PRE) pp[d][i] = acc;
-            u[d][i] = acc * sigmoidf_(acc);
-            dt[i] = fmaf(w0, u[d][i], dt[i]);
+    for (int it = 0; it < IT; ++it) {
+        const int idx = it * NT + threadIdx.x;
+        if (idx < K * L) {
+            const int k = idx / L, r = idx & (L - 1);
+            const int h = r >> p.lw, ww = r & (p.W - 1);
+            dst[k * L + zig_of(h, ww, p.H, p.lw)] = v[it];
         }
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float wv = wdt[d], bv = dtb ? dtb[d] : 0.f;
-#pragma unroll
-        for (int i = 0; i < T; ++i) dl[d][i] = softplus_thr(fmaf(wv, dt[i], bv));
     }
 }
 
-// ---- the carry between waves ----------------------------------------------------------------------------------------
-// Per state n every wave publishes ONE record: the scan state at its end for all D channels, then a progress word
-// (the number of records it has published).  Wave w reads the progress word and the record of wave w - 1 in one LDS
-// round trip (LDS operations of a wave execute in order: a record read behind a progress word that already says
-// "published" is the published record), combines and publishes its own without waiting for the writes.
-// Explicit ds_ instructions on LDS byte addresses: through `volatile` generic pointers the compiler emitted
-// flat_load / flat_store ... sc0 sc1 with s_waitcnt vmcnt(0) each -- every step then waited for every global store
-// issued before it (first version, a record per channel pair: 39 us forward, 86 us backward for a 32 x 32 map).
-// The compiler's waitcnt pass does not see memory operations inside inline asm: each asm waits for its own results.
-typedef float v4f_ __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned lds_addr(const void *q) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)q;
-}
-template <int D>
-struct CarryRec {
-    static constexpr int CS = 2 * D;   // floats per record: P[D] | S[D]   (12 or 4: 16-byte multiples)
-};
 #define MMU_COMPILER_FENCE() asm volatile("" ::: "memory")
 
-// in[d] = state entering wave w (0 for wave 0).  Every wave publishes its OWN aggregate (P, S) -- known right after
-// its lane scan, independent of what enters it -- and composes the aggregates of the waves before it itself: the
-// carry costs one LDS round trip, not a chain of nw - 1 (the chained form, where wave w published P in + S and wave
-// w + 1 waited for it, measured 570 cycles per hop: with two states per workgroup the last wave idled 4,000 cycles).
-template <int D>
-__device__ __forceinline__ void carry_all(float *hcar, int *prog, int w, int nw, int npp, int nn, const float (&Pt)[D],
-                                          const float (&St)[D], float (&in)[D]) {
-    constexpr int CS = CarryRec<D>::CS;
-    if (w + 1 < nw && (threadIdx.x & 63) == 0) {
-        float *rec = hcar + (w * npp + nn) * CS;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            rec[d] = Pt[d];
-            rec[D + d] = St[d];
-        }
-        MMU_COMPILER_FENCE();      // (the LDS executes one wave's operations in order: data, then the progress word)
-        prog[w] = nn + 1;
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) in[d] = 0.f;
-    if (w > 0) {
-        for (;;) {
-            MMU_COMPILER_FENCE();
-            int ok = 1;
-#pragma unroll
-            for (int v = 0; v < 7; ++v)
-                if (v < w) ok &= __builtin_amdgcn_readfirstlane(prog[v]) > nn;
-            if (ok) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        MMU_COMPILER_FENCE();
-#pragma unroll
-        for (int v = 0; v < 7; ++v) {
-            if (v < w) {
-                const float *rec = hcar + (v * npp + nn) * CS;
-#pragma unroll
-                for (int d = 0; d < D; ++d) in[d] = fmaf(rec[d], in[d], rec[D + d]);
-            }
-        }
-    }
-}
-
-// Inclusive affine scans over the 64 lanes for all D channels at once: the D independent chains are interleaved, so
-// every DPP read is >= D instructions behind the write of the register it reads (no s_nop, no dependent-issue stalls:
-// two chains at a time left a single wave per SIMD waiting on every second instruction).
-#define MMU_SCAN6_STEP(ctrl, mask)                                                              \
-    "v_fmac_f32_dpp %1, %1, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
-    "v_fmac_f32_dpp %3, %3, %2 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
-    "v_fmac_f32_dpp %5, %5, %4 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
-    "v_fmac_f32_dpp %7, %7, %6 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
-    "v_fmac_f32_dpp %9, %9, %8 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
-    "v_fmac_f32_dpp %11, %11, %10 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                 \
-    "v_mul_f32_dpp %0, %0, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                     \
-    "v_mul_f32_dpp %2, %2, %2 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                     \
-    "v_mul_f32_dpp %4, %4, %4 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                     \
-    "v_mul_f32_dpp %6, %6, %6 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                     \
-    "v_mul_f32_dpp %8, %8, %8 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                     \
-    "v_mul_f32_dpp %10, %10, %10 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"
-
-template <int D>
-__device__ __forceinline__ void wave_scan_affine_all(float (&P)[D], float (&S)[D]) {
-    if constexpr (D == 6) {
-        asm volatile("s_nop 1\n\t"
-                     MMU_SCAN6_STEP("row_shr:1", "0xf")
-                     MMU_SCAN6_STEP("row_shr:2", "0xf")
-                     MMU_SCAN6_STEP("row_shr:4", "0xf")
-                     MMU_SCAN6_STEP("row_shr:8", "0xf")
-                     MMU_SCAN6_STEP("row_bcast:15", "0xa")
-                     MMU_SCAN6_STEP("row_bcast:31", "0xc")
-                     "s_nop 1"
-                     : "+v"(P[0]), "+v"(S[0]), "+v"(P[1]), "+v"(S[1]), "+v"(P[2]), "+v"(S[2]), "+v"(P[3]), "+v"(S[3]),
-                       "+v"(P[4]), "+v"(S[4]), "+v"(P[5]), "+v"(S[5]));
-    } else {
-        wave_scan_affine_x2(P[0], S[0], P[1], S[1]);
-    }
-}
-
-// per-state scalars in LDS: record n = wb[D] (x_proj row 1 + n) | wc[D] (row 1 + N + n) | A[.][n] | padding
+// per-state scalars in LDS: record nn = wb[D] (x_proj row 1 + n) | wc[D] (row 1 + N + n) | A[.][n] | padding
 template <int D>
 struct WRec {
     static constexpr int RS = (3 * D + 3) & ~3;
 };
 template <int D>
-__device__ __forceinline__ void stage_wl(float *wl, const float *__restrict__ wx, const float *__restrict__ Aw, int N) {
+__device__ __forceinline__ void stage_wl(float *wl, const float *__restrict__ wx, const float *__restrict__ Aw, int N,
+                                         int n0, int npp) {
     constexpr int RS = WRec<D>::RS;
-    for (int idx = threadIdx.x; idx < N * 3 * D; idx += blockDim.x) {
-        const int n = idx / (3 * D), r = idx - n * 3 * D;
-        wl[n * RS + r] = r < D ? wx[(1 + n) * D + r] : r < 2 * D ? wx[(1 + N + n) * D + r - D] : Aw[(r - 2 * D) * N + n];
+    for (int idx = threadIdx.x; idx < npp * 3 * D; idx += blockDim.x) {
+        const int nn = idx / (3 * D), r = idx - nn * 3 * D, n = n0 + nn;
+        wl[nn * RS + r] = r < D ? wx[(1 + n) * D + r] : r < 2 * D ? wx[(1 + N + n) * D + r - D] : Aw[(r - 2 * D) * N + n];
+    }
+}
+
+// The wave's scalars (its channel's rows of the small weights), read at kernel entry: one batch of scalar loads whose
+// latency (~1 us from a cold scalar cache) overlaps the staging loads instead of stalling each phase at first use.
+template <int K>
+struct ChanW {
+    float wi[K], wz[K];        // in_proj rows d and 2K + d
+    float c0, c1, c2, c3, cb;  // conv1d taps and bias
+    float w0[2 * K];           // x_proj row 0 (the dt row), all channels
+    float wdt, dtb, Dv;        // dt_proj, its bias, D
+    float wo[K];               // out_proj column d
+    float altho;
+};
+template <int K>
+__device__ __forceinline__ ChanW<K> load_chan(int d, bool first, W_PARAMS) {
+    constexpr int D = 2 * K;
+    ChanW<K> c;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        c.wi[k] = win[d * K + k];
+        c.wz[k] = win[(D + d) * K + k];
+        c.wo[k] = wout[k * D + d];
+    }
+    c.c0 = cw[d * 4]; c.c1 = cw[d * 4 + 1]; c.c2 = cw[d * 4 + 2]; c.c3 = cw[d * 4 + 3];
+    c.cb = cb ? cb[d] : 0.f;
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) c.w0[dd] = wx[dd];
+    c.wdt = wdt[d];
+    c.dtb = dtb ? dtb[d] : 0.f;
+    c.Dv = (Dw && first) ? Dw[d] : 0.f;
+    c.altho = altho[0];
+    (void)Aw;
+    return c;
+}
+#define W_ARGS win, cw, cb, wx, wdt, dtb, Aw, Dw, wout, altho
+
+// own channel d of wave: in_proj (x and z rows), conv1d (width 4, halo from the tokens before the lane's run), SiLU
+template <int K, int TL>
+__device__ __forceinline__ void pre_channel(const ChanW<K> &cwv, const float *yoff, int L, int l0,
+                                            float (&x)[TL + 3], float (&z)[TL], float (&pp)[TL], float (&u)[TL]) {
+    const float (&wi)[K] = cwv.wi;
+    const float (&wz)[K] = cwv.wz;
+    // y_off of the tokens l0 - 3 .. l0 + TL - 1: the lane's own run plus the three before it (the previous lane's tail)
+    float yo[K][TL + 3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float own[TL];
+        run_load<TL>(yoff + k * L + l0, own);
+#pragma unroll
+        for (int i = 0; i < TL; ++i) yo[k][3 + i] = own[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) yo[k][j] = l0 - 3 + j >= 0 ? yoff[k * L + l0 - 3 + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TL + 3; ++j) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            a = fmaf(wi[k], yo[k][j], a);
+            c = fmaf(wz[k], yo[k][j], c);
+        }
+        x[j] = a;
+        if (j >= 3) z[j - 3] = c;
+    }
+    const float bv = cwv.cb, c0 = cwv.c0, c1 = cwv.c1, c2 = cwv.c2, c3 = cwv.c3;
+#pragma unroll
+    for (int i = 0; i < TL; ++i) {
+        const float acc = fmaf(c3, x[i + 3], fmaf(c2, x[i + 2], fmaf(c1, x[i + 1], fmaf(c0, x[i], bv))));
+        pp[i] = acc;
+        u[i] = acc * sigmoidf_(acc);
+    }
+}
+
+// dt row and the B_n / C_n rows of a state from the u table, by all threads (token l per thread and step)
+template <int D>
+__device__ __forceinline__ void coop_dt(const float *ut, float *dtt, const float (&w0)[D], int L) {
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s = fmaf(w0[d], ut[d * L + l], s);
+        dtt[l] = s;
+    }
+}
+template <int D>
+__device__ __forceinline__ void coop_bc(const float *ut, float *bc /* [2][L] */, const float *wr, int L) {
+    float wb[D], wc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        wb[d] = wr[d];
+        wc[d] = wr[D + d];
+    }
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        float sb = 0.f, sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float uu = ut[d * L + l];
+            sb = fmaf(wb[d], uu, sb);
+            sc = fmaf(wc[d], uu, sc);
+        }
+        bc[l] = sb;
+        bc[L + l] = sc;
     }
 }
 
 // ================================================================================================================
 // forward
 // ================================================================================================================
-template <int K, int T>
-__global__ __launch_bounds__(512) void mamba_small_fwd_kernel(SmallArgs p, W_PARAMS) {
-    constexpr int D = 2 * K;
-    extern __shared__ float smem[];
-    const int L = p.L, N = p.N, DN = D * N, G = L / T;
-    constexpr int RS = WRec<D>::RS, CS = CarryRec<D>::CS;
-    float *yoff = smem;                                         // [K][L]
-    float *wl = yoff + K * L;                                   // [N][RS]   per-state scalars
-    float *hcar = wl + N * RS;                                  // [nw][npp][CS]
-    int *prog = (int *)(hcar + p.nw * p.npp * CS);              // [nw]
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+template <int K, int TL>
+__global__ __launch_bounds__(128 * K) void mamba_small_fwd_kernel(SmallArgs p, W_PARAMS) {
+    constexpr int D = 2 * K, RS = WRec<D>::RS;
+    extern __shared__ __align__(16) float smem[];
+    constexpr int L = 64 * TL;
+    const int N = p.N, npp = p.npp;
+    float *yoff = smem;              // [K][L]      y_off, zig-zag order
+    float *ut = yoff + K * L;        // [D][L]      u; after the scan: out_z
+    float *dtt = ut + D * L;         // [L]         dt row
+    float *bct = dtt + L;            // [npp][2][L] B_n, C_n
+    float *wl = bct + npp * 2 * L;   // [npp][RS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int d = __builtin_amdgcn_readfirstlane(tid >> 6);     // this wave's channel
     const int b = blockIdx.x, part = blockIdx.y;
-    const int n0 = part * p.npp;
+    const int n0 = part * npp;
     const bool first = part == 0;     // the terms that are not sums over the states belong to part 0
     SMALL_STAMP(0, 0);
-    stage_yoff<K, T>(p, b, yoff);
-    stage_wl<D>(wl, wx, Aw, N);
-    if (tid < p.nw) prog[tid] = 0;
+    const ChanW<K> cwv = load_chan<K>(d, first, W_ARGS);
+    stage_zig<K, TL>(p, p.off + (long)b * 2 * K * L, yoff);
+    stage_wl<D>(wl, wx, Aw, N, n0, npp);
     __syncthreads();
     SMALL_STAMP(0, 1);
 
-    const int l0 = tid * T;
-    float xs[D][T + 3], z[D][T], pp[D][T], u[D][T], dl[D][T], dt[T];
-    pre_phase<K, T, false>(p, W_ARGS, yoff, l0, xs, z, pp, u, dl, dt);
+    const int l0 = lane * TL;
+    float x[TL + 3], z[TL], pp[TL], u[TL];
+    pre_channel<K, TL>(cwv, yoff, L, l0, x, z, pp, u);
+    run_store<TL>(ut + d * L + l0, u);
+    __syncthreads();
+    coop_dt<D>(ut, dtt, cwv.w0, L);
+    for (int nn = 0; nn < npp; ++nn) coop_bc<D>(ut, bct + nn * 2 * L, wl + nn * RS, L);
+    __syncthreads();
     SMALL_STAMP(0, 2);
-    float dlu[D][T], yacc[D][T];
+
+    float dl[TL], dlu[TL], yacc[TL];
+    {
+        const float wv = cwv.wdt, bv = cwv.dtb, Dv = cwv.Dv;
+        float dtv[TL];
+        run_load<TL>(dtt + l0, dtv);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float Dv = (Dw && first) ? Dw[d] : 0.f;
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            dlu[d][i] = dl[d][i] * u[d][i];
-            yacc[d][i] = Dv * u[d][i];
+        for (int i = 0; i < TL; ++i) {
+            dl[i] = softplus_thr(fmaf(wv, dtv[i], bv));
+            dlu[i] = dl[i] * u[i];
+            yacc[i] = Dv * u[i];
         }
     }
-    float *hs = p.hstate ? p.hstate + (long)b * DN * G + tid : nullptr;
-
-    for (int nn = 0; nn < p.npp; ++nn) {
-        const int n = n0 + nn;
-        const float *wr = wl + n * RS;
-        float Bn[T], Cn[T];
+    // two states per round: their two lane scans are interleaved (every DPP read two instructions behind its write)
+    for (int nn = 0; nn < npp; nn += 2) {
+        const bool two = nn + 1 < npp;
+        const int n1 = two ? nn + 1 : nn;
+        const float A0 = wl[nn * RS + 2 * D + d] * MMU_LOG2E, A1 = wl[n1 * RS + 2 * D + d] * MMU_LOG2E;
+        float B0[TL], B1[TL], C0[TL], C1[TL];
+        run_load<TL>(bct + nn * 2 * L + l0, B0);
+        run_load<TL>(bct + n1 * 2 * L + l0, B1);
+        run_load<TL>(bct + nn * 2 * L + L + l0, C0);
+        run_load<TL>(bct + n1 * 2 * L + L + l0, C1);
+        float P0 = 1.f, S0 = 0.f, P1 = 1.f, S1 = 0.f;
+        float pl0[TL], hl0[TL], pl1[TL], hl1[TL];
 #pragma unroll
-        for (int i = 0; i < T; ++i) Bn[i] = Cn[i] = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float wb = wr[d], wc = wr[D + d];
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                Bn[i] = fmaf(wb, u[d][i], Bn[i]);
-                Cn[i] = fmaf(wc, u[d][i], Cn[i]);
-            }
+        for (int i = 0; i < TL; ++i) {
+            const float a0 = fast_exp2(dl[i] * A0), a1 = fast_exp2(dl[i] * A1);
+            S0 = fmaf(a0, S0, dlu[i] * B0[i]);
+            S1 = fmaf(a1, S1, dlu[i] * B1[i]);
+            P0 *= a0;
+            P1 *= a1;
+            pl0[i] = P0; hl0[i] = S0;
+            pl1[i] = P1; hl1[i] = S1;
         }
-        float P[D], S[D], pl[D][T], hl[D][T];
+        wave_scan_affine_x2(P0, S0, P1, S1);
+        const float h0 = wave_shift_up1(S0, 0.f), h1 = wave_shift_up1(S1, 0.f);   // state entering this lane's tokens
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float A2 = wr[2 * D + d] * MMU_LOG2E;
-            P[d] = 1.f;
-            S[d] = 0.f;
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                const float a = fast_exp2(dl[d][i] * A2);
-                S[d] = fmaf(a, S[d], dlu[d][i] * Bn[i]);
-                P[d] *= a;
-                pl[d][i] = P[d];
-                hl[d][i] = S[d];
-            }
-        }
-        wave_scan_affine_all<D>(P, S);
-        float Pt[D], St[D], in[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            Pt[d] = readlane63(P[d]);
-            St[d] = readlane63(S[d]);
-        }
-        carry_all<D>(hcar, prog, w, p.nw, p.npp, nn, Pt, St, in);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            // state entering this lane's tokens
-            const float h0 = fmaf(wave_shift_up1(P[d], 1.f), in[d], wave_shift_up1(S[d], 0.f));
-            if (hs) hs[(long)(n * D + d) * G] = h0;
-#pragma unroll
-            for (int i = 0; i < T; ++i) yacc[d][i] = fmaf(Cn[i], fmaf(pl[d][i], h0, hl[d][i]), yacc[d][i]);
+        for (int i = 0; i < TL; ++i) {
+            yacc[i] = fmaf(C0[i], fmaf(pl0[i], h0, hl0[i]), yacc[i]);
+            if (two) yacc[i] = fmaf(C1[i], fmaf(pl1[i], h1, hl1[i]), yacc[i]);
         }
     }
-
     SMALL_STAMP(0, 3);
-    // gate, out_proj, inverse zig-zag, coordinates
+    // (every wave has left the cooperative reads of ut behind the last barrier: its own row is free for out_z)
+    {
+        float oz[TL];
+#pragma unroll
+        for (int i = 0; i < TL; ++i) oz[i] = yacc[i] * z[i] * sigmoidf_(z[i]);
+        run_store<TL>(ut + d * L + l0, oz);
+    }
+    __syncthreads();
+
+    // out_proj, inverse zig-zag, coordinates: a token per thread and step
     float dummy;
-    const float wgt = coord_weight(altho[0], dummy);
+    const float wgt = coord_weight(cwv.altho, dummy);
     constexpr int c = K / 2;
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-        const int l = l0 + i;
+    float *yb = p.y + ((long)part * p.B + b) * K * L;
+    for (int l = tid; l < L; l += blockDim.x) {
         int h, ww;
-        unzig(l, p.H, p.W, h, ww);
-        float oz[D];
+        unzig(l, p.H, p.lw, h, ww);
+        float oz[D], off[K], cum[K];
 #pragma unroll
-        for (int d = 0; d < D; ++d) oz[d] = yacc[d][i] * z[d][i] * sigmoidf_(z[d][i]);
-        float off[K], cum[K];
+        for (int dd = 0; dd < D; ++dd) oz[dd] = ut[dd * L + l];
 #pragma unroll
         for (int k = 0; k < K; ++k) off[k] = yoff[k * L + l];
         cum[c] = 0.f;
@@ -427,9 +396,8 @@ __global__ __launch_bounds__(512) void mamba_small_fwd_kernel(SmallArgs p, W_PAR
         for (int k = 0; k < K; ++k) {
             float sq = 0.f;
 #pragma unroll
-            for (int d = 0; d < D; ++d) sq = fmaf(wout[k * D + d], oz[d], sq);
-            p.y[((((long)part * p.B + b) * K + k) * p.H + h) * p.W + ww] =
-                fmaf(wgt, sq, first ? (float)h + p.scope * cum[k] : 0.f);
+            for (int dd = 0; dd < D; ++dd) sq = fmaf(wout[k * D + dd], oz[dd], sq);
+            yb[((k * p.H + h) << p.lw) + ww] = fmaf(wgt, sq, first ? (float)h + p.scope * cum[k] : 0.f);
         }
     }
     SMALL_STAMP(0, 4);
@@ -438,364 +406,382 @@ __global__ __launch_bounds__(512) void mamba_small_fwd_kernel(SmallArgs p, W_PAR
 // ================================================================================================================
 // backward
 // ================================================================================================================
-// Sums NV per-lane values over the wave, four at a time, into slot[0 .. NV) (one per value; the lanes 12..15 that
-// hold a batch's results write them).
+// sums NV per-lane values over the wave, four at a time; dst[i] receives value i (written by one of lanes 12..15)
 template <int NV>
-__device__ __forceinline__ void wave_sums_to(const float (&v)[NV], float *slot) {
+__device__ __forceinline__ void wave_sums_scatter(const float (&v)[NV], float *wpart, const int (&dst)[NV]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NV; i += 4) {
         const float r = wave_sum4_swap(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
                                        i + 3 < NV ? v[i + 3] : 0.f);
-        const int k = i + lane - 12;
-        if (lane >= 12 && lane < 16 && k < NV) slot[k] = r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i + q < NV && lane == 12 + q) wpart[dst[i + q]] = r;
     }
 }
 
-template <int K, int T>
-__global__ __launch_bounds__(512) void mamba_small_bwd_kernel(SmallArgs p, W_PARAMS) {
-    constexpr int D = 2 * K;
-    extern __shared__ float smem[];
-    const int L = p.L, N = p.N, DN = D * N, G = L / T;
+template <int K, int TL>
+__global__ __launch_bounds__(128 * K) void mamba_small_bwd_kernel(SmallArgs p, W_PARAMS) {
+    constexpr int D = 2 * K, RS = WRec<D>::RS;
+    extern __shared__ __align__(16) float smem[];
+    constexpr int L = 64 * TL;
+    const int N = p.N, npp = p.npp;
     const GradLayout<K> lay(N);
     const int NV = lay.total;
-    constexpr int RS = WRec<D>::RS, CS = CarryRec<D>::CS;
-    float *yoff = smem;                                          // [K][L]
-    float *dpl = smem + K * L;                                   // [D][L + 4]   conv1d backward exchange
-    float *wl = dpl + D * (L + 4);                               // [N][RS]      per-state scalars (16-byte aligned)
-    float *hcar = wl + N * RS;                                   // [nw][npp][CS]
-    float *wpart = hcar + p.nw * p.npp * CS;                     // [nw][NV]
-    int *prog = (int *)(wpart + p.nw * NV);                      // [nw]
+    float *yoff = smem;                 // [K][L]      y_off, zig-zag order
+    float *dyz = yoff + K * L;          // [K][L]      d rows, zig-zag order
+    float *ut = dyz + K * L;            // [D][L]      u
+    float *dtt = ut + D * L;            // [L]         dt row
+    float *bct = dtt + L;               // [2][2][L]   B_n, C_n, double-buffered over the states
+    float *slab = bct + 4 * L;          // [2D][L + 4] per-channel exchange: dB_d | dC_d, then draw, dp, d xz
+    float *sums = slab + 2 * D * (L + 4);   // [2][L]  dB_n, dC_n summed over the channels; later d dt
+    float *wl = sums + 2 * L;           // [npp][RS]
+    float *wpart = wl + npp * RS;       // [NV + 1]    this workgroup's weight-gradient vector (+ a scratch word)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x, part = blockIdx.y;
-    const int n0 = part * p.npp;
-    const bool first = part == 0;     // the terms that are not sums over the states belong to part 0
+    const int n0 = part * npp;
+    const bool first = part == 0;
     SMALL_STAMP(1, 0);
-    // lanes take the token groups in REVERSE order: the adjoint scan runs forward over lanes and waves
-    const int gr = G - 1 - tid;
-    const int l0 = gr * T;
-    float dyr[K][T];     // incoming gradient of the row coordinates (issued first: in flight during the staging)
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-        int h, ww;
-        unzig(l0 + i, p.H, p.W, h, ww);
-#pragma unroll
-        for (int k = 0; k < K; ++k) dyr[k][i] = p.dy[(((long)b * K + k) * p.H + h) * p.W + ww];
-    }
-    stage_yoff<K, T>(p, b, yoff);
-    stage_wl<D>(wl, wx, Aw, N);
-    if (tid < p.nw) prog[tid] = 0;
-    for (int i = tid; i < p.nw * NV; i += blockDim.x) wpart[i] = 0.f;   // (the other parts' rows of dW_x / dA stay 0)
-    for (int i = tid; i < D * 4; i += blockDim.x) dpl[(i >> 2) * (L + 4) + L + (i & 3)] = 0.f;   // tokens past the end
+    const ChanW<K> cwv = load_chan<K>(d, first, W_ARGS);
+    stage_zig<K, TL>(p, p.off + (long)b * 2 * K * L, yoff);
+    stage_zig<K, TL>(p, p.dy + (long)b * K * L, dyz);
+    stage_wl<D>(wl, wx, Aw, N, n0, npp);
+    for (int i = tid; i < NV; i += blockDim.x) wpart[i] = 0.f;   // (the other parts' rows of dW_x / dA stay 0)
     __syncthreads();
-
-    float xs[D][T + 3], z[D][T], pp[D][T], u[D][T], dl[D][T], dt[T];
     SMALL_STAMP(1, 1);
-    pre_phase<K, T, true>(p, W_ARGS, yoff, l0, xs, z, pp, u, dl, dt);
-    SMALL_STAMP(1, 2);
 
+    const int l0 = lane * TL;
     float dwgt_da;
-    const float wgt = coord_weight(altho[0], dwgt_da);
-    // the incoming gradient through out_proj and the gate
-    float doz[D][T], dyv[D][T], sz[D][T];
+    const float wgt = coord_weight(cwv.altho, dwgt_da);
+    const float wdv = cwv.wdt, dbv = cwv.dtb, Dv = cwv.Dv;
+    // Across the state loop a lane keeps six values per token (u, delta, dy, and the three accumulators); x, z, the
+    // conv pre-activation and d out_z are formed again behind the loop (TL = 16: 256 registers would not hold them)
+    float u[TL], dl[TL], dyv[TL], du[TL], ddl[TL], yacc[TL];
+    auto d_out_z = [&](float (&doz)[TL]) {
 #pragma unroll
-    for (int i = 0; i < T; ++i) {
+        for (int i = 0; i < TL; ++i) doz[i] = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float s = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float g[TL];
+            run_load<TL>(dyz + k * L + l0, g);
+            const float wo = wgt * cwv.wo[k];
 #pragma unroll
-            for (int k = 0; k < K; ++k) s = fmaf(wout[k * D + d], dyr[k][i], s);
-            doz[d][i] = wgt * s;
-            sz[d][i] = sigmoidf_(z[d][i]);
-            dyv[d][i] = doz[d][i] * z[d][i] * sz[d][i];     // d out_z * silu(z) = gradient of y
+            for (int i = 0; i < TL; ++i) doz[i] = fmaf(wo, g[i], doz[i]);
+        }
+    };
+    {
+        float x[TL + 3], z[TL], pp[TL], doz[TL];
+        pre_channel<K, TL>(cwv, yoff, L, l0, x, z, pp, u);
+        run_store<TL>(ut + d * L + l0, u);
+        d_out_z(doz);
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            dyv[i] = doz[i] * z[i] * sigmoidf_(z[i]);            // d y = d out_z * silu(z)
+            du[i] = Dv * dyv[i];
+            ddl[i] = 0.f;
+            yacc[i] = Dv * u[i];
         }
     }
-    float dlu[D][T], du[D][T], ddl[D][T], yacc[D][T];
+    __syncthreads();
+    coop_dt<D>(ut, dtt, cwv.w0, L);
+    coop_bc<D>(ut, bct, wl, L);                 // state 0 of this part; state nn + 1 is formed during round nn
+    __syncthreads();
+    SMALL_STAMP(1, 2);
+    {
+        float dtv[TL];
+        run_load<TL>(dtt + l0, dtv);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float Dv = (Dw && first) ? Dw[d] : 0.f;
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            dlu[d][i] = dl[d][i] * u[d][i];
-            du[d][i] = Dv * dyv[d][i];
-            ddl[d][i] = 0.f;
-            yacc[d][i] = Dv * u[d][i];
-        }
+        for (int i = 0; i < TL; ++i) dl[i] = softplus_thr(fmaf(wdv, dtv[i], dbv));
     }
-    const float *hs = p.hstate + (long)b * DN * G + gr;
-    float *myw = wpart + w * NV;
     SMALL_STAMP(1, 3);
 
-    for (int nn = 0; nn < p.npp; ++nn) {
+    for (int nn = 0; nn < npp; ++nn) {
         const int n = n0 + nn;
-        const float *wr = wl + n * RS;
-        float hin[D];     // saved states entering this lane's tokens: in flight during (1) and the carry
+        const float *wr = wl + nn * RS;
+        const float Ar = wr[2 * D + d], A2 = Ar * MMU_LOG2E;
+        float Bn[TL], Cn[TL], a[TL];
+        run_load<TL>(bct + (nn & 1) * 2 * L + l0, Bn);
+        run_load<TL>(bct + (nn & 1) * 2 * L + L + l0, Cn);
+        // (1) the lane's tokens as two affine maps: h forward (P, S), and the adjoint gh_t = a_t g_t,
+        //     g_t = C_t dy_t + gh_{t+1} backward (Q, R)
+        float P = 1.f, S = 0.f, Q = 1.f, R = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) hin[d] = hs[(long)(n * D + d) * G];
-        float Bn[T], Cn[T], dBn[T], dCn[T];
-#pragma unroll
-        for (int i = 0; i < T; ++i) Bn[i] = Cn[i] = dBn[i] = dCn[i] = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float wb = wr[d], wc = wr[D + d];
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                Bn[i] = fmaf(wb, u[d][i], Bn[i]);
-                Cn[i] = fmaf(wc, u[d][i], Cn[i]);
-            }
+        for (int i = 0; i < TL; ++i) {
+            a[i] = fast_exp2(dl[i] * A2);
+            S = fmaf(a[i], S, dl[i] * u[i] * Bn[i]);
+            P *= a[i];
         }
-        // (1) the adjoint recurrence gh_t = a_t g_t, g_t = c_t + gh_{t+1}, c_t = C_t dy_t: every channel's T tokens, last
-        //     first, as one affine map (Q, R); only (Q, R) is kept -- (2) rebuilds a and c per channel (one exp and one
-        //     multiply per token: cheaper than 4 T registers per channel across the scan)
-        float Q[D], R[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float A2 = wr[2 * D + d] * MMU_LOG2E;
-            Q[d] = 1.f;
-            R[d] = 0.f;
-#pragma unroll
-            for (int i = T - 1; i >= 0; --i) {
-                const float a = fast_exp2(dl[d][i] * A2);
-                R[d] = a * fmaf(Cn[i], dyv[d][i], R[d]);
-                Q[d] *= a;
-            }
+        for (int i = TL - 1; i >= 0; --i) {
+            R = a[i] * fmaf(Cn[i], dyv[i], R);
+            Q *= a[i];
         }
-        wave_scan_affine_all<D>(Q, R);
-        float Qt[D], Rt[D], in[D];
+        // the adjoint runs from the last lane to the first: reverse the lanes, scan forward, reverse back
+        Q = wave_reverse(Q);
+        R = wave_reverse(R);
+        wave_scan_affine_x2(P, S, Q, R);
+        float hp = wave_shift_up1(S, 0.f);                    // state entering this lane's first token
+        float gh = wave_reverse(wave_shift_up1(R, 0.f));      // gh of the token after this lane's last
+        // (2) h forward, then the adjoint backward with everything that needs it
+        //     dB_n / dC_n are sums over the channels: this channel's rows go to LDS, all threads add them up in (3)
+        float hm[TL];
+        {
+            float dCn[TL];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            Qt[d] = readlane63(Q[d]);
-            Rt[d] = readlane63(R[d]);
-        }
-        carry_all<D>(hcar, prog, w, p.nw, p.npp, nn, Qt, Rt, in);
-        // (2) per channel: h forward from the saved state, then the adjoint backward with every gradient that needs it
-        float dAv[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float Ar = wr[2 * D + d], A2 = Ar * MMU_LOG2E;
-            float gh = fmaf(wave_shift_up1(Q[d], 1.f), in[d], wave_shift_up1(R[d], 0.f));   // gh of the token after this lane's last
-            float hp = hin[d];                                                               // state entering its first token
-            float a[T], hm[T];
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                a[i] = fast_exp2(dl[d][i] * A2);
+            for (int i = 0; i < TL; ++i) {
                 hm[i] = a[i] * hp;
-                hp = fmaf(dlu[d][i], Bn[i], hm[i]);
-                yacc[d][i] = fmaf(Cn[i], hp, yacc[d][i]);
-                dCn[i] = fmaf(dyv[d][i], hp, dCn[i]);
+                hp = fmaf(dl[i] * u[i], Bn[i], hm[i]);
+                yacc[i] = fmaf(Cn[i], hp, yacc[i]);
+                dCn[i] = dyv[i] * hp;
             }
-            float da = 0.f;
-#pragma unroll
-            for (int i = T - 1; i >= 0; --i) {
-                const float g = fmaf(Cn[i], dyv[d][i], gh);
-                gh = a[i] * g;
-                const float t0 = g * dl[d][i];
-                dBn[i] = fmaf(t0, u[d][i], dBn[i]);
-                du[d][i] = fmaf(t0, Bn[i], du[d][i]);
-                da = fmaf(t0, hm[i], da);
-                ddl[d][i] = fmaf(g, fmaf(u[d][i], Bn[i], Ar * hm[i]), ddl[d][i]);
-            }
-            dAv[d] = da;
+            run_store<TL>(slab + (D + d) * (L + 4) + l0, dCn);
         }
-        // d x_dbl rows 1 + n (B_n) and 1 + N + n (C_n): back into u, and their x_proj weight gradients
-        float wv[3 * D];
+        float da = 0.f;
+        {
+            float dBn[TL];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float wb = wr[d], wc = wr[D + d];
+            for (int i = TL - 1; i >= 0; --i) {
+                const float g = fmaf(Cn[i], dyv[i], gh);
+                gh = a[i] * g;
+                const float t0 = g * dl[i];
+                dBn[i] = t0 * u[i];
+                du[i] = fmaf(t0, Bn[i], du[i]);
+                da = fmaf(t0, hm[i], da);
+                ddl[i] = fmaf(g, fmaf(u[i], Bn[i], Ar * hm[i]), ddl[i]);
+            }
+            run_store<TL>(slab + d * (L + 4) + l0, dBn);
+        }
+        // (3)
+        __syncthreads();
+        for (int l = tid; l < L; l += blockDim.x) {
             float sb = 0.f, sc = 0.f;
 #pragma unroll
-            for (int i = 0; i < T; ++i) {
-                du[d][i] = fmaf(wb, dBn[i], fmaf(wc, dCn[i], du[d][i]));
-                sb = fmaf(dBn[i], u[d][i], sb);
-                sc = fmaf(dCn[i], u[d][i], sc);
+            for (int dd = 0; dd < D; ++dd) {
+                sb += slab[dd * (L + 4) + l];
+                sc += slab[(D + dd) * (L + 4) + l];
             }
-            wv[d] = sb;
-            wv[D + d] = sc;
-            wv[2 * D + d] = dAv[d];
+            sums[l] = sb;
+            sums[L + l] = sc;
         }
-        // (three destinations: two rows of dW_x and one column of dA)
+        if (nn + 1 < npp) coop_bc<D>(ut, bct + ((nn + 1) & 1) * 2 * L, wl + (nn + 1) * RS, L);
+        __syncthreads();
+        // (4) back into u through the x_proj rows 1 + n and 1 + N + n, and this channel's entries of their gradients
         {
-            const int ln = lane;
+            const float wb = wr[d], wc = wr[D + d];
+            float sb = 0.f, sc = 0.f, gb[TL], gc[TL];
+            run_load<TL>(sums + l0, gb);
+            run_load<TL>(sums + L + l0, gc);
 #pragma unroll
-            for (int i = 0; i < 3 * D; i += 4) {
-                const float r = wave_sum4_swap(wv[i], i + 1 < 3 * D ? wv[i + 1] : 0.f, i + 2 < 3 * D ? wv[i + 2] : 0.f,
-                                               i + 3 < 3 * D ? wv[i + 3] : 0.f);
-                const int k = i + ln - 12;
-                if (ln >= 12 && ln < 16 && k < 3 * D) {
-                    const int which = k / D, d = k - which * D;
-                    const int dst = which == 0 ? lay.wx + (1 + n) * D + d
-                                  : which == 1 ? lay.wx + (1 + N + n) * D + d
-                                               : lay.A + d * N + n;
-                    myw[dst] = r;
-                }
+            for (int i = 0; i < TL; ++i) {
+                du[i] = fmaf(wb, gb[i], fmaf(wc, gc[i], du[i]));
+                sb = fmaf(gb[i], u[i], sb);
+                sc = fmaf(gc[i], u[i], sc);
             }
+            const float v3[3] = {sb, sc, da};
+            const int dst[3] = {lay.wx + (1 + n) * D + d, lay.wx + (1 + N + n) * D + d, lay.A + d * N + n};
+            wave_sums_scatter<3>(v3, wpart, dst);
         }
     }
-
     SMALL_STAMP(1, 4);
-    // ---- behind the scan: gate, dt row, softplus, conv1d, in_proj, coordinates ---------------------------------
-    float wsm[K * D + 1 + 4 * D];   // dWout [K*D], dwgt, dD [D], dWdt [D], dbias [D], dWx row 0 [D]
+
+    // ---- behind the scan -------------------------------------------------------------------------------------------
+    // gate: out_z (for d out_proj), dz; softplus -> d raw delta; the dt row needs the sum over the channels
+    float dz[TL], wv[3 * K + 10];
 #pragma unroll
-    for (int i = 0; i < K * D + 1 + 4 * D; ++i) wsm[i] = 0.f;
-    float dzv[D][T];
+    for (int i = 0; i < 3 * K + 10; ++i) wv[i] = 0.f;
+    float x[TL + 3], z[TL], pp[TL], dtv[TL];
+    {
+        float u2[TL], doz[TL];
+        MMU_COMPILER_FENCE();          // (formed again, not kept alive across the loop)
+        pre_channel<K, TL>(cwv, yoff, L, l0, x, z, pp, u2);
+        run_load<TL>(dtt + l0, dtv);
+        d_out_z(doz);
 #pragma unroll
-    for (int i = 0; i < T; ++i) {
-        float oz[D];
+        for (int i = 0; i < TL; ++i) {
+            const float sg = sigmoidf_(z[i]);
+            dz[i] = doz[i] * yacc[i] * sg * (1.f + z[i] * (1.f - sg));
+        }
+    }
+    // wv: [0,K) dWout[.][d] | K dD | K+1 dWdt | K+2 dbias | K+3 dWx row 0 | K+4..K+7 dcw | K+8 dcb |
+    //     K+9..2K+8 dWin row d | 2K+9..3K+8 dWin row D+d | 3K+9 unused
+    {
+        float ozv[TL], wdr[TL];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float zs = z[d][i] * sz[d][i];                        // silu(z)
-            oz[d] = yacc[d][i] * zs;
-            dzv[d][i] = doz[d][i] * yacc[d][i] * sz[d][i] * (1.f + z[d][i] * (1.f - sz[d][i]));
-            if (first) wsm[K * D + 1 + d] = fmaf(dyv[d][i], u[d][i], wsm[K * D + 1 + d]);   // dD
+        for (int i = 0; i < TL; ++i) {
+            ozv[i] = yacc[i] * z[i] * sigmoidf_(z[i]);
+            if (first) wv[K] = fmaf(dyv[i], u[i], wv[K]);
+            const float raw = fmaf(wdv, dtv[i], dbv);
+            const float draw = ddl[i] * (raw <= 20.f ? sigmoidf_(raw) : 1.f);   // softplus' (threshold 20)
+            wv[K + 1] = fmaf(draw, dtv[i], wv[K + 1]);
+            wv[K + 2] += draw;
+            wdr[i] = wdv * draw;
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            float sq = 0.f;
+            float g[TL];
+            run_load<TL>(dyz + k * L + l0, g);
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                sq = fmaf(wout[k * D + d], oz[d], sq);
-                wsm[k * D + d] = fmaf(wgt * dyr[k][i], oz[d], wsm[k * D + d]);        // dWout
-            }
-            wsm[K * D] = fmaf(dyr[k][i], sq, wsm[K * D]);                              // d wgt
+            for (int i = 0; i < TL; ++i) wv[k] = fmaf(wgt * g[i], ozv[i], wv[k]);
         }
-        // softplus, dt_proj, the dt row of x_proj
-        float ddt = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float raw = fmaf(wdt[d], dt[i], dtb ? dtb[d] : 0.f);
-            const float draw = ddl[d][i] * (raw <= 20.f ? sigmoidf_(raw) : 1.f);   // softplus' (threshold 20)
-            ddt = fmaf(wdt[d], draw, ddt);
-            wsm[K * D + 1 + D + d] = fmaf(draw, dt[i], wsm[K * D + 1 + D + d]);        // dWdt
-            wsm[K * D + 1 + 2 * D + d] += draw;                                        // d dt_bias
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            du[d][i] = fmaf(wx[d], ddt, du[d][i]);
-            wsm[K * D + 1 + 3 * D + d] = fmaf(ddt, u[d][i], wsm[K * D + 1 + 3 * D + d]);   // dWx row 0
-        }
+        run_store<TL>(slab + d * (L + 4) + l0, wdr);
     }
-    // conv1d backward: dp = du * silu'(pre); neighbours' dp through LDS
-    float wcv[5 * D];   // dcw [D][4], dcb [D]
+    __syncthreads();
+    float *ddtt = sums;                // d dt [L]
+    for (int l = tid; l < L; l += blockDim.x) {
+        float s = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        float s4[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            const float sg = sigmoidf_(pp[d][i]);
-            const float dp = du[d][i] * sg * (1.f + pp[d][i] * (1.f - sg));
-            dpl[d * (L + 4) + l0 + i] = dp;
-            sb += dp;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) s4[m] = fmaf(xs[d][i + m], dp, s4[m]);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) wcv[d * 4 + m] = s4[m];
-        wcv[4 * D + d] = sb;
+        for (int dd = 0; dd < D; ++dd) s += slab[dd * (L + 4) + l];
+        ddtt[l] = s;
     }
+    __syncthreads();
     SMALL_STAMP(1, 5);
+    // dt row of x_proj back into u; conv1d backward (this channel's dp: the next lane's first three through LDS)
+    {
+        const float w0 = cwv.w0[d];
+        const float c0 = cwv.c0, c1 = cwv.c1, c2 = cwv.c2, c3 = cwv.c3;
+        float *dpr = slab + d * (L + 4);
+        if (lane < 4) dpr[L + lane] = 0.f;      // tokens past the end
+        float dp[TL + 3], ddt[TL];
+        run_load<TL>(ddtt + l0, ddt);
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            du[i] = fmaf(w0, ddt[i], du[i]);
+            wv[K + 3] = fmaf(ddt[i], u[i], wv[K + 3]);
+            const float sg = sigmoidf_(pp[i]);
+            dp[i] = du[i] * sg * (1.f + pp[i] * (1.f - sg));
+            wv[K + 8] += dp[i];
+            wv[K + 4] = fmaf(x[i], dp[i], wv[K + 4]);
+            wv[K + 5] = fmaf(x[i + 1], dp[i], wv[K + 5]);
+            wv[K + 6] = fmaf(x[i + 2], dp[i], wv[K + 6]);
+            wv[K + 7] = fmaf(x[i + 3], dp[i], wv[K + 7]);
+        }
+        {
+            float own[TL];
+#pragma unroll
+            for (int i = 0; i < TL; ++i) own[i] = dp[i];
+            run_store<TL>(dpr + l0, own);
+        }
+        // the next lane's first three.  The wave reads what the wave wrote: the LDS executes a wave's operations in
+        // order -- but the compiler sees a thread's stores to [l0, l0 + TL) and loads from [l0 + TL, ...) as independent
+        // and is free to hoist the loads (it did, for some TL: d offset off by a few per cent); the fence pins the order.
+        MMU_COMPILER_FENCE();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dp[TL + j] = dpr[l0 + TL + j];
+        MMU_COMPILER_FENCE();     // ... and the stores of d x below (same row) stay behind these loads
+        float dx[TL];
+#pragma unroll
+        for (int i = 0; i < TL; ++i) dx[i] = fmaf(c3, dp[i], fmaf(c2, dp[i + 1], fmaf(c1, dp[i + 2], c0 * dp[i + 3])));
+        // in_proj: this channel's two rows of d xz; their weight gradients; d y_off is a sum over all rows
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float yo[TL];
+            run_load<TL>(yoff + k * L + l0, yo);
+#pragma unroll
+            for (int i = 0; i < TL; ++i) {
+                wv[K + 9 + k] = fmaf(dx[i], yo[i], wv[K + 9 + k]);
+                wv[2 * K + 9 + k] = fmaf(dz[i], yo[i], wv[2 * K + 9 + k]);
+            }
+        }
+        // (row d holds this wave's own dp, row D + d nothing that is still read: no barrier needed before the stores)
+        run_store<TL>(slab + d * (L + 4) + l0, dx);
+        run_store<TL>(slab + (D + d) * (L + 4) + l0, dz);
+    }
     __syncthreads();
     SMALL_STAMP(1, 6);
-    float wiv[4 * K * K];
+    {
+        constexpr int c = K / 2;
+        float *db = p.doff + ((long)part * p.B + b) * K * L;
+        for (int l = tid; l < L; l += blockDim.x) {
+            float g[K];
 #pragma unroll
-    for (int i = 0; i < 4 * K * K; ++i) wiv[i] = 0.f;
-    constexpr int c = K / 2;
+            for (int k = 0; k < K; ++k) g[k] = 0.f;
 #pragma unroll
-    for (int i = 0; i < T; ++i) {
-        const int l = l0 + i;
-        float dxz[2 * D];
+            for (int j = 0; j < 2 * D; ++j) {
+                const float v = slab[j * (L + 4) + l];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float s = 0.f;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) s = fmaf(cw[d * 4 + m], dpl[d * (L + 4) + l + 3 - m], s);
-            dxz[d] = s;
-            dxz[D + d] = dzv[d][i];
-        }
-        float yo[K], g[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            yo[k] = yoff[k * L + l];
-            g[k] = 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 2 * D; ++j) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                g[k] = fmaf(win[j * K + k], dxz[j], g[k]);
-                wiv[j * K + k] = fmaf(dxz[j], yo[k], wiv[j * K + k]);
+                for (int k = 0; k < K; ++k) g[k] = fmaf(win[j * K + k], v, g[k]);
             }
-        }
-        // the coordinate terms: tap j > c feeds cum[k] for k >= j, tap j < c for k <= j
-        if (first) {
-            float run = 0.f;
+            // the coordinate terms: tap j > c feeds cum[k] for k >= j, tap j < c for k <= j
+            if (first) {
+                float run = 0.f;
 #pragma unroll
-            for (int j = K - 1; j > c; --j) {
-                run += dyr[j][i];
-                g[j] = fmaf(p.scope, run, g[j]);
+                for (int j = K - 1; j > c; --j) {
+                    run += dyz[j * L + l];
+                    g[j] = fmaf(p.scope, run, g[j]);
+                }
+                run = 0.f;
+#pragma unroll
+                for (int j = 0; j < c; ++j) {
+                    run += dyz[j * L + l];
+                    g[j] = fmaf(p.scope, run, g[j]);
+                }
             }
-            run = 0.f;
+            int h, ww;
+            unzig(l, p.H, p.lw, h, ww);
 #pragma unroll
-            for (int j = 0; j < c; ++j) {
-                run += dyr[j][i];
-                g[j] = fmaf(p.scope, run, g[j]);
-            }
+            for (int k = 0; k < K; ++k) db[((k * p.H + h) << p.lw) + ww] = g[k];
         }
-        int h, ww;
-        unzig(l, p.H, p.W, h, ww);
-#pragma unroll
-        for (int k = 0; k < K; ++k) p.doff[((((long)part * p.B + b) * K + k) * p.H + h) * p.W + ww] = g[k];
     }
     SMALL_STAMP(1, 7);
-    // weight gradients: wave sums into this wave's LDS slots, then the waves are added and the batch item's partial
-    // vector goes out
-    wave_sums_to<4 * K * K>(wiv, myw + lay.win);
-    wave_sums_to<5 * D>(wcv, myw + lay.cw);                  // cw and cb are adjacent in the layout
+    // this channel's rows of the weight gradients
     {
-        float tmp[K * D];
+        int dst[3 * K + 10];
 #pragma unroll
-        for (int i = 0; i < K * D; ++i) tmp[i] = wsm[i];
-        wave_sums_to<K * D>(tmp, myw + lay.wout);
-        float one[1] = {wsm[K * D]};
-        wave_sums_to<1>(one, myw + lay.altho);
-        float t4[D];
+        for (int k = 0; k < K; ++k) {
+            dst[k] = lay.wout + k * D + d;
+            dst[K + 9 + k] = lay.win + d * K + k;
+            dst[2 * K + 9 + k] = lay.win + (D + d) * K + k;
+        }
+        dst[K] = first ? lay.Dp + d : NV;      // (NV: the scratch word behind the vector)
+        dst[K + 1] = lay.wdt + d;
+        dst[K + 2] = lay.dtb + d;
+        dst[K + 3] = lay.wx + d;
 #pragma unroll
-        for (int i = 0; i < D; ++i) t4[i] = wsm[K * D + 1 + i];
-        wave_sums_to<D>(t4, myw + lay.Dp);
-#pragma unroll
-        for (int i = 0; i < D; ++i) t4[i] = wsm[K * D + 1 + D + i];
-        wave_sums_to<D>(t4, myw + lay.wdt);
-#pragma unroll
-        for (int i = 0; i < D; ++i) t4[i] = wsm[K * D + 1 + 2 * D + i];
-        wave_sums_to<D>(t4, myw + lay.dtb);
-#pragma unroll
-        for (int i = 0; i < D; ++i) t4[i] = wsm[K * D + 1 + 3 * D + i];
-        wave_sums_to<D>(t4, myw + lay.wx);
+        for (int m = 0; m < 4; ++m) dst[K + 4 + m] = lay.cw + d * 4 + m;
+        dst[K + 8] = lay.cb + d;
+        dst[3 * K + 9] = NV;
+        wave_sums_scatter<3 * K + 10>(wv, wpart, dst);
     }
     SMALL_STAMP(1, 8);
     __syncthreads();
-    SMALL_STAMP(1, 9);
-    for (int i = tid; i < NV; i += blockDim.x) {
+    // d altho: rows = wgt * seq + ..., seq = out_proj(out_z)  =>  d wgt = sum_{k,d} Wout[k][d] * (dWout[k][d] / wgt)
+    if (tid == 0) {
         float s = 0.f;
-        for (int ww = 0; ww < p.nw; ++ww) s += wpart[ww * NV + i];
-        if (i == lay.altho) s *= dwgt_da;
-        p.part[((long)b * p.ns + part) * NV + i] = s;
+        for (int i = 0; i < K * D; ++i) s = fmaf(wout[i], wpart[lay.wout + i], s);
+        wpart[lay.altho] = s / wgt * dwgt_da;
     }
-    SMALL_STAMP(1, 10);
+    __syncthreads();
+    float *pb = p.part + ((long)b * p.ns + part) * NV;
+    for (int i = tid; i < NV; i += blockDim.x) pb[i] = wpart[i];
+    SMALL_STAMP(1, 9);
 }
 
-// Workgroups [0, nbw): dweights[i] = sum over the B * ns slots of part[slot][i].  The rest: d offset [B, 2K, H, W] =
-// sum over the ns parts of dparts[part][b][k][pixel] for the first K channels, 0 for the others.  Fixed order.
+// Workgroups [0, nbw): dweights[i] = sum over the B * ns slots of part[slot][i] -- 16 outputs per workgroup, the slots
+// dealt to 16 groups of threads whose partial sums meet in LDS in fixed order (a single thread walking 64+ slots waited
+// for every load in turn: 10 us).  The rest: d offset [B, 2K, H, W] = sum over the ns parts of dparts[part][b][k][pixel]
+// for the first K channels, 0 for the others.  Fixed order: bit-reproducible.
 __global__ __launch_bounds__(256) void mamba_small_reduce_kernel(const float *__restrict__ part, float *__restrict__ out,
                                                                  int slots, int NV, int nbw,
                                                                  const float *__restrict__ dparts,
                                                                  float *__restrict__ doff, int B, int K, int L, int ns) {
+    __shared__ float red[16][17];
     if ((int)blockIdx.x < nbw) {
-        const int i = blockIdx.x * 256 + threadIdx.x;
-        if (i >= NV) return;
+        const int x = threadIdx.x & 15, g = threadIdx.x >> 4;
+        const int i = blockIdx.x * 16 + x;
         float s = 0.f;
-        for (int b = 0; b < slots; ++b) s += part[(long)b * NV + i];
-        out[i] = s;
+        if (i < NV) {
+#pragma unroll 8
+            for (int b = g; b < slots; b += 16) s += part[(long)b * NV + i];
+        }
+        red[g][x] = s;
+        __syncthreads();
+        if (g == 0 && i < NV) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[q][x];
+            out[i] = t;
+        }
         return;
     }
     const long idx = (long)(blockIdx.x - nbw) * 256 + threadIdx.x;
@@ -806,17 +792,17 @@ __global__ __launch_bounds__(256) void mamba_small_reduce_kernel(const float *__
     if (r < (long)K * L) {
         const long ps = (long)B * K * L;
         const float *src = dparts + (long)b * K * L + r;
+#pragma unroll 8
         for (int j = 0; j < ns; ++j) s += src[j * ps];
     }
     doff[idx] = s;
 }
 
-// tokens per lane / waves for a sequence length: the smallest T in {1, 2, 4} with L = 64 T nw, nw <= 8
-bool plan(int L, int &T, int &nw) {
-    for (int t = 1; t <= 4; t *= 2) {
-        if (L % (64 * t) == 0 && L / (64 * t) <= 8) {
-            T = t;
-            nw = L / (64 * t);
+// tokens per lane: L = 64 * TL with TL in {1, 2, 4, 8, 16}
+bool plan(int L, int &TL) {
+    for (int t = 1; t <= 16; t *= 2) {
+        if (L == 64 * t) {
+            TL = t;
             return true;
         }
     }
@@ -825,26 +811,38 @@ bool plan(int L, int &T, int &nw) {
 
 int grad_total(int K, int N) { return K == 3 ? GradLayout<3>(N).total : GradLayout<1>(N).total; }
 
-// State-range parts per batch item: a scan kernel with one workgroup per batch item keeps 8 of 256 CUs busy and is
-// bound by the instruction issue of that one CU; the states are independent up to the final sums over n, so part j takes
-// states [j N / ns, (j + 1) N / ns) and the partial results are added downstream (the sampler adds the row maps while it
-// reads them, mamba_small_reduce_kernel adds the gradients).  MMU_SMALL_PARTS overrides (tuning / tests).
-int default_parts(int batch, int N) {
+size_t fwd_lds_floats(int K, int L, int npp) {
+    const int D = 2 * K, RS = (3 * D + 3) & ~3;
+    return (size_t)K * L + (size_t)D * L + L + (size_t)npp * 2 * L + (size_t)npp * RS;
+}
+size_t bwd_lds_floats(int K, int L, int npp, int NV) {
+    const int D = 2 * K, RS = (3 * D + 3) & ~3;
+    return (size_t)2 * K * L + (size_t)D * L + L + (size_t)4 * L + (size_t)2 * D * (L + 4) + (size_t)2 * L +
+           (size_t)npp * RS + NV + 4;
+}
+
+// State-range parts per batch item: the states are independent up to the final sums over n, so part j takes states
+// [j N / ns, (j + 1) N / ns).  Enough workgroups to spread over the chip, two states per part at least where possible
+// (the forward interleaves two lane scans).  MMU_SMALL_PARTS overrides (tuning / tests).
+int default_parts(int batch, int K, int L, int N) {
     static const int forced = []() { const char *e = getenv("MMU_SMALL_PARTS"); return e ? atoi(e) : 0; }();
     int ns = forced > 0 ? forced : 8;
-    while (ns > 1 && (N % ns != 0 || (long)batch * ns > 512)) ns >>= 1;
-    if (N % ns != 0) ns = 1;
+    if (ns > N) ns = N;
+    while (ns > 1 && (N % ns != 0 || (long)batch * ns > 1024)) --ns;
+    if (ns < 1) ns = 1;
+    // the forward keeps the B_n / C_n rows of all its states in LDS: more parts until they fit
+    while (ns < N && (N % ns != 0 || fwd_lds_floats(K, L, N / ns) * sizeof(float) > 160 * 1024)) ++ns;
     return ns;
 }
 
-int check(const mmu_mamba_small_params *p, const char *name, int &T, int &nw) {
+int check(const mmu_mamba_small_params *p, const char *name, int &TL) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
     MMU_CHECK(p->taps == 1 || p->taps == 3, "%s: 1 or 3 taps supported (got %d)", name, p->taps);
     MMU_CHECK(p->batch > 0 && p->height > 0 && p->width > 0, "%s: empty tensor", name);
     MMU_CHECK(p->dstate >= 1 && p->dstate <= 64, "%s: d_state must be in 1..64 (got %d)", name, p->dstate);
-    MMU_CHECK(plan(p->height * p->width, T, nw),
-              "%s: height * width must be a multiple of 64, at most 2048, and 64 * {1,2,4} * (<= 8 waves) (got %d)", name,
-              p->height * p->width);
+    MMU_CHECK(plan(p->height * p->width, TL) && (p->width & (p->width - 1)) == 0,
+              "%s: height and width must be powers of two with height * width in 64 .. 1024 (got %d x %d)", name,
+              p->height, p->width);
     MMU_CHECK(p->parts >= 1 && p->dstate % p->parts == 0, "%s: parts (%d) must divide d_state (%d)", name, p->parts,
               p->dstate);
     MMU_CHECK(p->offset && p->in_proj_weight && p->conv_weight && p->x_proj_weight && p->dt_proj_weight && p->A &&
@@ -853,15 +851,14 @@ int check(const mmu_mamba_small_params *p, const char *name, int &T, int &nw) {
     return 0;
 }
 
-SmallArgs to_args(const mmu_mamba_small_params *p, int nw) {
+SmallArgs to_args(const mmu_mamba_small_params *p) {
     SmallArgs a = {};
-    a.B = p->batch; a.H = p->height; a.W = p->width; a.L = p->height * p->width; a.N = p->dstate; a.nw = nw;
+    a.B = p->batch; a.H = p->height; a.W = p->width; a.N = p->dstate;
+    a.lw = 0;
+    while ((1 << a.lw) < p->width) ++a.lw;
     a.ns = p->parts; a.npp = p->dstate / p->parts;
     a.scope = p->extend_scope;
-    a.off = p->offset; a.win = p->in_proj_weight; a.cw = p->conv_weight; a.cb = p->conv_bias;
-    a.wx = p->x_proj_weight; a.wdt = p->dt_proj_weight; a.dtb = p->dt_bias; a.A = p->A; a.Dp = p->D;
-    a.wout = p->out_proj_weight; a.altho = p->altho; a.y = p->y; a.hstate = p->hstate; a.dy = p->dy;
-    a.doff = p->doffset; a.part = p->workspace;
+    a.off = p->offset; a.y = p->y; a.dy = p->dy;
     return a;
 }
 
@@ -875,18 +872,24 @@ int set_lds_attr(F kernel, size_t bytes, const char *name) {
     return 0;
 }
 
-#define SMALL_DISPATCH(KERNEL, K_, T_, ...)                         \
-    do {                                                            \
-        if (K_ == 3) {                                              \
-            if (T_ == 1) { KERNEL(3, 1, __VA_ARGS__); }             \
-            else if (T_ == 2) { KERNEL(3, 2, __VA_ARGS__); }        \
-            else { KERNEL(3, 4, __VA_ARGS__); }                     \
-        } else {                                                    \
-            if (T_ == 1) { KERNEL(1, 1, __VA_ARGS__); }             \
-            else if (T_ == 2) { KERNEL(1, 2, __VA_ARGS__); }        \
-            else { KERNEL(1, 4, __VA_ARGS__); }                     \
-        }                                                           \
+#define SMALL_TL(KERNEL, K_, ...)                        \
+    switch (TL) {                                        \
+        case 1: KERNEL(K_, 1, __VA_ARGS__); break;       \
+        case 2: KERNEL(K_, 2, __VA_ARGS__); break;       \
+        case 4: KERNEL(K_, 4, __VA_ARGS__); break;       \
+        case 8: KERNEL(K_, 8, __VA_ARGS__); break;       \
+        default: KERNEL(K_, 16, __VA_ARGS__); break;     \
+    }
+#define SMALL_DISPATCH(KERNEL, ...)                      \
+    do {                                                 \
+        if (p->taps == 3) {                              \
+            SMALL_TL(KERNEL, 3, __VA_ARGS__)             \
+        } else {                                         \
+            SMALL_TL(KERNEL, 1, __VA_ARGS__)             \
+        }                                                \
     } while (0)
+#define W_CALL p->in_proj_weight, p->conv_weight, p->conv_bias, p->x_proj_weight, p->dt_proj_weight, p->dt_bias, p->A, \
+               p->D, p->out_proj_weight, p->altho
 
 }  // namespace
 
@@ -897,24 +900,14 @@ extern "C" int mmu_debug_small_stamps(unsigned long long *host_out) {
 #endif
 
 extern "C" int mmu_mamba_small_supported(int taps, int height, int width, int dstate) {
-    int T, nw;
+    int TL;
     return (taps == 1 || taps == 3) && dstate >= 1 && dstate <= 64 && height > 0 && width > 0 &&
-           plan(height * width, T, nw);
+           (width & (width - 1)) == 0 && plan(height * width, TL);
 }
 
-extern "C" int mmu_mamba_small_tokens_per_lane(int height, int width) {
-    int T, nw;
-    return plan(height * width, T, nw) ? T : 0;
+extern "C" int mmu_mamba_small_parts(int batch, int taps, int height, int width, int dstate) {
+    return default_parts(batch, taps, height * width, dstate);
 }
-
-// floats of hstate: batch * 2 * taps * dstate * (L / T)
-extern "C" size_t mmu_mamba_small_state_floats(int batch, int taps, int height, int width, int dstate) {
-    int T, nw;
-    if (!plan(height * width, T, nw)) return 0;
-    return (size_t)batch * 2 * taps * dstate * (size_t)(height * width / T);
-}
-
-extern "C" int mmu_mamba_small_parts(int batch, int dstate) { return default_parts(batch, dstate); }
 
 // floats of the backward workspace: batch * parts weight-gradient partial vectors + parts partial d offset maps
 extern "C" size_t mmu_mamba_small_bwd_workspace_floats(int batch, int taps, int height, int width, int dstate, int parts) {
@@ -930,48 +923,45 @@ extern "C" size_t mmu_mamba_small_grad_floats(int taps, int dstate) {
 }
 
 extern "C" int mmu_mamba_small_fwd(const mmu_mamba_small_params *p, void *stream) {
-    int T, nw;
-    if (int r = check(p, "mamba_small_fwd", T, nw)) return r;
+    int TL;
+    if (int r = check(p, "mamba_small_fwd", TL)) return r;
     MMU_CHECK(p->y != nullptr, "mamba_small_fwd: y is required");
-    const SmallArgs a = to_args(p, nw);
-    const int K = p->taps, D = 2 * K;
-    const int RS = (3 * D + 3) & ~3, CS = 2 * D;
-    const size_t lds = sizeof(float) * ((size_t)K * a.L + (size_t)a.N * RS + (size_t)nw * a.npp * CS + nw);
+    const SmallArgs a = to_args(p);
+    const size_t lds = sizeof(float) * fwd_lds_floats(p->taps, p->height * p->width, a.npp);
     hipStream_t st = (hipStream_t)stream;
 #define SMALL_FWD(K_, T_, a_)                                                                         \
     if (int r = set_lds_attr(mamba_small_fwd_kernel<K_, T_>, lds, "mamba_small_fwd")) return r;       \
-    mamba_small_fwd_kernel<K_, T_><<<dim3(a_.B, a_.ns), 64 * nw, lds, st>>>(a_, a_.win, a_.cw, a_.cb, a_.wx, a_.wdt, a_.dtb, a_.A, a_.Dp, a_.wout, a_.altho)
-    SMALL_DISPATCH(SMALL_FWD, K, T, a);
+    mamba_small_fwd_kernel<K_, T_><<<dim3(a_.B, a_.ns), 128 * K_, lds, st>>>(a_, W_CALL)
+    SMALL_DISPATCH(SMALL_FWD, a);
 #undef SMALL_FWD
     MMU_HIP_LAUNCH_CHECK("mamba_small_fwd");
     return 0;
 }
 
 extern "C" int mmu_mamba_small_bwd(const mmu_mamba_small_params *p, void *stream) {
-    int T, nw;
-    if (int r = check(p, "mamba_small_bwd", T, nw)) return r;
-    MMU_CHECK(p->hstate && p->dy && p->doffset && p->workspace && p->dweights,
-              "mamba_small_bwd: hstate, dy, doffset, workspace and dweights are required");
-    SmallArgs a = to_args(p, nw);
+    int TL;
+    if (int r = check(p, "mamba_small_bwd", TL)) return r;
+    MMU_CHECK(p->dy && p->doffset && p->workspace && p->dweights,
+              "mamba_small_bwd: dy, doffset, workspace and dweights are required");
+    SmallArgs a = to_args(p);
+    const int K = p->taps;
+    const int NV = grad_total(K, a.N);
     // workspace: [B * parts][NV] weight-gradient partials, then [parts][B][K][L] partial d offset
     a.part = p->workspace;
-    a.doff = p->workspace + (size_t)a.B * a.ns * grad_total(p->taps, a.N);
-    const int K = p->taps, D = 2 * K;
-    const int NV = grad_total(K, a.N);
-    const int RS = (3 * D + 3) & ~3, CS = 2 * D;
-    const size_t lds = sizeof(float) * ((size_t)K * a.L + (size_t)D * (a.L + 4) + (size_t)a.N * RS +
-                                        (size_t)nw * a.npp * CS + (size_t)nw * NV + nw);
+    a.doff = p->workspace + (size_t)a.B * a.ns * NV;
+    const size_t lds = sizeof(float) * bwd_lds_floats(K, p->height * p->width, a.npp, NV);
     hipStream_t st = (hipStream_t)stream;
 #define SMALL_BWD(K_, T_, a_)                                                                         \
     if (int r = set_lds_attr(mamba_small_bwd_kernel<K_, T_>, lds, "mamba_small_bwd")) return r;       \
-    mamba_small_bwd_kernel<K_, T_><<<dim3(a_.B, a_.ns), 64 * nw, lds, st>>>(a_, a_.win, a_.cw, a_.cb, a_.wx, a_.wdt, a_.dtb, a_.A, a_.Dp, a_.wout, a_.altho)
-    SMALL_DISPATCH(SMALL_BWD, K, T, a);
+    mamba_small_bwd_kernel<K_, T_><<<dim3(a_.B, a_.ns), 128 * K_, lds, st>>>(a_, W_CALL)
+    SMALL_DISPATCH(SMALL_BWD, a);
 #undef SMALL_BWD
     MMU_HIP_LAUNCH_CHECK("mamba_small_bwd");
-    const int nbw = (NV + 255) / 256;
-    const long nd = (long)a.B * 2 * K * a.L;
+    const int nbw = (NV + 15) / 16;
+    const int L = p->height * p->width;
+    const long nd = (long)a.B * 2 * K * L;
     mamba_small_reduce_kernel<<<nbw + (unsigned)((nd + 255) / 256), 256, 0, st>>>(a.part, p->dweights, a.B * a.ns, NV, nbw,
-                                                                                 a.doff, p->doffset, a.B, K, a.L, a.ns);
+                                                                                 a.doff, p->doffset, a.B, K, L, a.ns);
     MMU_HIP_LAUNCH_CHECK("mamba_small_reduce");
     return 0;
 }

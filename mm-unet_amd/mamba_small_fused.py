@@ -7,7 +7,7 @@
     requirements/mamba_simple.py:303-318 = ``MambaInnerFn``, selective_scan_interface.py:292-434) -> inverse zig-zag
     (:95-121,182-183) -> ``clamp(softplus(altho), .01) * y_keep + row + extend_scope * cumsum-from-centre`` (:138-188)
 
-for maps of ``64 * T * nw`` tokens (``T`` in 1, 2, 4; ``nw`` <= 8 waves; MM-UNet's 16 x 16 and 32 x 32 maps), instead of the
+for power-of-two maps of 64 .. 1,024 tokens (MM-UNet's 16 x 16 and 32 x 32 maps), instead of the
 six-launch chain zigzag_inproj -> mamba_pre_small -> selective scan (3 kernels) -> coords_outproj and its eleven-launch
 backward.  float32; taps K in (1, 3); conv width 4; dt_rank 1; d_state <= 64; no in_proj / out_proj / x_proj bias.
 Anything else: ``supported()`` is False and MMConv takes the chain.  No CPU path.
@@ -77,28 +77,25 @@ class MambaSmallFusedFn(torch.autograd.Function):
         if altho.numel() != 1 or altho.dtype != torch.float32:
             raise RuntimeError("mamba_small_fused: altho must hold one float32 element")
         al = _c(altho.reshape(1))
-        parts = L.mmu_mamba_small_parts(B, N)
+        parts = L.mmu_mamba_small_parts(B, K, H, W, N)
         y = torch.empty((parts, B, K, H, W), device=offset.device, dtype=torch.float32)
-        need_grad = any(ctx.needs_input_grad)
-        hstate = (torch.empty(L.mmu_mamba_small_state_floats(B, K, H, W, N), device=offset.device, dtype=torch.float32)
-                  if need_grad else None)
         p = _lib.MambaSmallParams()
         p.batch, p.height, p.width, p.taps, p.dstate, p.parts, p.extend_scope = B, H, W, K, N, parts, float(scope)
         p.offset, p.in_proj_weight, p.conv_weight, p.conv_bias = offset.data_ptr(), w_in.data_ptr(), conv_w.data_ptr(), \
             _lib.ptr(conv_b)
         p.x_proj_weight, p.dt_proj_weight, p.dt_bias, p.A, p.D = w_x.data_ptr(), w_dt.data_ptr(), _lib.ptr(dt_bias), \
             A.data_ptr(), _lib.ptr(D)
-        p.out_proj_weight, p.altho, p.y, p.hstate = w_out.data_ptr(), al.data_ptr(), y.data_ptr(), _lib.ptr(hstate)
+        p.out_proj_weight, p.altho, p.y = w_out.data_ptr(), al.data_ptr(), y.data_ptr()
         with torch.cuda.device(offset.device):
             _lib.check(L.mmu_mamba_small_fwd(p, _lib.stream_of(offset)))
-        ctx.save_for_backward(offset, w_in, conv_w, conv_b, w_x, w_dt, dt_bias, A, D, w_out, al, hstate)
+        ctx.save_for_backward(offset, w_in, conv_w, conv_b, w_x, w_dt, dt_bias, A, D, w_out, al)
         ctx.scope, ctx.parts = float(scope), parts
         ctx.altho_shape = altho.shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        offset, w_in, conv_w, conv_b, w_x, w_dt, dt_bias, A, D, w_out, al, hstate = ctx.saved_tensors
+        offset, w_in, conv_w, conv_b, w_x, w_dt, dt_bias, A, D, w_out, al = ctx.saved_tensors
         B, C2, H, W = offset.shape
         K = C2 // 2
         Dn, N = 2 * K, A.shape[1]
@@ -123,7 +120,7 @@ class MambaSmallFusedFn(torch.autograd.Function):
             _lib.ptr(conv_b)
         p.x_proj_weight, p.dt_proj_weight, p.dt_bias, p.A, p.D = w_x.data_ptr(), w_dt.data_ptr(), _lib.ptr(dt_bias), \
             A.data_ptr(), _lib.ptr(D)
-        p.out_proj_weight, p.altho, p.hstate = w_out.data_ptr(), al.data_ptr(), hstate.data_ptr()
+        p.out_proj_weight, p.altho = w_out.data_ptr(), al.data_ptr()
         p.dy, p.doffset, p.workspace, p.dweights = g.data_ptr(), doff.data_ptr(), ws.data_ptr(), dw.data_ptr()
         with torch.cuda.device(offset.device):
             _lib.check(L.mmu_mamba_small_bwd(p, _lib.stream_of(offset)))

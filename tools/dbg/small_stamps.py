@@ -15,12 +15,11 @@ L = _lib.lib()
 buf = (ctypes.c_ulonglong * (2 * 8 * 16))()
 L.mmu_debug_small_stamps.argtypes = [ctypes.c_void_p]
 assert L.mmu_debug_small_stamps(buf) == 0
-nw = (H * W) // (64 * L.mmu_mamba_small_tokens_per_lane(H, W))
-names = (["stage", "pre", "scan", "epilogue"],
-         ["stage", "pre", "dy/doz", "scan", "post-a", "barrier", "post-b(in_proj,doff)", "wave sums", "barrier", "final"])
+nw = 2 * K
+names = (["stage", "pre+coop", "scan", "epilogue"],
+         ["stage", "pre+coop", "softplus", "scan", "gate+ddt", "conv+in_proj", "d offset", "wave sums", "final"])
 for d, nm in enumerate(names):
-    print("forward" if d == 0 else "backward", "(100 MHz ticks -> us)")
+    print("forward" if d == 0 else "backward", "(s_memtime cycles)")
     for w in range(nw):
         st = [buf[(d * 8 + w) * 16 + i] for i in range(len(nm) + 1)]
-        print(f"  wave {w}: " + "  ".join(f"{n} {(st[i + 1] - st[i]) / 100:.2f}" for i, n in enumerate(nm)) +
-              f"   total {(st[-1] - st[0]) / 100:.2f}")
+        print(f"  wave {w}: " + "  ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(nm)) + f"   total {st[-1] - st[0]} cycles")
