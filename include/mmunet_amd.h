@@ -614,7 +614,8 @@ typedef struct {
 } mmu_mamba_small_params;
 
 int mmu_mamba_small_supported(int taps, int height, int width, int dstate);
-int mmu_mamba_small_parts(int batch, int taps, int height, int width, int dstate);
+/* parts for the forward (backward = 0) or the backward call (backward = 1); the two need not agree */
+int mmu_mamba_small_parts(int batch, int taps, int height, int width, int dstate, int backward);
 size_t mmu_mamba_small_bwd_workspace_floats(int batch, int taps, int height, int width, int dstate, int parts);
 size_t mmu_mamba_small_grad_floats(int taps, int dstate);
 int mmu_mamba_small_fwd(const mmu_mamba_small_params *p, void *stream);

@@ -265,7 +265,7 @@ def lib():
     L.mmu_mamba_small_supported.restype = ctypes.c_int
     L.mmu_mamba_small_supported.argtypes = [ctypes.c_int] * 4
     L.mmu_mamba_small_parts.restype = ctypes.c_int
-    L.mmu_mamba_small_parts.argtypes = [ctypes.c_int] * 5
+    L.mmu_mamba_small_parts.argtypes = [ctypes.c_int] * 6
     L.mmu_mamba_small_bwd_workspace_floats.restype = ctypes.c_size_t
     L.mmu_mamba_small_bwd_workspace_floats.argtypes = [ctypes.c_int] * 6
     L.mmu_mamba_small_grad_floats.restype = ctypes.c_size_t

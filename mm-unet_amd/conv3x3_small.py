@@ -15,8 +15,11 @@ SUPPORTED_CO = (1, 2, 6, 8)
 WEIGHT_GRAD_NATIVE = True    # False: weight / bias gradient from ATen (MIOpen); tests cover both
 
 
+ENABLED = True   # False: callers keep their nn.Conv2d call (fused_paths.plain_aten, A/B tests)
+
+
 def supported(x, weight):
-    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32 and x.dim() == 4
+    return (ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32 and x.dim() == 4
             and weight.shape[2:] == (3, 3) and weight.shape[0] in SUPPORTED_CO)
 
 

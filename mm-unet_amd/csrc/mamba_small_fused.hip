@@ -824,9 +824,13 @@ size_t bwd_lds_floats(int K, int L, int npp, int NV) {
 // State-range parts per batch item: the states are independent up to the final sums over n, so part j takes states
 // [j N / ns, (j + 1) N / ns).  Enough workgroups to spread over the chip, two states per part at least where possible
 // (the forward interleaves two lane scans).  MMU_SMALL_PARTS overrides (tuning / tests).
-int default_parts(int batch, int K, int L, int N) {
+int default_parts(int batch, int K, int L, int N, int backward) {
     static const int forced = []() { const char *e = getenv("MMU_SMALL_PARTS"); return e ? atoi(e) : 0; }();
-    int ns = forced > 0 ? forced : 8;
+    static const int forced_b = []() { const char *e = getenv("MMU_SMALL_PARTS_BWD"); return e ? atoi(e) : 0; }();
+    // forward: two states per part (its two lane scans are interleaved); backward: a round per state with two
+    // workgroup barriers each, so as few states per part as the chip has room for (measured at batch 8, 32 x 32:
+    // 2 / 4 / 8 / 16 parts = 46 / 34 / 28 / 25 us)
+    int ns = backward ? (forced_b > 0 ? forced_b : 16) : (forced > 0 ? forced : 8);
     if (ns > N) ns = N;
     while (ns > 1 && (N % ns != 0 || (long)batch * ns > 1024)) --ns;
     if (ns < 1) ns = 1;
@@ -905,8 +909,8 @@ extern "C" int mmu_mamba_small_supported(int taps, int height, int width, int ds
            (width & (width - 1)) == 0 && plan(height * width, TL);
 }
 
-extern "C" int mmu_mamba_small_parts(int batch, int taps, int height, int width, int dstate) {
-    return default_parts(batch, taps, height * width, dstate);
+extern "C" int mmu_mamba_small_parts(int batch, int taps, int height, int width, int dstate, int backward) {
+    return default_parts(batch, taps, height * width, dstate, backward);
 }
 
 // floats of the backward workspace: batch * parts weight-gradient partial vectors + parts partial d offset maps

@@ -85,6 +85,7 @@ def neg_exp(param):
     return a if a is not None else -torch.exp(param.float())
 
 
+BCL_ENABLED = True   # False: forward_bcl() is forward() between two transposes (fused_paths.plain_aten)
 BCL_LOWP = os.environ.get("MMUNET_BCL_LOWP", "1") != "0"   # 0: under autocast the tri-directional block takes the (B, L, C) route
 
 
@@ -216,7 +217,7 @@ class Mamba(nn.Module):
                                              torch.get_autocast_dtype("cuda") == torch.bfloat16)
         # bf16 activations (autocast): the same channels-first route with bf16 tensors between the kernels, when the slice
         # count is one the re-ordering kernels take in bf16 (MM-UNet: 16 / 32 / 64)
-        ok = (self.use_fast_path and self.bimamba_type == "v3" and self.in_proj.bias is None and x.is_cuda
+        ok = (BCL_ENABLED and self.use_fast_path and self.bimamba_type == "v3" and self.in_proj.bias is None and x.is_cuda
               and self.out_proj.bias is None and x.dtype in (torch.float32, torch.bfloat16)
               and (not lowp or (BCL_LOWP and 4 < self.nslices <= 64))
               and (lowp or not torch.is_autocast_enabled()))

@@ -77,7 +77,7 @@ class MambaSmallFusedFn(torch.autograd.Function):
         if altho.numel() != 1 or altho.dtype != torch.float32:
             raise RuntimeError("mamba_small_fused: altho must hold one float32 element")
         al = _c(altho.reshape(1))
-        parts = L.mmu_mamba_small_parts(B, K, H, W, N)
+        parts = L.mmu_mamba_small_parts(B, K, H, W, N, 0)
         y = torch.empty((parts, B, K, H, W), device=offset.device, dtype=torch.float32)
         p = _lib.MambaSmallParams()
         p.batch, p.height, p.width, p.taps, p.dstate, p.parts, p.extend_scope = B, H, W, K, N, parts, float(scope)
@@ -100,15 +100,15 @@ class MambaSmallFusedFn(torch.autograd.Function):
         K = C2 // 2
         Dn, N = 2 * K, A.shape[1]
         L = _lib.lib()
-        parts = ctx.parts
-        if tuple(dy.shape) != (parts, B, K, H, W):
-            raise RuntimeError(f"mamba_small_fused: gradient shape {tuple(dy.shape)} != {(parts, B, K, H, W)}")
+        if tuple(dy.shape) != (ctx.parts, B, K, H, W):
+            raise RuntimeError(f"mamba_small_fused: gradient shape {tuple(dy.shape)} != {(ctx.parts, B, K, H, W)}")
         # every part's gradient is the gradient of the sum: the sampler hands back a stride-0 view of it (any other
         # producer: the parts' gradients must agree, which a plain sum of the parts guarantees)
-        if parts > 1 and dy.stride(0) != 0:
+        if ctx.parts > 1 and dy.stride(0) != 0:
             raise RuntimeError("mamba_small_fused: the partial row maps may only be consumed through their sum "
                                "(morph_sample / .sum(0)); got per-part gradients")
         g = _c(dy[0].float())
+        parts = L.mmu_mamba_small_parts(B, K, H, W, N, 1)     # (the backward's own split of the states)
         doff = torch.empty_like(offset)
         nv = L.mmu_mamba_small_grad_floats(K, N)
         ws = torch.empty(L.mmu_mamba_small_bwd_workspace_floats(B, K, H, W, N, parts), device=offset.device,

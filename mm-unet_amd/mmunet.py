@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from .mamba_simple import Mamba, neg_exp, precomputed_A
 from . import conv3x3_mfma, conv3x3_small, mamba_small_fused, morph_coords, norm_fused
+from . import morph_sample as morph_sample_mod
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
 from . import maxpool as maxpool_op, pointwise
@@ -176,6 +177,11 @@ class MMConv(nn.Module):
         # Fused HIP sampler (morph_sample): the tap columns are the integers w + k - K//2, so only the
         # row coordinates are passed on.  get_interpolated_feature (grid_sample) stays as the
         # reference-shaped method and is what the fused op is tested against.
+        if not morph_sample_mod.ENABLED:
+            # the reference's own sequence (MMUNet.py:252-265): coordinate maps, grid_sample, the K x 1 convolution module
+            y_map, x_map = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope)
+            deformed = self.get_interpolated_feature(input.float() if input.dtype != torch.float32 else input, y_map, x_map)
+            return (self.dsc_conv_x if self.morph == 0 else self.dsc_conv_y)(deformed), None
         if self.mamba.in_proj.bias is None and self.mamba.out_proj.bias is None and \
                 morph_coords.supported(offset, self.kernel_size):
             y_rows = self._rows_fused(offset, combine=False)   # (the sampler adds the fused kernel's partial maps)

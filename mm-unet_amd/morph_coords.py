@@ -15,8 +15,11 @@ import torch
 from . import _lib
 
 
+ENABLED = True   # False: MMConv builds its coordinate map with tensor ops (fused_paths.plain_aten)
+
+
 def supported(offset, K):
-    return offset.is_cuda and offset.dtype == torch.float32 and K in (1, 3)
+    return ENABLED and offset.is_cuda and offset.dtype == torch.float32 and K in (1, 3)
 
 
 def _params(offset, K, scope=1.0):

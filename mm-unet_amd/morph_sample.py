@@ -22,6 +22,8 @@ import torch
 
 from . import _lib
 
+ENABLED = True   # False: MMConv samples with F.grid_sample (its reference-shaped method; fused_paths.plain_aten)
+
 
 class MorphSampleFn(torch.autograd.Function):
     @staticmethod

@@ -173,8 +173,11 @@ def _count_batch(bn):
             bn.num_batches_tracked.add_(1)
 
 
+ENABLED = True   # False: GroupNorm / BatchNorm2d / activation stay separate module calls (fused_paths.plain_aten)
+
+
 def supported(x, gn, bn=None):
-    ok = x.is_cuda and x.dtype in _IO and x.dim() == 4 and \
+    ok = ENABLED and x.is_cuda and x.dtype in _IO and x.dim() == 4 and \
         x.shape[0] * x.shape[1] < 65536 and isinstance(gn, nn.GroupNorm)
     if bn is not None:
         ok = ok and isinstance(bn, nn.BatchNorm2d) and (bn.track_running_stats or bn.training) and \
@@ -183,7 +186,7 @@ def supported(x, gn, bn=None):
 
 
 def bn_act_supported(x, bn):
-    return x.is_cuda and x.dtype in _IO and x.dim() == 4 and \
+    return ENABLED and x.is_cuda and x.dtype in _IO and x.dim() == 4 and \
         x.shape[0] * x.shape[1] < 65536 and isinstance(bn, nn.BatchNorm2d) and bn.affine and \
         (bn.track_running_stats or bn.training) and bn.momentum is not None
 

@@ -43,10 +43,16 @@ class BilinearResizeFn(torch.autograd.Function):
         return dx.to(ctx.dtype), None, None
 
 
+ENABLED = True   # False: F.interpolate itself (fused_paths.plain_aten)
+
+
 def bilinear_resize(x, size=None, scale_factor=None):
     """``F.interpolate(x, size=size | scale_factor=..., mode="bilinear", align_corners=True)``."""
     if (size is None) == (scale_factor is None):
         raise ValueError("bilinear_resize: give exactly one of size / scale_factor")
+    if not ENABLED:
+        import torch.nn.functional as F
+        return F.interpolate(x, size=size, scale_factor=scale_factor, mode="bilinear", align_corners=True)
     if size is None:
         size = (int(x.shape[2] * scale_factor), int(x.shape[3] * scale_factor))
     return BilinearResizeFn.apply(x, int(size[0]), int(size[1]))

@@ -307,7 +307,10 @@ def conv1x1_stride2(x, weight):
     return _Conv1x1Stride2Fn.apply(x, weight)
 
 
+STRIDE2_ENABLED = True   # False: the shortcut convolutions stay nn.Conv2d calls (fused_paths.plain_aten)
+
+
 def conv1x1_stride2_supported(m, x):
-    return (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
+    return (STRIDE2_ENABLED and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
             and m.bias is None and m.groups == 1 and m.dilation == (1, 1) and x.is_cuda and x.dim() == 4
             and x.dtype == torch.float32 and m.weight.dtype == torch.float32 and not torch.is_autocast_enabled())

@@ -24,8 +24,13 @@ def _dense_rows(t):
     return None
 
 
+ENABLED = True   # False: Mamba's tri-directional branch uses flip / stack / permute (fused_paths.plain_aten)
+
+
 def supported(*tensors, nslices=None):
     """float32, or bfloat16 when 5 <= nslices <= 64 (the kernels' tiled form; pass nslices to have it checked)."""
+    if not ENABLED:
+        return False
     tags = [_dense_rows(t) for t in tensors]
     lowp = tensors[0].dtype != torch.float32
     return tags[0] is not None and all(tag == tags[0] for tag in tags) and \

@@ -2,7 +2,9 @@
 data-parallel run, covered on CPU by tests/test_dp_gloo.py and on one device by tests/test_dp_gpu.py):
 
   C2  MM-UNet inference bs=8 3x512x512 fp32          -> the graph-replayed bs-8 forward == eight bs-1 forwards
-  C3  MM-UNet fwd+bwd bf16 bs=16 3x512x512, Dice+BCE -> finite step, live-gradient set, loss / logits vs the fp32 run
+  C3  MM-UNet fwd+bwd bf16 bs=16 3x512x512, Dice+BCE -> eval-mode logits at bs 8: bf16 autocast vs fp32 on the same weights,
+                                                        bounded by what the plain-ATen bf16 route (the reference's own
+                                                        op sequence) loses; then one finite train step with the live set
   C5  MM-UNet 3x1024x1024 bf16, d_state=64           -> d_state-64 model vs the CPU oracle (fp32, 256x256, <= 1e-3),
                                                         and one finite bf16 training step at 1024x1024
 """
@@ -45,6 +47,40 @@ def test_config2_inference_bs8_512_matches_single_image_forwards():
             worst = max(worst, float((out[i:i + 1] - ref).abs().max()), float((out2[7 - i:8 - i] - ref).abs().max()))
     assert torch.isfinite(out).all()
     assert worst <= 1e-3, f"bs-8 graph forward differs from the bs-1 forwards by {worst:.3e}"
+
+
+def test_config3_bf16_eval_logits_vs_fp32_and_plain_aten_route():
+    """BASELINE config 3, parity half.  Eval mode (running statistics, no dropout) at 8 x 3 x 512 x 512,
+    same weights through four routes: {fused kernels, plain ATen module calls (fused_paths.plain_aten: the reference's own
+    op sequence, only the scan / conv1d extension kernels stay HIP)} x {fp32, bf16 autocast}.
+      * fp32: the two routes agree to 2e-3 absolute (each is within the north star's 1e-3 of the oracle);
+      * bf16: what the network itself does to bf16 rounding is measured, not assumed -- the PLAIN route's distance from
+        fp32 (random-init MM-UNet, eval: 0.22 relative RMS; measured 2026-10, tools/dbg/parity_probe.py c3) is the yardstick:
+        the fused route may be at most 25 % further from fp32 than that (measured: 0.15, i.e. closer, because the fused
+        chain keeps coordinates / normalisation statistics in fp32), and below 0.45 = 3 x its measured value.  A bf16
+        kernel that is wrong rather than rounded (the failure the old correlation bound could not see) moves the fused
+        route away from fp32 while the plain route stays where it is.
+    Block-level bf16 checks against the reference's fp32 fixtures: tests/test_modules_gpu.py::test_block_bf16_autocast_*."""
+    from mm_unet_amd import fused_paths
+    m = _model().to(DEV).eval()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 3, 512, 512, generator=gen).to(DEV)
+    with torch.no_grad():
+        f32 = m(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            b16 = m(x).float()
+        with fused_paths.plain_aten():
+            p32 = m(x)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                p16 = m(x).float()
+    assert all(torch.isfinite(t_).all() for t_ in (f32, b16, p32, p16))
+    rms = lambda a, b_: float((a - b_).pow(2).mean().sqrt() / b_.pow(2).mean().sqrt())   # noqa: E731
+    e32 = float((f32 - p32).abs().max())
+    e_fused, e_plain = rms(b16, f32), rms(p16, p32)
+    print(f"C3 eval: fp32 fused vs plain max abs {e32:.2e}; bf16 vs fp32 relative RMS: fused {e_fused:.3f}, plain {e_plain:.3f}")
+    assert e32 <= 2e-3, f"fp32: fused and plain-ATen routes differ by {e32:.3e}"
+    assert e_fused <= max(1.25 * e_plain, 0.1), f"bf16 fused route {e_fused:.3f} from fp32, plain ATen route {e_plain:.3f}"
+    assert e_fused <= 0.45, e_fused
 
 
 def test_config3_bf16_autocast_train_step_bs16_512():

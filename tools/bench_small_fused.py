@@ -18,7 +18,7 @@ def run(B, K, H, W, N, parts=None, iters=200):
     w_in, cw, cb, wx, wdt, dtb = r(4 * K, K) * 0.5, r(D, 4) * 0.5, r(D) * 0.1, r(1 + 2 * N, D) * 0.3, r(D) * 0.3, r(D) * 0.1
     A = -torch.exp(torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(D, 1)).to(dev).contiguous()
     Dp, wout, al = torch.ones(D, device=dev), r(K, D) * 0.3, torch.tensor([0.54], device=dev)
-    parts = parts or L.mmu_mamba_small_parts(B, K, H, W, N)
+    parts = parts or L.mmu_mamba_small_parts(B, K, H, W, N, 0)
     y = torch.empty(parts, B, K, H, W, device=dev)
     dy = r(B, K, H, W)
     doff = torch.empty_like(off)
