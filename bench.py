@@ -101,6 +101,18 @@ def _scan_case(dev, b, d, l, n, layout):
     return u, delta, A, B, C, D, z, bias, dout
 
 
+def _scan_issue_floor_ms(b, d, l, n, backward):
+    """Issue-time floor of the selective scan at fp32 on gfx950: per element group (64 (channel, state,
+    token) elements = one wave-instruction each) the recurrence needs one v_exp_f32 (4.29 ns of a SIMD at two waves per
+    SIMD, profiles/r02_valu_rates_microbench.txt) and delta * A, (delta u) B, h = a h + b, y += C h as four halves of
+    packed FMAs (2.46 ns per v_pk_fma_f32): 9.2 ns -> 151 us at the headline shape on 1,024 SIMDs.  Backward: the
+    forward again, the adjoint recurrence and the gradient streams -- about 2.5 x (a second exp is not needed by the
+    algorithm, 14 packed halves are)."""
+    groups = b * d * n * l / 64.0
+    per_group_ns = 4.29 + (4 if not backward else 14) * 2.46 / 2.0
+    return groups * per_group_ns / 1024 / 1e6
+
+
 def scan_rooflines(dev, iters=20):
     """Live measurement of the hand-written streaming kernels against the HBM roofline (algorithmic bytes of
     SURVEY.md 8d / DESIGN.md 4): selective-scan forward and backward at the headline shape, the same at the
@@ -109,14 +121,20 @@ def scan_rooflines(dev, iters=20):
     s_ = 4  # fp32
     legs = {}
 
-    def leg(name, kernel, shape, alg_bytes, ms, binding, traffic=None):
+    def leg(name, kernel, shape, alg_bytes, ms, binding, traffic=None, issue_floor_ms=None):
         ach = alg_bytes / (ms * 1e-3) / 1e9
         legs[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                       "frac": round(ach / 8000.0, 4), "traffic": traffic, "kernel": kernel, "binding": binding,
                       "shape": shape, "algorithmic_bytes": alg_bytes, "ms_per_launch": round(ms, 4)}
+        if issue_floor_ms is not None:
+            # the second roof: the instruction-issue time of the ALGORITHM's minimum mix at the VALU
+            # rates measured on this chip (profiles/r02_valu_rates_microbench.txt), next to the HBM fraction
+            legs[name]["issue_floor_ms"] = round(issue_floor_ms, 4)
+            legs[name]["frac_of_issue_floor"] = round(issue_floor_ms / ms, 4)
 
     for (b, d, l, n, tag) in ((8, 128, 65536, 16, ""), (8, 6, 65536, 16, "_d6")):
-        u, delta, A, B, C, D, z, bias, dout = _scan_case(dev, b, d, l, n, "bdl" if tag == "" else "dbl")
+        # both legs on the layout the model hands the kernels: u / delta / z / dout physically [D][B][L]
+        u, delta, A, B, C, D, z, bias, dout = _scan_case(dev, b, d, l, n, "dbl")
         shape = {"batch": b, "dim": d, "seqlen": l, "dstate": n, "dtype": "f32"}
         ms_f = _timed(dev, lambda: ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False), iters)
         x = ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False)[1]
@@ -128,14 +146,16 @@ def scan_rooflines(dev, iters=20):
             "mmu_selective_scan_fwd = chunk_reduce8 + chunk_carry_par + chunk_apply_fwd8 (chunk-parallel: too few "
             "rows to stream)", shape, s_ * b * l * (4 * d + 2 * n), ms_f,
             "VALU issue, not HBM: one v_exp_f32 + ~5.6 VALU instructions per (d, n, t) element group against a budget "
-            "of ~6.5 issue slots at 70 % of HBM (DESIGN.md 4.1)", _traffic("scan_fwd_traffic.json") if tag == "" else None)
+            "of ~6.5 issue slots at 70 % of HBM (DESIGN.md 4.1)", _traffic("scan_fwd_traffic.json") if tag == "" else None,
+            issue_floor_ms=_scan_issue_floor_ms(b, d, l, n, backward=False))
         leg("roofline_bwd" + tag,
             "mmu_selective_scan_bwd = chunk_reduce8<bwd> + chunk_carry_par + chunk_apply_bwd_w8 (512-token tiles, one "
             "state pair per wave) + reduce_partials_w8",
             shape, s_ * b * l * (8 * d + 2 * n) + 4 * b * l * 2 * n, ms_b,
             "VALU issue: ~15 packed fp32 + 2 exp + 6.6 DPP instructions per (d, state pair, t) in the apply kernel "
             "(recompute + adjoint scan + 8 gradient streams) at ~2.5 ns per packed instruction and SIMD, DESIGN.md 4.2",
-            _traffic("scan_bwd_traffic.json") if tag == "" else None)
+            _traffic("scan_bwd_traffic.json") if tag == "" else None,
+            issue_floor_ms=_scan_issue_floor_ms(b, d, l, n, backward=True))
         if tag == "":
             w = torch.randn(d, 4, device=dev)
             cb = torch.randn(d, device=dev)
