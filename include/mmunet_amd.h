@@ -342,6 +342,40 @@ int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream);
 size_t mmu_conv3x3_wgrad_mfma_workspace_floats(int batch, int in_channels, int out_channels, int height, int width);
 int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *stream);
 
+/* ---- the stride-2 dense convolutions on the bf16 matrix cores with float32 accuracy ----- */
+/* src/UM_Net/MMUNet.py:360-375 (RCG: ConvTranspose2d(64, 64, 4, 2, 1) and Conv2d(64, 64, 4, 2, 1)) and :439-452
+ * (Conv2d(C, 2C, 3, 2, 1) of the down-sampling ResidualBlocks), their input and weight gradients.  kernel in {3, 4},
+ * stride 2, padding 1; float32 NCHW contiguous; in_channels % 16 == 0, out_channels % 64 == 0 (weight gradient: both
+ * % 64 == 0, output width % 4 == 0).
+ *   mmu_conv_s2_mfma            out [B, out_channels, Ho, Wo] = conv2d(input [B, in_channels, Hi, Wi], weight
+ *                               [out_channels][in_channels][K][K], stride 2, padding 1) (+ bias), Ho = (Hi + 2 - K) / 2 + 1.
+ *                               Also the input gradient of a transposed convolution: input = its output gradient,
+ *                               weight = its [Cin_T][Cout_T][K][K] as it is (in_channels = Cout_T, out_channels = Cin_T).
+ *   mmu_conv_s2_transposed_mfma out [B, out_channels, 2 Hi, 2 Wi] = conv_transpose2d(input [B, in_channels, Hi, Wi],
+ *                               weight [in_channels][out_channels][K][K], stride 2, padding 1) (+ bias) (K = 3: with
+ *                               output_padding 1).  Also the input gradient of a strided convolution: input = its
+ *                               output gradient, weight = its [Cout_c][Cin_c][K][K] as it is.
+ *   mmu_conv_s2_wgrad_mfma      out = dweight [out_channels][in_channels][K][K] of the strided convolution: input = x,
+ *                               weight field = dout [B, out_channels, Ho, Wo] (16-byte aligned).  For a transposed
+ *                               convolution's weight [Cin_T][Cout_T]: input = its output gradient (in_channels =
+ *                               Cout_T ... the high-resolution tensor), weight field = its input (out_channels = Cin_T).
+ * workspace: mmu_conv_s2_workspace_bytes() bytes (prepared bf16 weights), 16-byte aligned /
+ *            mmu_conv_s2_wgrad_workspace_floats() floats.  Deterministic (no atomics). */
+typedef struct {
+    int32_t batch, in_channels, out_channels, in_height, in_width, out_height, out_width, kernel;
+    const float *input;
+    const float *weight;
+    const float *bias;      /* [out_channels] or NULL */
+    float *out;
+    void *workspace;
+} mmu_conv_s2_params;
+
+size_t mmu_conv_s2_workspace_bytes(int in_channels, int out_channels);
+int mmu_conv_s2_mfma(const mmu_conv_s2_params *p, void *stream);
+int mmu_conv_s2_transposed_mfma(const mmu_conv_s2_params *p, void *stream);
+size_t mmu_conv_s2_wgrad_workspace_floats(int batch, int in_channels, int out_channels, int out_height, int out_width);
+int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream);
+
 /* ---- W (rows x inner) times a tokens-last matrix, on the bf16 matrix cores with float32 accuracy ------------- */
 /* out[b] = W . X[b] for b < batch;  X[b] = x + b*x_bs, `inner` rows of `tokens` contiguous floats, row stride x_rs;
  * out[b] = out + b*out_bs, `rows` rows, row stride out_rs (strides in elements).  rows % 64 == 0, inner % 16 == 0.

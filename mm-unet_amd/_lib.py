@@ -167,6 +167,12 @@ class CoordsParams(ctypes.Structure):
                                       "daltho")])
 
 
+class ConvS2Params(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "in_channels", "out_channels", "in_height", "in_width", "out_height",
+                                     "out_width", "kernel")]
+                + [(n, _vp) for n in ("input", "weight", "bias", "out", "workspace")])
+
+
 class MambaSmallParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps", "dstate", "parts")]
                 + [("extend_scope", ctypes.c_float)]
@@ -190,6 +196,8 @@ EXPORTS = (
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_mamba_small_supported", "mmu_mamba_small_parts", "mmu_mamba_small_bwd_workspace_floats",
     "mmu_mamba_small_grad_floats", "mmu_mamba_small_fwd", "mmu_mamba_small_bwd",
+    "mmu_conv_s2_workspace_bytes", "mmu_conv_s2_mfma", "mmu_conv_s2_transposed_mfma",
+    "mmu_conv_s2_wgrad_workspace_floats", "mmu_conv_s2_wgrad_mfma",
     "mmu_debug_wave_scan",
 )
 
@@ -236,7 +244,9 @@ def lib():
                      ("mmu_gated_mul_fwd", GatedMulParams), ("mmu_gated_mul_bwd", GatedMulParams),
                      ("mmu_conv7x7_2to1_fwd", Conv7x7Params), ("mmu_conv7x7_2to1_bwd", Conv7x7Params),
                      ("mmu_maxpool3s2_bwd", MaxPoolParams), ("mmu_sum_parts", SumPartsParams), ("mmu_conv1x1_one_fwd", Conv1x1OneParams), ("mmu_conv1x1_one_bwd", Conv1x1OneParams),
-                     ("mmu_mamba_small_fwd", MambaSmallParams), ("mmu_mamba_small_bwd", MambaSmallParams)):
+                     ("mmu_mamba_small_fwd", MambaSmallParams), ("mmu_mamba_small_bwd", MambaSmallParams),
+                     ("mmu_conv_s2_mfma", ConvS2Params), ("mmu_conv_s2_transposed_mfma", ConvS2Params),
+                     ("mmu_conv_s2_wgrad_mfma", ConvS2Params)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]
@@ -262,6 +272,10 @@ def lib():
     L.mmu_mamba_post_small_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
     L.mmu_norm_fused_workspace_floats.restype = ctypes.c_size_t
     L.mmu_norm_fused_workspace_floats.argtypes = [ctypes.c_int] * 3
+    L.mmu_conv_s2_workspace_bytes.restype = ctypes.c_size_t
+    L.mmu_conv_s2_workspace_bytes.argtypes = [ctypes.c_int] * 2
+    L.mmu_conv_s2_wgrad_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_conv_s2_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_mamba_small_supported.restype = ctypes.c_int
     L.mmu_mamba_small_supported.argtypes = [ctypes.c_int] * 4
     L.mmu_mamba_small_parts.restype = ctypes.c_int

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba, neg_exp, precomputed_A
-from . import conv3x3_mfma, conv3x3_small, mamba_small_fused, morph_coords, norm_fused
+from . import conv3x3_mfma, conv3x3_small, conv_s2, mamba_small_fused, morph_coords, norm_fused
 from . import morph_sample as morph_sample_mod
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
@@ -244,6 +244,8 @@ def run_fused(seq, x, residual=None):
                 x = conv3x3_mfma.conv3x3_mfma(x, m.weight, m.bias)
         elif conv1x1_stride2_supported(m, x):     # shortcut of a down-sampling residual block
             x = conv1x1_stride2(x, m.weight)
+        elif conv_s2.module_supported(m, x):      # 3 x 3 / stride 2 opening of a down-sampling residual block
+            x = conv_s2.module_call(m, x)
         else:
             x = m(x)
         i += 1
@@ -341,12 +343,12 @@ class RCG(nn.Module):
         edge1 = bilinear_resize(edge, size=f.size()[2:])
         x2 = run_fused(self.conv1, torch.cat((edge1, r), 1))
         # tri-directional Mamba at 2x resolution (MMUNet.py:398-412)
-        x0 = self.upsample(x2)
+        x0 = conv_s2.module_call(self.upsample, x2)      # ConvTranspose2d(64, 64, 4, 2, 1) on the matrix cores
         B, C, H, W = x0.shape
         # (channels-first entry: same block as self.mamba(x0.flatten(2).transpose(1, 2)), without the
         # (B, L, C) round trip -- 134 MB transposing copies each way at 256 x 256)
         out, _, _, _ = self.mamba.forward_bcl(x0.reshape(B, C, H * W))
-        x0 = self.downsample(out.reshape(B, C, H, W))
+        x0 = conv_s2.module_call(self.downsample, out.reshape(B, C, H, W))
         gate = torch.sigmoid(pointwise.conv_module(self.mlp[0], x2))       # mlp = Conv2d(64, 1, 1) -> Sigmoid
         return pointwise.gated_mul(x0 * x2, gate) + f
 

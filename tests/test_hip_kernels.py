@@ -775,3 +775,56 @@ def test_gemm_nt_full_size_properties(shape):
     assert torch.equal(c_bm, c)
     c2 = mfma_gemm.gemm_nt(2.0 * a, b, m, n, B, L, B * L, L, B * L, L)
     assert torch.equal(c2, 2.0 * c)                               # powers of two commute with every rounding
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 32, 64, 4), (1, 64, 128, 16, 24, 3), (2, 16, 64, 20, 12, 3),
+                                  (1, 128, 256, 64, 64, 3), (3, 64, 64, 10, 130, 4)])
+def test_conv_s2_mfma_vs_conv2d_fp64(case):
+    """csrc/conv_s2_mfma.hip, strided form: Conv2d(k, stride 2, padding 1) (MMUNet.py:375,439) forward, input gradient
+    (the transposed kernel) and weight gradient against ATen in float64; hi/lo bf16 split: ~2^-16 per product."""
+    import torch.nn.functional as F
+    from mm_unet_amd import conv_s2
+    B, cin, cout, H, W, k = case
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, cin, H, W, generator=gen).to(DEV).requires_grad_()
+    w = (torch.randn(cout, cin, k, k, generator=gen) / (k * cin ** 0.5)).to(DEV).requires_grad_()
+    b = torch.randn(cout, generator=gen).to(DEV).requires_grad_()
+    assert conv_s2.conv_supported(x, w)
+    out = conv_s2.conv_s2(x, w, b)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    ref = F.conv2d(xd, wd, bd, stride=2, padding=1)
+    assert out.shape == ref.shape
+    g = torch.randn(out.shape, generator=gen).to(DEV)
+    out.backward(g)
+    ref.backward(g.double())
+    sc = lambda t: max(1.0, float(t.abs().max()))   # noqa: E731
+    assert float((out.double() - ref).abs().max()) < 1e-4 * sc(ref), "forward"
+    assert float((x.grad.double() - xd.grad).abs().max()) < 1e-4 * sc(xd.grad), "d input"
+    assert float((w.grad.double() - wd.grad).abs().max()) < 2e-4 * sc(wd.grad), "d weight"
+    assert float((b.grad.double() - bd.grad).abs().max()) < 1e-4 * sc(bd.grad), "d bias"
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 16, 32), (1, 64, 64, 64, 64), (2, 32, 64, 9, 20), (1, 128, 128, 6, 70)])
+def test_conv_transpose_s2_mfma_vs_fp64(case):
+    """csrc/conv_s2_mfma.hip, transposed form: ConvTranspose2d(4, stride 2, padding 1) (MMUNet.py:360) forward, input
+    gradient (the strided kernel) and weight gradient against ATen in float64."""
+    import torch.nn.functional as F
+    from mm_unet_amd import conv_s2
+    B, cin, cout, H, W = case
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(B, cin, H, W, generator=gen).to(DEV).requires_grad_()
+    w = (torch.randn(cin, cout, 4, 4, generator=gen) / (4 * cin ** 0.5)).to(DEV).requires_grad_()
+    b = torch.randn(cout, generator=gen).to(DEV).requires_grad_()
+    assert conv_s2.convt_supported(x, w)
+    out = conv_s2.conv_transpose_s2(x, w, b)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    ref = F.conv_transpose2d(xd, wd, bd, stride=2, padding=1)
+    assert out.shape == ref.shape
+    g = torch.randn(out.shape, generator=gen).to(DEV)
+    out.backward(g)
+    ref.backward(g.double())
+    sc = lambda t: max(1.0, float(t.abs().max()))   # noqa: E731
+    assert float((out.double() - ref).abs().max()) < 1e-4 * sc(ref), "forward"
+    assert float((x.grad.double() - xd.grad).abs().max()) < 1e-4 * sc(xd.grad), "d input"
+    assert float((w.grad.double() - wd.grad).abs().max()) < 2e-4 * sc(wd.grad), "d weight"
+    assert float((b.grad.double() - bd.grad).abs().max()) < 1e-4 * sc(bd.grad), "d bias"
