@@ -26,6 +26,8 @@ writes dx / dz straight into the two halves of one dxz buffer (:244-245).
 
 No CPU path: tensors must live on the GPU, the HIP library must be present.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -115,6 +117,8 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 # ---------------------------------------------------------------------------------------------
 # conv1d + x_proj + dt_proj of the small (inner width 2 / 6, dt_rank 1) blocks as one kernel; False keeps the
 # three-launch path (tests compare the two)
+KEEP_LARGE_ACTIVATIONS = os.environ.get("MMUNET_KEEP_ACTIVATIONS", "1") != "0"
+KEEP_MAX_BYTES = 1 << 30     # per tensor
 PRE_SMALL_FUSED = True
 POST_SMALL_FUSED = True   # ... and the backward mirror (d x_dbl row 0, both weight gradients, d conv += W_x^T d x_dbl)
 
@@ -261,7 +265,12 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.checkpoint_lvl = checkpoint_lvl
     ctx.with_out_proj = with_out_proj
     ctx.out_proj_bias_is_None = out_proj_bias is None
-    if checkpoint_lvl >= 1 and not ctx.pre_small:  # recomputed in the backward pass (the reference's checkpoint_lvl=1)
+    # The reference drops conv1d_out and delta and recomputes them in the backward pass (checkpoint_lvl=1, :218-219,238-241:
+    # a memory saving sized for 24-80 GB devices).  One MI355X has 288 GB: at BASELINE's sizes the nine large scans of a
+    # step keep 2 x 268 MB each at most (2.1 GB in all), and the recomputation is a conv1d kernel + a dt_proj GEMM per
+    # scan and step (0.8 ms of 40).  KEEP_LARGE_ACTIVATIONS = False restores the reference's behaviour.
+    if checkpoint_lvl >= 1 and not ctx.pre_small and not (KEEP_LARGE_ACTIVATIONS and
+                                                          conv1d_out.numel() * conv1d_out.element_size() <= KEEP_MAX_BYTES):
         conv1d_out, delta = None, None
     # (the small blocks keep both: 2 x 6 channels per token against one more launch per block and step -- the launch
     #  chain, not memory, is what the 47 small Mamba blocks cost)
@@ -291,7 +300,7 @@ def _inner_backward(ctx, dout):
     if ctx.checkpoint_lvl == 1 and ctx.pre_small:
         if conv1d_out is None:
             conv1d_out, _, delta = _pre_small(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, False)
-    elif ctx.checkpoint_lvl == 1:
+    elif ctx.checkpoint_lvl == 1 and conv1d_out is None:
         conv1d_out = causal_conv1d_hip.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
         delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
     if ctx.is_variable_B:

@@ -266,16 +266,47 @@ def test_mmnet_fwd_bwd_vs_reference(mode):
     # class at 27-31 %.
     names = [str(s) for s in g["gabs_names"]]
     floor = 2e-2 if mode == "eval" else 0.25
-    through_rows = ("offset_conv.", "gn_offset.", ".mamba.", ".altho")
-    bad = []
+    dev_, bad = [], []
     for nme, a, s in zip(names, g[f"{mode}_gabs"], g[f"{mode}_gabs_sens"]):
         mine = float(params[nme].grad.double().abs().sum())
-        band = max(floor, 6 * s)
-        if mode == "train" and any(t in nme or nme.endswith(t.rstrip(".")) for t in through_rows):
-            band = max(band, 0.6)
-        if abs(mine - a) > band * max(a, 1e-12) + 2e-4:
+        dev_.append(abs(mine - a) / (max(a, 1e-12) + 2e-4))
+        if abs(mine - a) > max(floor, 6 * s) * max(a, 1e-12) + 2e-4:
             bad.append((nme, a, mine))
-    assert not bad, f"{len(bad)} of {len(names)} gradient checksums off: {bad[:5]}"
+    if mode == "eval":
+        assert not bad, f"{len(bad)} of {len(names)} gradient checksums off: {bad[:5]}"
+    else:
+        # Train mode on 2 x 3 x 64 x 64 is chaotic (the deepest BatchNorms see 8 samples; the reference answers a 1e-6 input
+        # perturbation with 16 % on its own stem gradient, and d(row) of the sampler jumps when a coordinate crosses an
+        # integer): single checksums are not comparable there -- whichever kernel produced the last bit.  This fixture
+        # keeps the aggregate (half of all checksums within 2 %, nine in ten within 15 %); the per-parameter comparison in
+        # train mode is test_mmnet_train_mode_128_vs_reference (4 x 128 x 128: 64 samples per channel, every checksum).
+        dv = np.sort(np.array(dev_))
+        assert dv[len(dv) // 2] < 0.02 and dv[int(0.9 * len(dv))] < 0.15, (dv[len(dv) // 2], dv[int(0.9 * len(dv))])
+
+
+def test_mmnet_train_mode_128_vs_reference():
+    """Train-mode forward + Dice+BCE + backward of MM_Net against the reference at a size where train mode is
+    comparable (fixture mmnet_128_train, tools/make_golden_modules.py:make_mmnet_train128: 4 x 3 x 128 x 128, deepest maps
+    4 x 4): logits, loss, the live set, and the |grad| sum of EVERY live parameter -- no allowance for a fraction of them.
+    Band per parameter: 6 x the reference's own response to 1e-5 input noise (the size of the matrix-core convolutions'
+    2^-16 hi/lo-split error), at least 2 %; absolute floor 2e-4 for the analytically-zero GroupNorm biases."""
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    g = golden("mmnet_128_train")
+    m = _mmnet().train()
+    lt = m(torch.from_numpy(g["xb"]).to(DEV))
+    close(lt, g["logits"], 1e-3, max(1e-3, 4 * float(g["logits_sens5"])), "train logits")
+    loss = DICE_BCE_Loss()(lt, torch.from_numpy(g["tb"]).to(DEV))
+    assert abs(float(loss) - float(g["loss"])) < max(1e-4, float(g["logits_sens5"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    names = [str(s) for s in g["gabs_names"]]
+    assert {k for k, p in params.items() if p.grad is not None} == set(names)
+    bad = []
+    for nme, a, s in zip(names, g["gabs"], g["gabs_sens5"]):
+        mine = float(params[nme].grad.double().abs().sum())
+        if abs(mine - a) > max(2e-2, 6 * s) * max(a, 1e-12) + 2e-4:
+            bad.append((nme, float(a), mine, float(s)))
+    assert not bad, f"{len(bad)} of {len(names)} gradient checksums off: {bad[:8]}"
 
 
 def test_unet_gpu_vs_reference():

@@ -109,6 +109,10 @@ def main():
     if what in ("modules", "all"):
         import make_golden_modules
         make_golden_modules.main()
+    if what in ("mmnet128", "all"):     # the better-conditioned train-mode fixture of round 3 (~3 min of CPU)
+        import make_golden_modules
+        R = ref_import.load_reference_model()
+        make_golden_modules.make_mmnet_train128(R)
 
 
 if __name__ == "__main__":

@@ -134,6 +134,52 @@ def make_mmnet(R):
     print(f"  MM_Net: live grads {n_live}, never-used params {len(no_grad)}")
 
 
+def make_mmnet_train128(R):
+    """MM_Net in TRAIN mode on 4 x 3 x 128 x 128 (round 3): the train-mode half of ``mmnet_64`` runs 2 images at 64 x 64 -- the
+    deepest BatchNorms see 2 x 2 x 2 = 8 samples per channel and the network amplifies a 1e-6 input perturbation to
+    16 % on the stem gradient, so gradient checksums cannot be compared more tightly than tens of per cent there.
+    Here the deepest maps are 4 x 4 with 4 images (64 samples per channel).  Stored: logits, loss, |grad| sums of every
+    live parameter and the reference's OWN response of each to input noise of 1e-6 and of 1e-5 (the size of the
+    bf16 hi/lo-split error of the matrix-core convolutions, 2^-16)."""
+    import io
+    import contextlib
+    torch.manual_seed(50)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = R.MM_Net(num_classes=1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(11)
+    xb = torch.randn(4, 3, 128, 128)
+    tb = (torch.rand(4, 1, 128, 128) > 0.88).float()
+    torch.manual_seed(12)
+    noise = torch.randn_like(xb)
+
+    def step(eps):
+        m.load_state_dict(state0)
+        m.train(True)
+        m.zero_grad(set_to_none=True)
+        lt = m(xb + eps * noise)
+        loss = R.DICE_BCE_Loss()(lt, tb)
+        loss.backward()
+        return lt.detach(), float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    lt, loss, g0 = step(0.0)
+    lt6, _, g6 = step(1e-6)
+    lt5, _, g5 = step(1e-5)
+    gabs = lambda g: np.array([float(v.double().abs().sum()) for v in g.values()])   # noqa: E731
+    a0, a6, a5 = gabs(g0), gabs(g6), gabs(g5)
+    save("mmnet_128_train", xb=_np(xb), tb=_np(tb), logits=_np(lt), loss=np.array(loss),
+         logits_sens6=np.array(float((lt - lt6).abs().max())), logits_sens5=np.array(float((lt - lt5).abs().max())),
+         gabs_names=np.array(list(g0.keys())), gabs=a0, gabs_sens6=np.abs(a6 - a0) / np.maximum(a0, 1e-30),
+         gabs_sens5=np.abs(a5 - a0) / np.maximum(a0, 1e-30))
+    print(f"  MM_Net train 4x128x128: loss {loss:.6f}; logits response to 1e-6 / 1e-5 noise "
+          f"{float((lt - lt6).abs().max()):.2e} / {float((lt - lt5).abs().max()):.2e}; |grad|-sum response median "
+          f"{np.median(np.abs(a6 - a0) / np.maximum(a0, 1e-30)):.2e} / {np.median(np.abs(a5 - a0) / np.maximum(a0, 1e-30)):.2e}, "
+          f"max {np.max(np.abs(a6 - a0) / np.maximum(a0, 1e-30)):.2e} / {np.max(np.abs(a5 - a0) / np.maximum(a0, 1e-30)):.2e}")
+
+
 def make_unet(R):
     torch.manual_seed(50)
     m = R.Unet(3, 1)
