@@ -1,6 +1,7 @@
 """Steady-state per-step kernel breakdown from a rocprofv3 kernel_trace.csv of bench.py:
 steps are delimited by the fused-AdamW kernel; the first `skip` steps (warm-up, MIOpen find) are dropped.
-usage: python tools/prof_steady.py <dir> [skip_steps=1] [top=45]"""
+usage: python tools/prof_steady.py <dir> [skip_steps=1] [top=45] [detail_regex]
+(detail_regex: those kernels again, split by launch grid -- one line per distinct shape)"""
 import glob, re, sys
 import pandas as pd
 d = sys.argv[1]
@@ -38,3 +39,21 @@ print(f"GEMM(rocBLAS) {cat('^GEMM'):.1f} | conv(MIOpen/ck/igemm) {cat('igemm|mio
       f"morph {cat('morph_|zigzag_|coords_'):.1f} | norm(own nf_*) {cat('nf_'):.1f} | norm(library) "
       f"{cat('BatchNorm|Rowwise|GroupNorm|ComputeInternal|batch_norm'):.1f} | small conv3x3 {cat('conv3x3s_'):.1f} | "
       f"matrix-core conv/GEMM {cat('conv3x3_mfma|conv3x3_wgrad_mfma|gemm_tokens'):.1f} | small Mamba pre/post {cat('mamba_pre|mamba_post'):.1f}")
+
+if len(sys.argv) > 4:
+    gx = [c for c in sub.columns if c.lower() in ('grid_size_x', 'grid_size_y', 'grid_size_z', 'grid_size', 'workgroup_size_x', 'lds_block_size')]
+    det = sub[sub.s.str.contains(sys.argv[4])]
+    print('\nby launch grid:', gx)
+    gd = det.groupby(['s'] + gx).dur.agg(['sum', 'count']).sort_values('sum', ascending=False)
+    for key, r in gd.iterrows():
+        print(f"{r['sum']/1e6/n_steps:8.3f} ms/step  calls/step {r['count']/n_steps:5.1f}  avg {r['sum']/r['count']/1e3:9.1f} us  {key[0][:60]}  {key[1:]}")
+
+# the launch sequence of ONE steady step (name, grid, duration), for reading who follows whom
+seq_path = d.rstrip('/') + '_step_sequence.txt'
+lo_, hi_ = ends[-2] + 1, ends[-1] + 1
+with open(seq_path, 'w') as fh:
+    t0 = df.Start_Timestamp[lo_]
+    for i in range(lo_, hi_):
+        r = df.iloc[i]
+        fh.write(f"{(r.Start_Timestamp - t0)/1e3:10.1f} us  {(r.End_Timestamp - r.Start_Timestamp)/1e3:8.1f} us  "
+                 f"grid ({r.Grid_Size_X},{r.Grid_Size_Y},{r.Grid_Size_Z}) wg {r.Workgroup_Size_X}  {short(r.Kernel_Name)}\n")
