@@ -7,7 +7,11 @@
     from causal_conv1d import causal_conv1d_fn                    # mamba_simple.py:14
     import selective_scan_cuda, causal_conv1d_cuda                # selective_scan_interface.py:10-11
 
-Only ``sys.modules`` entries are added; nothing is installed or patched on disk.
+    import monai                                                  # train.py:7 -- ONLY if MONAI itself is absent
+
+Only ``sys.modules`` entries are added; nothing is installed or patched on disk.  The MONAI names train.py uses
+(sliding-window inferer, post-transforms, the seven metrics, DiceFocalLoss: monai_shim.py) are registered only when no
+real ``monai`` can be imported.
 """
 import sys
 import types
@@ -46,3 +50,8 @@ def install(force=False):
     put("mamba_ssm.ops.selective_scan_interface", selective_scan_interface)
     put("mamba_ssm.modules", mods)
     put("mamba_ssm.modules.mamba_simple", mamba_simple)
+    if "monai" not in sys.modules:
+        import importlib.util
+        if importlib.util.find_spec("monai") is None:
+            from . import monai_shim
+            monai_shim.install(put)
