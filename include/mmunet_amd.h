@@ -382,7 +382,9 @@ int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream);
  * transposed_weight = 0: weight is [rows][inner] with leading dimension w_ld; 1: weight is [inner][rows] (w_ld its
  * leading dimension) and is read transposed.  MMConv's dsc_conv_x on the sampler output (src/UM_Net/MMUNet.py:262):
  * forward = (Cout x 3Cin) . samples, input gradient = transposed weight . dout.
- * workspace: mmu_gemm_tokens_workspace_bytes() bytes, 16-byte aligned. */
+ * workspace: mmu_gemm_tokens_workspace_bytes() bytes, 16-byte aligned.
+ * weight = NULL: the workspace ALREADY holds this weight's bf16 hi/lo image, written by mmu_gemm_tokens_prepare_batch
+ * for the same (rows, inner, transposed_weight); the call then launches the product alone. */
 typedef struct {
     int32_t rows, inner, tokens, batch, transposed_weight;
     const float *weight;  int64_t w_ld;
@@ -393,6 +395,11 @@ typedef struct {
 
 size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner);
 int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream);
+/* The weight images of MANY products in one launch (a model prepares all its DSC weights once per forward pass).
+ * table: DEVICE array of n_items rows of six int64 {weight pointer, its leading dimension, image pointer (16-byte
+ * aligned, mmu_gemm_tokens_workspace_bytes(rows, inner) bytes), rows, inner, transposed_weight}; max_elements = the
+ * largest rows * inner among them.  The caller has checked rows % 64 == 0 and inner % 16 == 0 for every row. */
+int mmu_gemm_tokens_prepare_batch(const int64_t *table, int n_items, int64_t max_elements, void *stream);
 
 /* ---- C (m x n) = sum over tokens of A[i][t] * B[j][t]: token-contraction ("NT") product on the fp32 matrix cores - */
 /* The weight gradient of every projection applied per token: in_proj / out_proj / x_proj / dt_proj of the Mamba blocks

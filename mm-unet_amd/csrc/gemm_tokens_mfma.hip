@@ -67,6 +67,31 @@ __global__ __launch_bounds__(256) void gemm_tokens_prep_kernel(const float *__re
     out[base + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
 }
 
+// The same images for MANY weights in one launch (mmu_gemm_tokens_prepare_batch): blockIdx.y picks a row of the device
+// table {weight, leading dimension, image, rows, inner, transposed} (6 x int64).  MM_Net prepares the DSC weights of all
+// its MMConv blocks -- both orientations -- once per forward pass instead of one 4.8 us launch in front of each product.
+__global__ __launch_bounds__(256) void gemm_tokens_prep_batch_kernel(const long *__restrict__ table) {
+    const long *row = table + 6 * (long)blockIdx.y;
+    const float *w = reinterpret_cast<const float *>(row[0]);
+    const long ldw = row[1];
+    unsigned short *out = reinterpret_cast<unsigned short *>(row[2]);
+    const int M = (int)row[3], K = (int)row[4], trans = (int)row[5];
+    const long n = (long)M * K;
+    const int nch = K / CK;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int k8 = (int)(idx & 7), rw = (int)((idx >> 3) & 63), half = (int)((idx >> 9) & 1);
+        const long r = idx >> 10;
+        const int ch = (int)(r % nch), mt = (int)(r / nch);
+        const int m = mt * 64 + rw, k = ch * CK + half * 8 + k8;
+        const float v = trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k];
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        const long base = ((long)(mt * nch + ch) * 2) * (2 * 64 * 8) + ((long)half * 64 + rw) * 8 + k8;
+        out[base] = __builtin_bit_cast(unsigned short, h);
+        out[base + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
 struct GemmArgs {
     const float *x;
     const unsigned short *wp;
@@ -234,13 +259,15 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     MMU_CHECK(p->tokens % 4 == 0 && p->x_rs % 4 == 0 && p->x_bs % 4 == 0 && ((uintptr_t)p->x & 15) == 0,
               "gemm_tokens_mfma: tokens, x_rs, x_bs must be multiples of 4 and x 16-byte aligned");
     MMU_CHECK((long)p->inner * p->x_rs * 4 < (1L << 31), "gemm_tokens_mfma: x rows span more than 2 GB");
-    MMU_CHECK(p->weight && p->x && p->out && p->workspace, "gemm_tokens_mfma: weight, x, out, workspace are required");
+    MMU_CHECK(p->x && p->out && p->workspace, "gemm_tokens_mfma: x, out, workspace are required");
     MMU_CHECK(((uintptr_t)p->workspace & 15) == 0, "gemm_tokens_mfma: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long nw = (long)p->rows * p->inner;
-    gemm_tokens_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->weight, p->w_ld, (unsigned short *)p->workspace,
-                                                                         p->rows, p->inner, p->transposed_weight ? 1 : 0);
-    MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma(prep)");
+    if (p->weight) {   // NULL: the workspace already holds this weight's image (mmu_gemm_tokens_prepare_batch)
+        gemm_tokens_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->weight, p->w_ld, (unsigned short *)p->workspace,
+                                                                             p->rows, p->inner, p->transposed_weight ? 1 : 0);
+        MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma(prep)");
+    }
     static unsigned long long attr_mask = 0;  // per device
     if (hipError_t e = mmu_set_lds_once(gemm_tokens_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
         return mmu_fail("gemm_tokens_mfma: LDS attribute: %s", hipGetErrorString(e));
@@ -257,5 +284,16 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     const int grid = total < n_cu ? (int)total : n_cu;   // persistent: one workgroup per CU (register-bound: 2 waves/SIMD)
     gemm_tokens_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma");
+    return 0;
+}
+
+extern "C" int mmu_gemm_tokens_prepare_batch(const int64_t *table, int n_items, int64_t max_elements, void *stream) {
+    MMU_CHECK(table != nullptr && n_items > 0 && n_items <= 65535 && max_elements > 0,
+              "gemm_tokens_prepare_batch: need a device table, 1..65535 items and the largest rows * inner");
+    static_assert(sizeof(long) == sizeof(int64_t), "the table is read as long");
+    const long blocks = (max_elements + 255) / 256;
+    dim3 grid((unsigned)(blocks < 64 ? blocks : 64), (unsigned)n_items);
+    gemm_tokens_prep_batch_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const long *>(table));
+    MMU_HIP_LAUNCH_CHECK("gemm_tokens_prepare_batch");
     return 0;
 }

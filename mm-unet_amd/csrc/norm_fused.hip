@@ -672,6 +672,388 @@ __global__ __launch_bounds__(256) void nf_apply_bwd_fused_kernel(FinArgs p, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small activations: ONE kernel each way.  On 16 x 16 / 32 x 32 maps (24 of MM-UNet's 47 MMConv blocks, two normalisations
+// each) the moments pass and the apply pass are a few workgroups' work each and cost the ~4.6 us dependent-launch floor
+// twice.  Here workgroup g owns GroupNorm group g for EVERY batch item -- all the rows that meet in the group statistics
+// and in its channels' BatchNorm statistics -- so the whole normalisation is local to it: moments of its B * C/G rows
+// (a wave per row), the per-row constants (the algebra of nf_fwd_constants / nf_bwd_constants for all its rows at once,
+// same order of operations and the same float roundings of the saved statistics), then the apply pass over the same rows,
+// which are still in L2.  Taken when B * C/G <= 64 rows of together <= 65,536 elements (nf_one_ok).
+constexpr int ONE_FWD_THREADS = 512, ONE_FWD_WAVES = ONE_FWD_THREADS / 64;
+constexpr int ONE_ITEMS = 32, ONE_BWD_ITEMS = 16;   // float4 items a lane holds: x forward; x and g2 backward
+// (16 waves x 16 items spilled 32 VGPRs under the 128-register cap of a 1,024-thread workgroup)
+
+// A wave's rows are w, w + 8, ...; a row is ipr = ceil(HW / 256) float4 items per lane; nf_one_ok guarantees
+// rows_per_wave * ipr <= ONE_ITEMS, so the forward keeps its x in registers between the moments and the apply phase.
+// Every parameter the algebra needs is fetched at the top (the loads fly together with those of x): after the first
+// barrier nothing waits for global memory again.
+template <typename xin_t, typename act_t, int IPR>
+__global__ __launch_bounds__(ONE_FWD_THREADS) void nf_one_fwd_kernel(FinArgs p, const xin_t *__restrict__ x,
+                                                                    act_t *__restrict__ out, const act_t *__restrict__ res,
+                                                                    int act) {
+    // IPR: float4 items per lane and row (a power of two >= ceil(HW / 256)); RPW rows per wave at most
+    constexpr int RPW = ONE_ITEMS / IPR < 8 ? ONE_ITEMS / IPR : 8;   // (64 rows at most: 8 per wave)
+    __shared__ double S1[64], S2[64], sh_mu[64], sh_rs[64];
+    __shared__ float sh_m[64], sh_rb[64], shA[64], shD[64];
+    const int cpg = p.C / p.G, g = blockIdx.x, rows = p.B * cpg;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n4 = p.HW / 4;
+    const double n = (double)cpg * p.HW, N = (double)p.B * p.HW;
+    // ---- parameters of this thread's row (tid < rows) / channel (tid < cpg)
+    float gwf = 1.f, gbf = 0.f, bwf = 1.f, bbf = 0.f, pbf = 0.f, rmf = 0.f, rvf = 1.f;
+    if (tid < rows) {
+        const int c = g * cpg + tid % cpg;
+        if (p.gn_w) gwf = p.gn_w[c];
+        if (p.gn_b) gbf = p.gn_b[c];
+        if (p.has_bn && p.bn_w) bwf = p.bn_w[c];
+        if (p.has_bn && p.bn_b) bbf = p.bn_b[c];
+        if (p.pre_bias) pbf = p.pre_bias[c];
+        if (tid < cpg && p.has_bn && p.run_mean) {
+            rmf = p.run_mean[c];
+            rvf = p.run_var[c];
+        }
+    }
+    // ---- x of this wave's rows -> registers (clamped addresses, no branches: every load is in flight before the first
+    //      use); raw moments per row
+    float xr[RPW][IPR][4];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = w + ONE_FWD_WAVES * q;
+        const int rr = r < rows ? r : 0;
+        const xin_t *xp = x + ((long)(rr / cpg) * p.C + g * cpg + rr % cpg) * p.HW;
+#pragma unroll
+        for (int k = 0; k < IPR; ++k) {
+            const int i = lane + 64 * k;
+            load_k<xin_t, 4, true>(xp + 4 * (i < n4 ? i : 0), 4, true, xr[q][k]);
+            const bool ok = r < rows && i < n4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[q][k][j] = ok ? xr[q][k][j] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = w + ONE_FWD_WAVES * q;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < IPR; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s1 += xr[q][k][j];
+                s2 = fmaf(xr[q][k][j], xr[q][k][j], s2);
+            }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0 && r < rows) {
+            S1[r] = s1;
+            S2[r] = s2;
+        }
+    }
+    __syncthreads();
+    if (tid < rows) {   // moments of x + pre_bias (rounded to float as the two-pass kernels store them), saved
+        float s1 = (float)S1[tid], s2 = (float)S2[tid];
+        if (p.pre_bias) {
+            const double bv = pbf, d1 = s1, d2 = s2;
+            s1 = (float)(d1 + bv * p.HW);
+            s2 = (float)(d2 + 2 * bv * d1 + bv * bv * p.HW);
+            S1[tid] = s1;
+            S2[tid] = s2;
+        }
+        const int bc = (tid / cpg) * p.C + g * cpg + tid % cpg;
+        p.s1[bc] = s1;
+        p.s2[bc] = s2;
+    }
+    __syncthreads();
+    // ---- constants of every row of the group
+    if (tid < p.B) {
+        double mu = 0, rs = 1;
+        if (p.has_gn) {
+            double a1 = 0, a2 = 0;
+            for (int j = 0; j < cpg; ++j) {
+                a1 += S1[tid * cpg + j];
+                a2 += S2[tid * cpg + j];
+            }
+            mu = a1 / n;
+            double var = a2 / n - mu * mu;
+            var = var < 0 ? 0 : var;
+            rs = 1.0 / sqrt(var + (double)p.eps_g);
+        }
+        const float muf = (float)mu, rsf = (float)rs;   // the float values the backward reads back
+        sh_mu[tid] = muf;
+        sh_rs[tid] = rsf;
+        p.mu[tid * p.G + g] = muf;
+        p.rstd[tid * p.G + g] = rsf;
+    }
+    __syncthreads();
+    if (tid < cpg && p.has_bn) {
+        const int c = g * cpg + tid;
+        const double gw = gwf, gb = gbf;
+        double m, rb;
+        if (p.training) {
+            double sm = 0, sq = 0;
+            for (int bb = 0; bb < p.B; ++bb) {
+                const double ab = gw * sh_rs[bb], db = gb - ab * sh_mu[bb];
+                const double s1 = S1[bb * cpg + tid], s2 = S2[bb * cpg + tid];
+                sm += ab * s1 + db * p.HW;
+                sq += ab * ab * s2 + 2 * ab * db * s1 + db * db * p.HW;
+            }
+            m = sm / N;
+            double v = sq / N - m * m;
+            v = v < 0 ? 0 : v;
+            rb = 1.0 / sqrt(v + (double)p.eps_b);
+            if (p.run_mean) {
+                p.run_mean[c] = (float)((1.0 - p.momentum) * rmf + p.momentum * m);
+                p.run_var[c] = (float)((1.0 - p.momentum) * rvf + p.momentum * v * (N > 1 ? N / (N - 1) : 1.0));
+            }
+        } else {
+            m = rmf;
+            rb = 1.0 / sqrt((double)rvf + (double)p.eps_b);
+        }
+        const float mf = (float)m, rf = (float)rb;
+        p.bmean[c] = mf;
+        p.brstd[c] = rf;
+        sh_m[tid] = mf;
+        sh_rb[tid] = rf;
+    }
+    __syncthreads();
+    if (tid < rows) {
+        const int bb = tid / cpg, j = tid % cpg, c = g * cpg + j;
+        const double gw = gwf, gb = gbf;
+        double a = gw * sh_rs[bb], d = gb - a * sh_mu[bb];
+        if (p.has_bn) {
+            const double k = (double)bwf * sh_rb[j];
+            d = (d - sh_m[j]) * k + (double)bbf;
+            a = a * k;
+        }
+        if (p.pre_bias) d += a * (double)pbf;
+        p.A[bb * p.C + c] = (float)a;
+        p.D[bb * p.C + c] = (float)d;
+        shA[tid] = (float)a;
+        shD[tid] = (float)d;
+    }
+    __syncthreads();
+    // ---- apply, from the registers
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = w + ONE_FWD_WAVES * q;
+        if (r < rows) {
+            const long rbase = ((long)(r / cpg) * p.C + g * cpg + r % cpg) * p.HW;
+            const float Av = shA[r], Dv = shD[r];
+#pragma unroll
+            for (int k = 0; k < IPR; ++k) {
+                const int i = lane + 64 * k;
+                if (i < n4) {
+                    float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (res) load_k<act_t, 4, true>(res + rbase + 4 * i, 4, true, rv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(Av, xr[q][k][j], Dv) + rv[j], act);
+                    store_k<act_t, 4, true>(out + rbase + 4 * i, 4, true, o);
+                }
+            }
+        }
+    }
+}
+
+template <typename xin_t, typename act_t, int IPR>
+__global__ __launch_bounds__(ONE_FWD_THREADS) void nf_one_bwd_kernel(FinArgs p, const xin_t *__restrict__ x,
+                                                                    const act_t *__restrict__ dout, xin_t *__restrict__ dx,
+                                                                    int act, int out_cb_batch, const act_t *__restrict__ res,
+                                                                    act_t *__restrict__ dres) {
+    // x and g2 = dout * act' of this wave's rows stay in registers between the two phases (ONE_BWD_ITEMS float4 each)
+    constexpr int RPW = ONE_BWD_ITEMS / IPR < 8 ? ONE_BWD_ITEMS / IPR : 8;
+    __shared__ double T1[64], T2[64], S1[64], S2[64], U1[64], U2[64];   // [b][channel of the group]
+    __shared__ double MU[64], RS[64], M1s[64], M2s[64];                  // [b]
+    __shared__ double KK[64], EE[64], FF[64], MX[64], GW[64], GB[64], RB[64], BM[64], BW[64], PB[64];   // [channel]
+    __shared__ float shc[3][64];
+    const int cpg = p.C / p.G, g = blockIdx.x, rows = p.B * cpg;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n4 = p.HW / 4;
+    const double n = (double)cpg * p.HW, N = (double)p.B * p.HW, HW = p.HW;
+    // ---- everything the algebra reads from global memory, fetched now (in flight together with the rows)
+    if (tid < rows) {
+        const int bc = (tid / cpg) * p.C + g * cpg + tid % cpg;
+        S1[tid] = p.s1[bc];
+        S2[tid] = p.s2[bc];
+    }
+    if (tid >= 64 && tid < 64 + p.B) {
+        MU[tid - 64] = p.mu[(tid - 64) * p.G + g];
+        RS[tid - 64] = p.rstd[(tid - 64) * p.G + g];
+    }
+    if (tid >= 128 && tid < 128 + cpg) {
+        const int cc = g * cpg + tid - 128;
+        GW[tid - 128] = p.gn_w ? p.gn_w[cc] : 1.0;
+        GB[tid - 128] = p.gn_b ? p.gn_b[cc] : 0.0;
+        RB[tid - 128] = p.has_bn ? p.brstd[cc] : 1.0;
+        BM[tid - 128] = p.has_bn ? p.bmean[cc] : 0.0;
+        BW[tid - 128] = (p.has_bn && p.bn_w) ? p.bn_w[cc] : 1.0;
+        PB[tid - 128] = p.pre_bias ? p.pre_bias[cc] : 0.0;
+    }
+    // ---- rows -> registers (clamped addresses, no branches); t1 = sum g2, t2 = sum g2 x per row
+    float xr[RPW][IPR][4], gr[RPW][IPR][4];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = w + ONE_FWD_WAVES * q;
+        const int rr = r < rows ? r : 0;
+        const int bc = (rr / cpg) * p.C + g * cpg + rr % cpg;
+        const long base = (long)bc * p.HW;
+        const float Av = p.A[bc], Dv = p.D[bc];
+#pragma unroll
+        for (int k = 0; k < IPR; ++k) {
+            const int i = lane + 64 * k;
+            const long off = base + 4 * (i < n4 ? i : 0);
+            float gv[4], ov[4] = {0.f, 0.f, 0.f, 0.f};
+            load_k<xin_t, 4, true>(x + off, 4, true, xr[q][k]);
+            load_k<act_t, 4, true>(dout + off, 4, true, gv);
+            if (res) load_k<act_t, 4, true>(res + off, 4, true, ov);
+            const bool ok = r < rows && i < n4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g2 = gv[j] * (res ? (ov[j] > 0.f ? 1.f : 0.f) : act_grad(fmaf(Av, xr[q][k][j], Dv), act));
+                gr[q][k][j] = ok ? g2 : 0.f;
+                xr[q][k][j] = ok ? xr[q][k][j] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = w + ONE_FWD_WAVES * q;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < IPR; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s1 += gr[q][k][j];
+                s2 = fmaf(gr[q][k][j], xr[q][k][j], s2);
+            }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0 && r < rows) {
+            T1[r] = s1;
+            T2[r] = s2;   // (+ pre_bias * t1 below, once the prefetched bias is visible)
+        }
+    }
+    __syncthreads();
+    if (tid < rows && p.pre_bias) T2[tid] += PB[tid % cpg] * T1[tid];   // sum_hw g2 (x + bias)
+    __syncthreads();
+    if (tid < cpg) {   // per channel: exact batch mean, d(bn weight / bias), k, e, f
+        const int cc = g * cpg + tid;
+        double k = 1, e = 0, f = 0, m = 0;
+        if (p.has_bn) {
+            const double gw = GW[tid], gb = GB[tid], rb = RB[tid];
+            m = BM[tid];
+            if (p.training) {
+                double sm = 0;
+                for (int bb = 0; bb < p.B; ++bb) {
+                    const double a = gw * RS[bb], d = gb - a * MU[bb];
+                    sm += a * S1[bb * cpg + tid] + d * p.HW;
+                }
+                m = sm / N;
+            }
+            double db = 0, dg = 0;
+            for (int bb = 0; bb < p.B; ++bb) {
+                const double a = gw * RS[bb], d = gb - a * MU[bb];
+                const double pq = a * rb, qq = (d - m) * rb;
+                db += T1[bb * cpg + tid];
+                dg += pq * T2[bb * cpg + tid] + qq * T1[bb * cpg + tid];
+            }
+            if (p.dbn_w) p.dbn_w[cc] = (float)dg;
+            if (p.dbn_b) p.dbn_b[cc] = (float)db;
+            k = BW[tid] * rb;
+            if (p.training) {
+                e = db / N;
+                f = dg / N;
+            }
+        }
+        KK[tid] = k; EE[tid] = e; FF[tid] = f; MX[tid] = m;
+    }
+    __syncthreads();
+    if (tid < rows) {   // u1 = sum_hw g1, u2 = sum_hw g1 x of every row
+        const int bb = tid / cpg, j = tid % cpg;
+        const double a = GW[j] * RS[bb], d = GB[j] - a * MU[bb];
+        double pq = 0, qq = 0;
+        if (p.has_bn) {
+            pq = a * RB[j];
+            qq = (d - MX[j]) * RB[j];
+        }
+        const double k = KK[j], e = EE[j], f = FF[j];
+        U1[tid] = k * (T1[tid] - e * HW - f * (pq * S1[tid] + qq * HW));
+        U2[tid] = k * (T2[tid] - e * S1[tid] - f * (pq * S2[tid] + qq * S1[tid]));
+    }
+    __syncthreads();
+    if (tid < p.B) {   // group means of gamma g1 and gamma g1 xhat, per batch item
+        double a1 = 0, a2 = 0;
+        for (int j = 0; j < cpg; ++j) {
+            a1 += GW[j] * U1[tid * cpg + j];
+            a2 += GW[j] * RS[tid] * (U2[tid * cpg + j] - MU[tid] * U1[tid * cpg + j]);
+        }
+        M1s[tid] = p.has_gn ? a1 / n : 0.0;
+        M2s[tid] = p.has_gn ? a2 / n : 0.0;
+    }
+    __syncthreads();
+    auto consts = [&](int bb, int j, double &k0, double &k1, double &k2) {
+        const double gw = GW[j], gb = GB[j], k = KK[j], e = EE[j], f = FF[j];
+        const double mu = MU[bb], r = RS[bb];
+        const double a = gw * r, d = gb - a * mu;
+        double pq = 0, qq = 0;
+        if (p.has_bn) {
+            pq = a * RB[j];
+            qq = (d - MX[j]) * RB[j];
+        }
+        const double rgk = r * gw * k;
+        k0 = rgk;
+        k1 = -rgk * f * pq - r * r * M2s[bb];
+        k2 = -rgk * e - rgk * f * qq - r * M1s[bb] + r * r * mu * M2s[bb];
+    };
+    if (tid < rows) {
+        const int bb = tid / cpg, j = tid % cpg;
+        double k0, k1, k2;
+        consts(bb, j, k0, k1, k2);
+        shc[0][tid] = (float)k0;
+        shc[1][tid] = (float)k1;
+        shc[2][tid] = (float)(k2 + (p.pre_bias ? k1 * PB[j] : 0.0));   // in terms of the raw x
+    }
+    if (tid >= 64 && tid < 64 + cpg) {   // this channel's parameter gradients
+        const int j = tid - 64, c = g * cpg + j;
+        double dw = 0, dbv = 0, dpb = 0;
+        for (int bb = 0; bb < p.B; ++bb) {
+            const double u1 = U1[bb * cpg + j], u2 = U2[bb * cpg + j];
+            dw += RS[bb] * (u2 - MU[bb] * u1);
+            dbv += u1;
+            if (p.dpre_bias) {
+                double q0, q1, q2;
+                consts(bb, j, q0, q1, q2);
+                dpb += q0 * T1[bb * cpg + j] + q1 * S1[bb * cpg + j] + q2 * HW;   // sum_hw dx of row (bb, c)
+            }
+        }
+        if (p.dgn_w) p.dgn_w[c] = (float)dw;
+        if (p.dgn_b) p.dgn_b[c] = (float)dbv;
+        if (p.dpre_bias) p.dpre_bias[c] = (float)dpb;
+    }
+    __syncthreads();
+    // ---- dx = c0 g2 + c1 x + c2, from the registers
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = w + ONE_FWD_WAVES * q;
+        if (r < rows) {
+            const int bb = r / cpg, c = g * cpg + r % cpg;
+            const long base = ((long)bb * p.C + c) * p.HW;
+            const long obase = out_cb_batch > 0 ? ((long)c * out_cb_batch + bb) * p.HW : base;
+            const float k0 = shc[0][r], k1 = shc[1][r], k2 = shc[2][r];
+#pragma unroll
+            for (int k = 0; k < IPR; ++k) {
+                const int i = lane + 64 * k;
+                if (i < n4) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(k0, gr[q][k][j], fmaf(k1, xr[q][k][j], k2));
+                    if (dres) store_k<act_t, 4, true>(dres + base + 4 * i, 4, true, gr[q][k]);
+                    store_k<xin_t, 4, true>(dx + obase + 4 * i, 4, true, o);
+                }
+            }
+        }
+    }
+}
+
 // runtime dtype codes -> the two element types
 #define NF_TYPES(xd, ad, ...)                                   \
     do {                                                        \
@@ -718,6 +1100,22 @@ int fill(const mmu_norm_params *p, FinArgs &a, const char *name) {
 static inline int nf_moment_threads(int BC, int HW) { return (HW / 4 >= 2048 && BC <= 2048) ? 1024 : 256; }
 // apply kernels: a few thousand workgroups at most, each with >= 16 KB of its row (a block's prologue computes the row's
 // constants: too small a share and the prologue dominates)
+static inline int nf_one_ipr(int HW) {   // float4 items per lane and row, rounded up to a power of two
+    int ipr = 1;
+    while (ipr * 256 < HW) ipr *= 2;
+    return ipr;
+}
+// one kernel each way (nf_one_*): every row of a group in one workgroup, small enough to be re-read from L2
+// Measured (profiles/r03_norm_one_kernel.txt): a workgroup streams only ~16 GB/s (the bytes in flight per CU over the
+// memory latency), so a group's rows must be small -- at 128 KB per workgroup the single kernel took 15 us against 13 us
+// for the two passes on 2,048 workgroups each; at <= 64 KB (forward) / <= 32 KB (backward: x and dout) it wins.
+static inline bool nf_one_ok(const FinArgs &a, int items = ONE_ITEMS) {
+    static const bool off = []() { const char *e = getenv("MMU_NF_ONE"); return e && e[0] == '0'; }();
+    const int cpg = a.C / a.G;
+    const int rows = a.B * cpg, rpw = (rows + ONE_FWD_WAVES - 1) / ONE_FWD_WAVES;
+    return !off && (a.HW & 3) == 0 && rows <= 64 && a.B <= 64 && a.HW <= 4 * 64 * items && rpw * nf_one_ipr(a.HW) <= items &&
+           (long)rows * a.HW <= (items == ONE_ITEMS ? 16384 : 8192);
+}
 static inline int nf_apply_splits(int BC, int HW) {
     int splits = (HW / 4 + 1023) / 1024;
     while (splits > 1 && (long)splits * BC > 8192) --splits;
@@ -740,6 +1138,24 @@ extern "C" int mmu_norm_fused_fwd(const mmu_norm_params *p, void *stream) {
     // MM-UNet); otherwise in the single-workgroup kernel between the passes
     const int cpg = a.C / a.G;
     const bool fused = (a.HW & 3) == 0 && a.B * cpg <= 64 && a.B <= 64 && getenv("MMU_NF_FINALIZE_KERNEL") == nullptr;
+    if (nf_one_ok(a) && !(p->has_bn && !p->training && !(p->running_mean && p->running_var))) {
+#define NF_ONE_FWD(I)                                                                                                  \
+    nf_one_fwd_kernel<xin_t, act_t, I><<<a.G, ONE_FWD_THREADS, 0, st>>>(a, (const xin_t *)p->input, (act_t *)p->out, \
+                                                                        (const act_t *)p->residual, p->act)
+        NF_TYPES(p->x_dtype, p->act_dtype, {
+            switch (nf_one_ipr(a.HW)) {
+                case 1: NF_ONE_FWD(1); break;
+                case 2: NF_ONE_FWD(2); break;
+                case 4: NF_ONE_FWD(4); break;
+                case 8: NF_ONE_FWD(8); break;
+                case 16: NF_ONE_FWD(16); break;
+                default: NF_ONE_FWD(32); break;
+            }
+        });
+#undef NF_ONE_FWD
+        MMU_HIP_LAUNCH_CHECK("norm_fused_fwd(one)");
+        return 0;
+    }
     NF_TYPES(p->x_dtype, p->act_dtype, {
         nf_moments_kernel<false, xin_t, act_t><<<BC, nf_moment_threads(BC, a.HW), 0, st>>>((const xin_t *)p->input, nullptr, nullptr, nullptr, p->s1,
                                                                   p->s2, a.HW, 0, nullptr, fused ? p->pre_bias : nullptr,
@@ -780,6 +1196,24 @@ extern "C" int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream) {
     dim3 grid((a.HW + 1023) / 1024, BC);
     const int cpg = a.C / a.G;
     const bool fused = (a.HW & 3) == 0 && a.B * cpg <= 64 && a.B <= 64 && getenv("MMU_NF_FINALIZE_KERNEL") == nullptr;
+    if (nf_one_ok(a, ONE_BWD_ITEMS)) {
+#define NF_ONE_BWD(I)                                                                                      \
+    nf_one_bwd_kernel<xin_t, act_t, I><<<a.G, ONE_FWD_THREADS, 0, st>>>(                                   \
+        a, (const xin_t *)p->input, (const act_t *)p->dout, (xin_t *)p->dinput, p->act,                    \
+        p->dinput_channel_major ? a.B : 0, (const act_t *)p->act_out, (act_t *)p->dresidual)
+        NF_TYPES(p->x_dtype, p->act_dtype, {
+            switch (nf_one_ipr(a.HW)) {
+                case 1: NF_ONE_BWD(1); break;
+                case 2: NF_ONE_BWD(2); break;
+                case 4: NF_ONE_BWD(4); break;
+                case 8: NF_ONE_BWD(8); break;
+                default: NF_ONE_BWD(16); break;
+            }
+        });
+#undef NF_ONE_BWD
+        MMU_HIP_LAUNCH_CHECK("norm_fused_bwd(one)");
+        return 0;
+    }
     NF_TYPES(p->x_dtype, p->act_dtype, {
         nf_moments_kernel<true, xin_t, act_t><<<BC, nf_moment_threads(BC, a.HW), 0, st>>>((const xin_t *)p->input, (const act_t *)p->dout, a.A, a.D,
                                                                  t1, t2, a.HW, p->act, (const act_t *)p->act_out, nullptr, a.C);

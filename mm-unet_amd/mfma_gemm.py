@@ -20,9 +20,79 @@ def supported(rows, inner, tokens, *tensors):
             and all(t.is_cuda and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 for t in tensors))
 
 
-def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, out_bs, transposed_weight=False):
+_PREPARED = {}   # (weight data_ptr, rows, inner, transposed) -> uint8 image; alive only inside a prepared_weights block
+
+
+class prepared_weights:
+    """``with prepared_weights(weights):`` -- the bf16 hi/lo images ``gemm_tokens`` multiplies with, for every 2-D float32
+    weight in the list and both orientations (``W . X`` and ``W^T . G``), written by ONE launch on entry instead of one
+    4.8 us launch in front of each product (MM_Net: 48 per training step).  Inside the block ``gemm_tokens`` finds the
+    image by the weight's address; ``prepared_for`` hands a caller the transposed image to keep for its backward pass
+    (which runs after the block has been left -- the arena is only rewritten by the next entry, i.e. by the next forward
+    pass, after the weights may have changed).  The table of addresses is built once: parameters keep their storage."""
+
+    def __init__(self, weights_fn):
+        # weights_fn() -> the weights as they are NOW (parameters may have been moved or replaced since the last pass);
+        # each is read as the (shape[0], numel / shape[0]) matrix of its contiguous storage
+        self.weights_fn = weights_fn
+        self.weights = []
+        self._key = None
+        self._images = {}
+        self._table = None
+        self._arena = None
+        self._max = 0
+
+    def _build(self):
+        dev = self.weights[0].device
+        L = _lib.lib()
+        items, off = [], 0
+        for w in self.weights:
+            m, k = w.shape[0], w.numel() // w.shape[0]
+            for rows, inner, trans in ((m, k, 0), (k, m, 1)):
+                if rows % 64 == 0 and inner % 16 == 0:
+                    nbytes = (int(L.mmu_gemm_tokens_workspace_bytes(rows, inner)) + 255) // 256 * 256
+                    items.append((w, rows, inner, trans, off, nbytes))
+                    off += nbytes
+        self._arena = torch.empty(max(off, 16), device=dev, dtype=torch.uint8)
+        rows_ = []
+        self._images = {}
+        for w, rows, inner, trans, o, nbytes in items:
+            img = self._arena[o:o + nbytes]
+            self._images[(w.data_ptr(), rows, inner, trans)] = img
+            rows_.append([w.data_ptr(), w.numel() // w.shape[0], img.data_ptr(), rows, inner, trans])
+            self._max = max(self._max, rows * inner)
+        self._table = torch.tensor(rows_, dtype=torch.int64).to(dev) if rows_ else None
+        self._key = tuple(w.data_ptr() for w in self.weights)
+
+    def __enter__(self):
+        ws = self.weights = [w for w in self.weights_fn() if w.dtype == torch.float32 and w.is_contiguous()]
+        if not ENABLED or not ws or not all(w.is_cuda for w in ws) or torch.is_autocast_enabled():
+            return self
+        if self._key != tuple(w.data_ptr() for w in ws):   # first use, or the parameters were moved / reloaded
+            self._build()
+        if self._table is not None:
+            dev = ws[0].device
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().mmu_gemm_tokens_prepare_batch(self._table.data_ptr(), self._table.shape[0], self._max,
+                                                                    torch.cuda.current_stream(dev).cuda_stream))
+            _PREPARED.update(self._images)
+        return self
+
+    def __exit__(self, *exc):
+        _PREPARED.clear()
+        return False
+
+
+def prepared_for(weight, rows, inner, transposed_weight):
+    """The prepared image of ``weight`` for this orientation, or None (outside a prepared_weights block / not listed)."""
+    return _PREPARED.get((weight.data_ptr(), rows, inner, int(transposed_weight)))
+
+
+def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, out_bs, transposed_weight=False,
+                prepared=None):
     """out[b] = W . X[b]; ``weight`` is (rows, inner) -- or (inner, rows) read transposed -- with unit inner stride;
-    ``x`` / ``out`` are float32 tensors whose storage holds the strided operands described by the element strides."""
+    ``x`` / ``out`` are float32 tensors whose storage holds the strided operands described by the element strides.
+    ``prepared``: this weight's image from :class:`prepared_weights` (looked up by address when not given)."""
     _lib.require_gpu(weight, x, out)
     if weight.dtype != torch.float32 or x.dtype != torch.float32 or out.dtype != torch.float32:
         raise RuntimeError("gemm_tokens: float32 tensors required")
@@ -31,10 +101,15 @@ def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, 
     want = (inner, rows) if transposed_weight else (rows, inner)
     if tuple(weight.shape) != want:
         raise RuntimeError(f"gemm_tokens: weight shape {tuple(weight.shape)} != {want}")
-    ws = torch.empty(_lib.lib().mmu_gemm_tokens_workspace_bytes(rows, inner), device=x.device, dtype=torch.uint8)
+    if prepared is None and weight.is_contiguous():
+        prepared = prepared_for(weight, rows, inner, transposed_weight)
+    need = _lib.lib().mmu_gemm_tokens_workspace_bytes(rows, inner)
+    if prepared is not None and (prepared.numel() < need or prepared.device != x.device or prepared.dtype != torch.uint8):
+        raise RuntimeError("gemm_tokens: the prepared weight image does not belong to this product")
+    ws = prepared if prepared is not None else torch.empty(need, device=x.device, dtype=torch.uint8)
     p = _lib.GemmTokensParams()
     p.rows, p.inner, p.tokens, p.batch, p.transposed_weight = rows, inner, tokens, batch, int(transposed_weight)
-    p.weight, p.w_ld = weight.data_ptr(), weight.stride(0)
+    p.weight, p.w_ld = (None if prepared is not None else weight.data_ptr()), weight.stride(0)
     p.x, p.x_rs, p.x_bs = x.data_ptr(), x_rs, x_bs
     p.out, p.out_rs, p.out_bs = out.data_ptr(), out_rs, out_bs
     p.workspace = ws.data_ptr()

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba, neg_exp, precomputed_A
-from . import conv3x3_mfma, conv3x3_small, conv_s2, mamba_small_fused, morph_coords, norm_fused
+from . import conv3x3_mfma, conv3x3_small, conv_s2, mamba_small_fused, mfma_gemm, morph_coords, norm_fused
 from . import morph_sample as morph_sample_mod
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
@@ -433,8 +433,14 @@ class MM_Net(nn.Module):
     def forward(self, x):
         if getattr(self, "_a_batch", None) is None:
             self._a_batch = [precomputed_A(self)]   # in a list: not a sub-module, just the parameter list found once
-        # A = -exp(A_log) of all 50 Mamba blocks in two launches; the 56 BatchNorm batch counters in one
-        with self._a_batch[0], norm_fused.batched_counters():
+            # the K x 1 DSC weights as the (Cout, Cin*K) matrices dsc_gemm multiplies with
+            blocks = [m for m in self.modules() if isinstance(m, MMConv) and m.morph == 0]
+            rcgs = [m.mamba for m in self.modules() if isinstance(m, RCG)]   # their projections take the same GEMM
+            self._dsc_prep = [mfma_gemm.prepared_weights(
+                lambda: [m.dsc_conv_x.weight for m in blocks] + [w for m in rcgs for w in (m.in_proj.weight, m.out_proj.weight)])]
+        # A = -exp(A_log) of all 50 Mamba blocks in two launches; the 56 BatchNorm batch counters in one; the bf16 hi/lo
+        # images of the 47 DSC weights (both orientations) in one
+        with self._a_batch[0], norm_fused.batched_counters(), self._dsc_prep[0]:
             return self._forward(x)
 
     def _forward(self, x):

@@ -83,6 +83,8 @@ class _DscGemmFn(torch.autograd.Function):
         T = samples.shape[1] // batch
         ctx.save_for_backward(W2, samples)
         ctx.batch = batch
+        # inside MM_Net's prepared_weights block: the image of W2^T for the input gradient, kept for the backward pass
+        ctx.prep_t = mfma_gemm.prepared_for(W2, I, O, True) if W2.is_contiguous() else None
         if mfma_gemm.supported(O, I, batch * T, W2, samples) and W2.stride(1) == 1 and samples.is_contiguous() \
                 and T % 4 == 0:
             out = torch.empty((batch, O, T), device=samples.device, dtype=torch.float32)
@@ -111,14 +113,16 @@ class _DscGemmFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if inplace and mfma_gemm.supported(I, O, B * T, W2, G):
                 dX = torch.empty((I, B * T), device=G.device, dtype=torch.float32)
-                mfma_gemm.gemm_tokens(W2, G, dX, I, O, T, B, T, O * T, B * T, T, transposed_weight=True)
+                mfma_gemm.gemm_tokens(W2, G, dX, I, O, T, B, T, O * T, B * T, T, transposed_weight=True,
+                                      prepared=ctx.prep_t)
             else:
                 if G2 is None:
                     G2 = G.permute(1, 0, 2).reshape(O, -1)
                 if mfma_gemm.supported(I, O, G2.shape[1], W2, G2) and W2.stride(1) == 1 and G2.is_contiguous():
                     NT = G2.shape[1]
                     dX = torch.empty((I, NT), device=G2.device, dtype=torch.float32)
-                    mfma_gemm.gemm_tokens(W2, G2, dX, I, O, NT, 1, NT, 0, NT, 0, transposed_weight=True)
+                    mfma_gemm.gemm_tokens(W2, G2, dX, I, O, NT, 1, NT, 0, NT, 0, transposed_weight=True,
+                                          prepared=ctx.prep_t)
                 else:
                     dX = W2.t() @ G2
         return dW, dX, None
@@ -172,6 +176,8 @@ class _ProjBclFn(torch.autograd.Function):
                 torch.mm(W, X[b], out=out[b])
         ctx.save_for_backward(W, X)
         ctx.to_cb = to_cb
+        # (inside a prepared_weights block: W^T's image for the input gradient, see _DscGemmFn)
+        ctx.prep_t = mfma_gemm.prepared_for(W, I, O, True) if W.dim() == 2 and W.is_contiguous() else None
         return out
 
     @staticmethod
@@ -188,7 +194,7 @@ class _ProjBclFn(torch.autograd.Function):
                 dX = torch.empty((I, B, L), device=X.device, dtype=X.dtype).permute(1, 0, 2)
             if _mfma_ok(I, W.shape[0], B, L, W, G, dX):
                 mfma_gemm.gemm_tokens(W, G, dX, I, W.shape[0], L, B, G.stride(1), G.stride(0), dX.stride(1),
-                                      dX.stride(0), transposed_weight=True)
+                                      dX.stride(0), transposed_weight=True, prepared=getattr(ctx, "prep_t", None))
             else:
                 Wt = W.t()
                 for b in range(B):

@@ -639,7 +639,13 @@ def test_tri_order_split_combine(case):
                                  dict(shape=(2, 16, 9, 7), groups=4, bn=True, act=None, train=True),
                                  dict(shape=(2, 8, 8, 8), groups=2, bn=True, act="relu", train=False),
                                  dict(shape=(1, 64, 32, 32), groups=16, bn=True, act="relu", train=True),
-                                 dict(shape=(2, 4, 5, 3), groups=4, bn=False, act=None, train=True)])
+                                 dict(shape=(2, 4, 5, 3), groups=4, bn=False, act=None, train=True),
+                                 # > 65,536 elements per group: the two-pass kernels (smaller ones run nf_one_*)
+                                 dict(shape=(2, 8, 128, 96), groups=2, bn=True, act="relu", train=True, pre_bias=True),
+                                 dict(shape=(2, 8, 128, 96), groups=2, bn=False, act="tanh", train=True),
+                                 dict(shape=(8, 16, 32, 32), groups=4, bn=True, act="relu", train=True, residual=True,
+                                      pre_bias=True),
+                                 dict(shape=(8, 6, 64, 64), groups=3, bn=False, act="tanh", train=True)])
 def test_gn_bn_act_vs_modules(cfg):
     """gn_bn_act == act(BatchNorm2d(GroupNorm(x))) evaluated with the torch modules on CPU: output, input
     gradient, all four parameter gradients and the BatchNorm running statistics, training and eval mode
@@ -864,6 +870,52 @@ def test_dsc_gemm_mfma_path_matches_library_path():
     close(res[True][0], res[False][0], 1e-4, 1e-4, "out")
     close(res[True][1], res[False][1], 1e-3, 1e-3, "d weight")
     close(res[True][2], res[False][2], 1e-4, 1e-4, "d samples")
+
+
+def test_dsc_gemm_with_batch_prepared_weight_images_is_bit_identical():
+    """mfma_gemm.prepared_weights (ONE launch writes the bf16 hi/lo images of every listed weight, both orientations;
+    MM_Net.forward uses it for its 47 DSC weights): dsc_gemm inside the block == dsc_gemm outside it, bit for bit --
+    output, d samples (the transposed image, kept by the forward for a backward that runs after the block was left),
+    d weight; a weight that changes between two blocks is re-prepared; conv-shaped (4-D) weights are read as matrices."""
+    import mm_unet_amd.mfma_gemm as mg
+    from mm_unet_amd.tall_gemm import dsc_gemm
+    gen = torch.Generator().manual_seed(23)
+    shapes = [(128, 64, 3, 2, 24 * 32), (64, 64, 3, 1, 40 * 40), (64, 128, 1, 2, 512)]     # Cout, Cin, K, B, T
+    convs = [torch.nn.Parameter((torch.randn(co, ci, k, 1, generator=gen) / (ci * k) ** 0.5).to(DEV))
+             for co, ci, k, _, _ in shapes]
+    data = [(torch.randn(ci * k, b * t, generator=gen).to(DEV), torch.randn(b, co, t, generator=gen).to(DEV))
+            for co, ci, k, b, t in shapes]
+    prep = mg.prepared_weights(lambda: convs)
+    min_tiles, mg.MIN_TILES = mg.MIN_TILES, 1
+    try:
+        def run(inside):
+            outs = []
+            for w4, (S, g), (co, ci, k, b, t) in zip(convs, data, shapes):
+                w4.grad = None
+                s_ = S.clone().requires_grad_()
+                if inside:
+                    with prep:
+                        assert mg.prepared_for(w4, co, ci * k, False) is not None
+                        out = dsc_gemm(w4.view(co, -1), s_, b)
+                    assert mg.prepared_for(w4, co, ci * k, False) is None      # the lookup ends with the block
+                else:
+                    out = dsc_gemm(w4.view(co, -1), s_, b)
+                # after the block has been left; one case with the channel-major gradient the fused normalisation hands back
+                out.backward(g.permute(1, 0, 2).contiguous().permute(1, 0, 2) if t == 512 else g)
+                outs.append((out.detach().clone(), s_.grad.clone(), w4.grad.clone()))
+            return outs
+        ref = run(False)
+        for _ in range(2):
+            for (o, ds, dw), (o2, ds2, dw2) in zip(ref, run(True)):
+                assert torch.equal(o, o2) and torch.equal(ds, ds2) and torch.equal(dw, dw2)
+        with torch.no_grad():
+            for w4 in convs:
+                w4.mul_(1.5).add_(0.01)
+        ref = run(False)
+        for (o, ds, dw), (o2, ds2, dw2) in zip(ref, run(True)):
+            assert torch.equal(o, o2) and torch.equal(ds, ds2) and torch.equal(dw, dw2)
+    finally:
+        mg.MIN_TILES = min_tiles
 
 
 @pytest.mark.parametrize("to_cb", [True, False])
