@@ -1,8 +1,8 @@
 #!/bin/bash
 # BASELINE configs 3 and 5 through bench.py, each once timed and once under rocprofv3 --kernel-trace (eager) for the
-# per-kernel split.  Output under gpurun_out/r2cfg/.
+# per-kernel split.  Output under gpurun_out/<tag> (default r3cfg).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r2cfg
+out=gpurun_out/${1:-r3cfg}
 mkdir -p $out
 python3 bench.py --dtype bf16 --batch 16 --no-cpu-baseline --no-roofline > $out/c3.json 2> $out/c3.err
 python3 bench.py --size 1024 --batch 2 --dtype bf16 --d-state 64 --no-cpu-baseline --no-roofline --steps 3 > $out/c5.json 2> $out/c5.err
