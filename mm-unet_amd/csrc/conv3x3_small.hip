@@ -208,6 +208,63 @@ __global__ __launch_bounds__(256) void conv3x3s_bwd_data_kernel(const float *__r
     }
 }
 
+// bwd data, FOUR pixels per thread (W % 4 == 0).  PMC of the two-pixel kernel at [8,64,128,128]
+// (profiles/r03_conv3x3s_waves_variant_negative.txt): half of the wave cycles are issue stalls -- its two accumulators
+// are ONE packed register, i.e. a single dependent chain of 54 v_pk_fma_f32 per input channel -- and a thread moves 8
+// bytes per channel.  Four pixels give two independent chains, 16-byte loads / stores and the 3 x 6 neighbourhood of dout
+// amortised over twice the outputs.  Same grid convention with wq = W / 4.
+template <int CO, typename in_t, bool NATIVE>
+__global__ __launch_bounds__(256) void conv3x3s_bwd_data4_kernel(const float *__restrict__ g, const float *__restrict__ wt,
+                                                                 in_t *__restrict__ dx, int B, int Cin, int H, int W,
+                                                                 int cps, const in_t *__restrict__ addend) {
+    const int wq = W / 4;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)B * H * wq) return;
+    const int q = (int)(idx % (unsigned)wq);
+    const unsigned r = idx / (unsigned)wq;
+    const int h = (int)(r % (unsigned)H), b = (int)(r / (unsigned)H);
+    const int w0 = q * 4;
+    const long HW = (long)H * W;
+    const int c_lo = blockIdx.y * cps, c_hi = c_lo + cps < Cin ? c_lo + cps : Cin;
+    // gv[co][dy][j]: g at row h+dy-1, col w0+j-1 (0 outside the image); columns w0 .. w0+3 are one 16-byte load
+    float gv[CO][3][6];
+    const float *gp = g + (long)b * CO * HW;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int hh = h + dy - 1;
+        const float rmask = (hh >= 0 && hh < H) ? 1.f : 0.f;
+        const int ro = (hh < 0 ? 0 : (hh > H - 1 ? H - 1 : hh)) * W;
+        const float ml = w0 > 0 ? rmask : 0.f, mr = w0 + 4 < W ? rmask : 0.f;
+        const int ol = ro + (w0 > 0 ? w0 - 1 : 0), orr = ro + (w0 + 4 < W ? w0 + 4 : W - 1);
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const float4 c = *reinterpret_cast<const float4 *>(gp + co * HW + ro + w0);
+            gv[co][dy][1] = c.x * rmask; gv[co][dy][2] = c.y * rmask; gv[co][dy][3] = c.z * rmask; gv[co][dy][4] = c.w * rmask;
+            gv[co][dy][0] = gp[co * HW + ol] * ml;
+            gv[co][dy][5] = gp[co * HW + orr] * mr;
+        }
+    }
+    in_t *dp = dx + ((long)b * Cin + c_lo) * HW + (long)h * W + w0;
+    const in_t *ap = addend ? addend + ((long)b * Cin + c_lo) * HW + (long)h * W + w0 : nullptr;
+    for (int ci = c_lo; ci < c_hi; ++ci, dp += HW) {
+        const float *wc = NATIVE ? wt + (long)ci * 9 : wt + (long)ci * 9 * CO;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ap) load_k<in_t, 4, true>(ap + (long)(ci - c_lo) * HW, 4, true, a);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float wv = NATIVE ? wc[(long)co * Cin * 9 + ky * 3 + kx] : wc[(ky * 3 + kx) * CO + co];
+                    // pixel (h, w0 + p): g row h-ky+1 -> dy = 2-ky ; col w0+p-kx+1 -> j = p - kx + 2
+#pragma unroll
+                    for (int pxl = 0; pxl < 4; ++pxl) a[pxl] = fmaf(wv, gv[co][2 - ky][pxl + 2 - kx], a[pxl]);
+                }
+        store_k<in_t, 4, true>(dp, 4, true, a);
+    }
+}
+
 // dW[co][ci][ky][kx] += sum_{b,y,x} g[b,co,y,x] * x[b,ci,y+ky-1,x+kx-1] ;  dbias[co] += sum g
 // grid (chunks of 64*gpl groups over B*H*ceil(W/4), ceil(Cin / 4)); block 256 = 4 waves = 4 input channels;
 // lane = group of 4 consecutive pixels of a row (the 3 x 6 input neighbourhood is shared by the 4 pixels:
@@ -498,11 +555,25 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
     MMU_CHECK(p->dout && p->weight_t, "conv3x3_small_bwd: dout and weight_t are required");
     hipStream_t st = (hipStream_t)stream;
     if (p->dinput) {
-        const long total = (long)p->batch * p->height * ((p->width + 1) / 2);
-        const int splits = channel_splits(total, p->in_channels);
+        static const bool four_off = []() { const char *e = getenv("MMU_CONV3X3S_BWD4"); return e && e[0] == '0'; }();
+        const size_t esz = p->in_dtype == MMU_DTYPE_BF16 ? 2 : 4;
+        const bool four = !four_off && p->width % 4 == 0 && ((uintptr_t)p->dout & 15) == 0 &&
+                          ((uintptr_t)p->dinput & (4 * esz - 1)) == 0 &&
+                          (!p->dinput_addend || ((uintptr_t)p->dinput_addend & (4 * esz - 1)) == 0);
+        const long total = (long)p->batch * p->height * (four ? p->width / 4 : (p->width + 1) / 2);
+        // (the 54 loads of the dout neighbourhood are per thread: the four-pixel form keeps the slice count of the two-pixel one)
+        const int splits = channel_splits(four ? 2 * total : total, p->in_channels);
         const int cps = (p->in_channels + splits - 1) / splits;
         dim3 grid((unsigned)((total + 255) / 256), splits);
-        if (p->weight_native) {
+        if (four && p->weight_native) {
+            CO_DISPATCH(p->out_channels, conv3x3s_bwd_data4_kernel<CO, in_t, true><<<grid, 256, 0, st>>>(
+                                             p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
+                                             p->width, cps, (const in_t *)p->dinput_addend);)
+        } else if (four) {
+            CO_DISPATCH(p->out_channels, conv3x3s_bwd_data4_kernel<CO, in_t, false><<<grid, 256, 0, st>>>(
+                                             p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
+                                             p->width, cps, (const in_t *)p->dinput_addend);)
+        } else if (p->weight_native) {
             CO_DISPATCH(p->out_channels, conv3x3s_bwd_data_kernel<CO, in_t, true><<<grid, 256, 0, st>>>(
                                              p->dout, p->weight_t, (in_t *)p->dinput, p->batch, p->in_channels, p->height,
                                              p->width, cps, (const in_t *)p->dinput_addend);)

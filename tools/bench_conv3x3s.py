@@ -10,7 +10,7 @@ dev = "cuda"
 res = []
 for B, C, H, W in shapes:
     xs = [torch.randn(B, C, H, W, device=dev, requires_grad=True) for _ in range(4)]   # rotate: 4 x input > L2
-    w = torch.randn(6, C, 3, 3, device=dev, requires_grad=True) * 0.1
+    w = (torch.randn(6, C, 3, 3, device=dev) * 0.1).requires_grad_()
     b = torch.randn(6, device=dev, requires_grad=True)
     g = torch.randn(B, 6, H, W, device=dev)
     def run(i):
