@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 3
+#define MMU_ABI_VERSION 4
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -203,6 +203,28 @@ typedef struct {
 
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
 int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
+
+/* ---- MMConv's sampling AFTER the channel mixing (csrc/morph_mix.hip) -------------------------------------------------
+ * The row sampling S_k of tap k is linear and the same for every channel, so the K x 1 DSC convolution of the samples
+ * (src/UM_Net/MMUNet.py:259-263) equals  out[o] = sum_k S_k(mixed[k * O + o])  with  mixed[k * O + o] = sum_c W[o][c][k]
+ * x[c]  (a 1 x 1 convolution of the block's input, computed by the caller as a GEMM).  For the blocks that reduce the
+ * channel count (MMUNet.py:344-349,357-359,424-430) the tensor that goes through HBM is Cin / Cout times smaller.
+ * mixed / dmixed: [batch][taps * out_channels] planes of height x width contiguous floats, element strides mixed_bs /
+ * mixed_cs over batch / channel (dmixed has the same strides); y, dy: [batch, taps, height, width]; out, dout:
+ * [batch, out_channels, height, width] contiguous.  taps in {1, 3}.  bwd overwrites dmixed and dy. */
+typedef struct {
+    int32_t batch, out_channels, height, width, taps;
+    const float *mixed;
+    int64_t mixed_bs, mixed_cs;
+    const float *y;
+    float *out;          /* fwd */
+    const float *dout;   /* bwd */
+    float *dmixed;       /* bwd */
+    float *dy;           /* bwd */
+} mmu_morph_mix_params;
+
+int mmu_morph_mix_sample_fwd(const mmu_morph_mix_params *p, void *stream);
+int mmu_morph_mix_sample_bwd(const mmu_morph_mix_params *p, void *stream);
 
 /* ---- bilinear resize, align_corners=True (a11: DecoderBlock x2, RCG edge map, side outputs) -------- */
 /* F.interpolate(mode="bilinear", align_corners=True) on contiguous float32 [planes = batch*channels, h, w]

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .mamba_simple import Mamba, neg_exp, precomputed_A
-from . import conv3x3_mfma, conv3x3_small, conv_s2, mamba_small_fused, mfma_gemm, morph_coords, norm_fused
+from . import conv3x3_mfma, conv3x3_small, conv_s2, mamba_small_fused, mfma_gemm, morph_coords, morph_mix, norm_fused
 from . import morph_sample as morph_sample_mod
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
@@ -187,6 +187,13 @@ class MMConv(nn.Module):
             y_rows = self._rows_fused(offset, combine=False)   # (the sampler adds the fused kernel's partial maps)
         else:
             y_rows = self.get_coordinate_map_2D(offset, self.morph, self.extend_scope, rows_only=True)
+        if self.morph == 0 and morph_mix.wanted(input, self.dsc_conv_x, self.kernel_size):
+            # a block that reduces the channel count on a large map: mix the channels first (a 1 x 1 convolution of the
+            # input as one GEMM), sample the K * Cout mixed planes afterwards -- the tensor that goes through HBM between
+            # the two steps is Cin / Cout times smaller than the sample matrix (morph_mix.py)
+            if y_rows.dim() == 5:
+                y_rows = y_rows.sum(0)
+            return morph_mix.dsc_mix_first(input, y_rows, self.dsc_conv_x, slot), self.dsc_conv_x.bias
         if self.morph == 0:
             # dsc_conv_x (K x 1, stride K x 1) as ONE GEMM: the sampler writes the (Cin*K, B*H*W) matrix
             # [c][k][b][h][w] directly, the conv weight [Cout, Cin, K, 1] viewed as [Cout, Cin*K] multiplies

@@ -61,7 +61,8 @@ def test_param_structs_match_header_field_order():
                         ("mmu_conv7x7_params", _lib.Conv7x7Params),
                         ("mmu_gated_mul_params", _lib.GatedMulParams),
                         ("mmu_mamba_small_params", _lib.MambaSmallParams),
-                        ("mmu_conv_s2_params", _lib.ConvS2Params)):
+                        ("mmu_conv_s2_params", _lib.ConvS2Params),
+                        ("mmu_morph_mix_params", _lib.MorphMixParams)):
         # (mmu_cbam_stats_params declares two pointers per line: not parsed by this check)
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 

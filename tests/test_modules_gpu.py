@@ -1456,3 +1456,38 @@ def test_mamba_small_fused_vs_kernel_chain(cfg):
     assert set(ga) == set(gb), set(ga) ^ set(gb)
     for k in sorted(ga):
         close(ga[k], gb[k], 2e-3, 2e-3 * max(1.0, float(gb[k].abs().max())), k)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 3, 24, 20), (1, 128, 32, 3, 16, 36), (2, 64, 16, 1, 12, 16), (2, 128, 64, 3, 8, 8)])
+def test_mmconv_mix_first_equals_sample_first(cfg, monkeypatch):
+    """morph_mix (channel mixing as a GEMM BEFORE the deformable sampling, for blocks that reduce the channel count) against
+    the sample-then-mix route of the same MMConv: output, input gradient and every parameter gradient -- the two are the
+    same sums in a different order.  Includes rows clamped at the borders and row offsets beyond the gather window (far
+    contributions through the atomics)."""
+    import mm_unet_amd.morph_mix as mm
+    from mm_unet_amd.mmunet import MMConv
+    B, Cin, Cout, K, H, W = cfg
+    torch.manual_seed(11)
+    m = MMConv(Cin, Cout, kernel_size=K, num_slices=4).to(DEV).train()
+    with torch.no_grad():   # offsets large enough to leave the image / the 2-row gather window here and there
+        m.offset_conv.weight.mul_(6.0)
+        m.altho.fill_(3.0)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(DEV)
+    g = torch.randn(B, Cout, H, W, generator=gen).to(DEV)
+    res = {}
+    for first in ("sample", "mix"):
+        monkeypatch.setattr(mm, "ENABLED", first == "mix")
+        monkeypatch.setattr(mm, "MIN_PIXELS", 1)
+        m.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_()
+        if first == "mix":
+            assert mm.wanted(xr, m.dsc_conv_x, K)
+        out = m(xr)
+        out.backward(g)
+        res[first] = (out.detach().clone(), xr.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    close(res["mix"][0], res["sample"][0], 2e-4, 2e-4, "out")
+    close(res["mix"][1], res["sample"][1], 2e-3, 2e-4 * float(res["sample"][1].abs().max()) + 1e-6, "d input")
+    assert set(res["mix"][2]) == set(res["sample"][2])
+    for k, v in res["sample"][2].items():
+        close(res["mix"][2][k], v, 5e-3, 5e-4 * float(v.abs().max()) + 1e-6, k)
