@@ -17,12 +17,13 @@ from .tall_gemm import proj_bcl
 
 ENABLED = os.environ.get("MMUNET_MORPH_MIX", "1") != "0"   # False: every block samples first (A/B runs, plain_aten)
 MIN_PIXELS = int(os.environ.get("MMUNET_MORPH_MIX_MIN_PIXELS", "16384"))   # per map: below, the launches are floor-bound
+RATIO = float(os.environ.get("MMUNET_MORPH_MIX_RATIO", "2"))                # mix first when Cin >= RATIO * Cout
 
 
 def wanted(x, conv, K):
     """Mix first when it shrinks the intermediate at least 2 x, on maps large enough to be bandwidth-bound."""
     return (ENABLED and x.is_cuda and x.dtype == torch.float32 and K in (1, 3) and not torch.is_autocast_enabled()
-            and 2 * conv.out_channels <= conv.in_channels and x.shape[2] * x.shape[3] >= MIN_PIXELS
+            and RATIO * conv.out_channels <= conv.in_channels and x.shape[2] * x.shape[3] >= MIN_PIXELS
             and conv.weight.dtype == torch.float32)
 
 
