@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round-3 evidence set (run on the GPU box through gpurun); the summaries are copied to profiles/r03_* by hand:
-#   1. the default bench line, exactly as the driver runs it (python bench.py)
+#   1. the bench line with the command the driver used in round 2 (python bench.py --gpus 1 --steps 20 --warmup 5)
 #   2. rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`   (kernel averages behind the roofline legs)
 #   3. HBM traffic of one scan forward / backward call (tools/pmc_traffic.sh: separate --pmc passes)
 #   4. kernel trace of the replayed graph, per kernel and per launch grid (tools/prof_steady.py)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r3final
 mkdir -p $out
-python3 bench.py > $out/bench_line.json 2> $out/bench.err || exit 1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench.err || exit 1
 tail -c 600 $out/bench_line.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/roofline -- python3 bench.py --roofline-only > $out/roofline_leg.json 2> $out/roofline_leg.err || exit 1
 cp $out/roofline/*/*kernel_stats.csv $out/roofline_leg_kernel_stats.csv
