@@ -204,6 +204,22 @@ typedef struct {
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
 int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
 
+/* ---- AdamW over many tensors in one launch (csrc/adamw_multi.hip) -------------------------------------------------------
+ * torch.optim.AdamW's fused step (train.py:197-201 builds timm's adamw = torch.optim.AdamW) for a training step whose
+ * parameters, gradients and optimizer state are static (a captured graph).  table: DEVICE array of n_tensors rows of eight
+ * int64 {param, grad, exp_avg, exp_avg_sq, step (float scalar), numel, lr (float scalar), weight_decay (float bits in the
+ * low 32)}; work: DEVICE array of n_work int32 pairs (tensor index, chunk index), one per 4,096 elements of every tensor.
+ * All tensors float32 contiguous.  Increments every step counter, then updates in place.  No amsgrad / maximize. */
+typedef struct {
+    int32_t n_tensors, n_work;
+    const int64_t *table;
+    const int32_t *work;
+    double beta1, beta2;
+    float eps;
+} mmu_adamw_params;
+
+int mmu_adamw_multi(const mmu_adamw_params *p, void *stream);
+
 /* ---- MMConv's sampling AFTER the channel mixing (csrc/morph_mix.hip) -------------------------------------------------
  * The row sampling S_k of tap k is linear and the same for every channel, so the K x 1 DSC convolution of the samples
  * (src/UM_Net/MMUNet.py:259-263) equals  out[o] = sum_k S_k(mixed[k * O + o])  with  mixed[k * O + o] = sum_c W[o][c][k]

@@ -112,6 +112,11 @@ class MorphMixParams(ctypes.Structure):
                 ("dmixed", _vp), ("dy", _vp)]
 
 
+class AdamWParams(ctypes.Structure):
+    _fields_ = [("n_tensors", _i32), ("n_work", _i32), ("table", _vp), ("work", _vp), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_float)]
+
+
 class GemmTokensParams(ctypes.Structure):
     _fields_ = [("rows", _i32), ("inner", _i32), ("tokens", _i32), ("batch", _i32), ("transposed_weight", _i32),
                 ("weight", _vp), ("w_ld", _i64), ("x", _vp), ("x_rs", _i64), ("x_bs", _i64),
@@ -197,7 +202,7 @@ EXPORTS = (
     "mmu_conv3x3_small_wgrad_workspace_floats",
     "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
-    "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
+    "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_adamw_multi", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_mamba_small_supported", "mmu_mamba_small_parts", "mmu_mamba_small_bwd_workspace_floats",
@@ -253,7 +258,8 @@ def lib():
                      ("mmu_mamba_small_fwd", MambaSmallParams), ("mmu_mamba_small_bwd", MambaSmallParams),
                      ("mmu_conv_s2_mfma", ConvS2Params), ("mmu_conv_s2_transposed_mfma", ConvS2Params),
                      ("mmu_conv_s2_wgrad_mfma", ConvS2Params),
-                     ("mmu_morph_mix_sample_fwd", MorphMixParams), ("mmu_morph_mix_sample_bwd", MorphMixParams)):
+                     ("mmu_morph_mix_sample_fwd", MorphMixParams), ("mmu_morph_mix_sample_bwd", MorphMixParams),
+                     ("mmu_adamw_multi", AdamWParams)):
         fn = getattr(L, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(st), _vp]

@@ -16,6 +16,7 @@ buffers; shapes are fixed at capture time.
 """
 import torch
 
+from . import adamw_multi
 from .dp import GradAllReducer
 
 
@@ -62,10 +63,11 @@ def set_lr(optimizer, lr):
 
 class TrainStep:
     def __init__(self, model, loss_fn, optimizer, group=None, amp_dtype=None, bucket_bytes=16 << 20, overlap=True,
-                 use_graph=False):
+                 use_graph=False, multi_tensor_adamw=True):
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.amp_dtype = amp_dtype
         self.use_graph = use_graph
+        self.multi_tensor_adamw = multi_tensor_adamw
         self.reducer = GradAllReducer(model, group=group, bucket_bytes=bucket_bytes, overlap=overlap,
                                       static_grads=use_graph)
         self._graph = None
@@ -95,10 +97,24 @@ class TrainStep:
         whole = self.reducer.world == 1
         self.model.zero_grad(set_to_none=True)
         self._graph = torch.cuda.CUDAGraph()
+        # one rank: AdamW is part of the graph -- as two launches over a device table of the (static) parameter / gradient
+        # / state addresses (adamw_multi.py) where the optimizer allows it, as optimizer.step() (41 launches) otherwise
+        self._adamw = None
+        if whole and self.multi_tensor_adamw and adamw_multi.supported(self.optimizer) and \
+                all(isinstance(s.get("step"), torch.Tensor) and s["step"].is_cuda for s in self.optimizer.state.values()) \
+                and len(self.optimizer.state) > 0:
+            self._adamw = adamw_multi.MultiTensorAdamW(self.optimizer)
+            self._adamw.reserve()
         with torch.cuda.graph(self._graph):
             self._loss = self.forward_backward(self._x, self._t)
             if whole:
-                self.optimizer.step()
+                if self._adamw is not None:
+                    self._adamw.plan()         # (the parameters the captured backward has just given gradients)
+                    self._adamw.launch()
+                else:
+                    self.optimizer.step()
+        if self._adamw is not None:
+            self._adamw.bind()                 # addresses into the table the captured launches read
         self._whole = whole
         torch.cuda.synchronize(dev)
 

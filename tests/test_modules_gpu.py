@@ -1491,3 +1491,57 @@ def test_mmconv_mix_first_equals_sample_first(cfg, monkeypatch):
     assert set(res["mix"][2]) == set(res["sample"][2])
     for k, v in res["sample"][2].items():
         close(res["mix"][2][k], v, 5e-3, 5e-4 * float(v.abs().max()) + 1e-6, k)
+
+
+def test_multi_tensor_adamw_equals_torch_fused_adamw():
+    """adamw_multi.MultiTensorAdamW (two launches over a device table of addresses) on the optimizer's own state against
+    torch.optim.AdamW(fused=True, capturable=True).step(): parameters, exp_avg, exp_avg_sq and step counters after
+    three steps, two groups (weight decay 0 / 0.05), tensors from 1 to 70,001 elements (ragged chunk tails, unaligned
+    sizes), a parameter without gradient, and a learning rate changed in place between steps."""
+    from mm_unet_amd.adamw_multi import MultiTensorAdamW
+    gen = torch.Generator().manual_seed(77)
+    shapes = [(), (3,), (64, 3, 3, 3), (4097,), (70001,), (128, 33), (5, 1, 7)]
+
+    def build():
+        ps = [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, s in enumerate(shapes)]
+        lr = torch.tensor(1e-3, device=DEV)
+        opt = torch.optim.AdamW([{"params": ps[:3], "weight_decay": 0.0}, {"params": ps[3:], "weight_decay": 0.05}],
+                                lr=lr, betas=(0.9, 0.95), fused=True, capturable=True)
+        return ps, opt
+
+    pa, oa = build()
+    pb, ob = build()
+    grads = [[torch.randn(s, generator=gen).to(DEV) for s in shapes] for _ in range(4)]
+
+    def set_grads(ps, gs):
+        for i, (p, g) in enumerate(zip(ps, gs)):
+            p.grad = None if i == 5 else g.clone()
+
+    # one torch step on both: lazy state initialisation
+    for ps, opt in ((pa, oa), (pb, ob)):
+        set_grads(ps, grads[0])
+        opt.step()
+    mt = MultiTensorAdamW(ob)
+    mt.reserve()
+    for k in (1, 2, 3):
+        if k == 2:
+            for opt in (oa, ob):
+                for g in opt.param_groups:
+                    g["lr"].fill_(3e-3)
+        set_grads(pa, grads[k])
+        oa.step()
+        set_grads(pb, grads[k])
+        mt.plan()
+        mt.bind()
+        mt.launch()
+    torch.cuda.synchronize()
+    assert mt.n_tensors == len(shapes) - 1
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        close(y, x, 1e-5, 2e-7, f"param {i}")      # (one-ulp differences: fma contraction)
+        if i == 5:
+            assert pb[i] not in ob.state or torch.equal(ob.state[pb[i]]["step"], oa.state[pa[i]]["step"])
+            continue
+        sa, sb = oa.state[x], ob.state[y]
+        assert float(sa["step"]) == float(sb["step"]) == 4.0
+        close(sb["exp_avg"], sa["exp_avg"], 1e-5, 2e-7, f"exp_avg {i}")
+        close(sb["exp_avg_sq"], sa["exp_avg_sq"], 1e-5, 1e-8, f"exp_avg_sq {i}")
