@@ -204,6 +204,21 @@ typedef struct {
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);
 int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
 
+/* ---- the final weight-gradient sums of a backward pass in one launch (csrc/deferred_reduce.hip) -------------------------
+ * Between mmu_deferred_begin() and mmu_deferred_end() the launchers of mmu_gemm_nt_splitk, mmu_conv3x3_small_bwd (weight
+ * gradient) and mmu_causal_conv1d_bwd (with a workspace) run their main kernels but only RECORD their final ordered sums
+ * (one row of eight int64 per job: kind, partials, destinations, shape).  The caller keeps the partial buffers alive,
+ * reads the rows with mmu_deferred_jobs (returns the number recorded; copies at most max_jobs rows; rows_out may be NULL),
+ * places them and a work list of int32 pairs (job, workgroup) -- kind 0: ceil(row[4] / 64) workgroups, kind 1:
+ * ceil(row[4] * ((row[6] * 10 + 3) & ~3) / 64), kind 2: ceil(row[5] / 16) -- in DEVICE memory and launches them all with
+ * mmu_deferred_launch.  Same summation order as the kernels it replaces.  Process-wide state (autograd runs the
+ * backward pass on its own thread): one scope at a time. */
+void mmu_deferred_begin(void);
+void mmu_deferred_pause(int paused);   /* 1: launchers reduce at once again (scope stays open); 0: record again */
+void mmu_deferred_end(void);
+int mmu_deferred_jobs(int64_t *rows_out, int max_jobs);
+int mmu_deferred_launch(const int64_t *table, const int32_t *work, int n_work, void *stream);
+
 /* ---- AdamW over many tensors in one launch (csrc/adamw_multi.hip) -------------------------------------------------------
  * torch.optim.AdamW's fused step (train.py:197-201 builds timm's adamw = torch.optim.AdamW) for a training step whose
  * parameters, gradients and optimizer state are static (a captured graph).  table: DEVICE array of n_tensors rows of eight

@@ -10,7 +10,7 @@ Weights/bias are read as float32 (cast here when they arrive in a 16-bit dtype).
 """
 import torch
 
-from . import _lib
+from . import _lib, deferred
 
 
 def _check(cond, msg):
@@ -84,8 +84,16 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
     p.dx_bs, p.dx_ds = dx.stride(0), dx.stride(1)
     p.w_ds, p.w_ws = w32.stride(0), w32.stride(1)
     p.workspace = ws.data_ptr()
+    # inside a deferred.Scope the ordered sum of the per-block partials runs with all the others of the backward pass --
+    # unless the result is converted (read) right here
+    same = weight.dtype == torch.float32 and (bias_ is None or bias_.dtype == torch.float32)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().mmu_causal_conv1d_bwd(p, _lib.stream_of(x)))
+        if same:
+            _lib.check(_lib.lib().mmu_causal_conv1d_bwd(p, _lib.stream_of(x)))
+            deferred.keep(ws)
+        else:
+            with deferred.paused():
+                _lib.check(_lib.lib().mmu_causal_conv1d_bwd(p, _lib.stream_of(x)))
     return [dx, dweight.to(weight.dtype), dbias.to(bias_.dtype) if bias_ is not None else None]
 
 

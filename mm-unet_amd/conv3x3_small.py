@@ -9,7 +9,7 @@ the output feeds a GroupNorm that autocast runs in float32 anyway); anything els
 """
 import torch
 
-from . import _lib
+from . import _lib, deferred
 
 SUPPORTED_CO = (1, 2, 6, 8)
 WEIGHT_GRAD_NATIVE = True    # False: weight / bias gradient from ATen (MIOpen); tests cover both
@@ -106,6 +106,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
                 p.workspace = _lib.ptr(ws)
                 with torch.cuda.device(x.device):
                     _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
+                deferred.keep(ws)   # (deferred.Scope: the sum over the row blocks runs later)
             else:
                 # ATen / MIOpen weight gradient (kept for comparison: its implicit-GEMM kernel plus layout
                 # transposes take 50-110 us where the row-walking kernel needs a fraction of that)

@@ -266,6 +266,8 @@ extern "C" int mmu_causal_conv1d_bwd(const mmu_conv1d_bwd_params *p, void *strea
         conv1d_bwd_kernel<bf16_t><<<grid, CTHREADS, 0, (hipStream_t)stream>>>(a);
     MMU_HIP_LAUNCH_CHECK("causal_conv1d_bwd");
     if (p->workspace) {
+        const long job[8] = {2, (long)p->workspace, (long)p->dweight, (long)p->dbias, p->batch, p->dim, (long)grid.x, p->width};
+        if (mmu_defer_job(job)) return 0;   // (deferred_reduce.hip)
         conv1d_wgrad_reduce_kernel<<<p->dim, 64, 0, (hipStream_t)stream>>>(p->workspace, p->batch, p->dim, (int)grid.x,
                                                                          p->width, p->dweight, p->dbias);
         MMU_HIP_LAUNCH_CHECK("causal_conv1d_bwd(reduce)");

@@ -596,8 +596,10 @@ extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream)
                                                                  p->height, p->width, lwq, rs);
             MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight rows)");
             constexpr int NV4 = (CO * 10 + 3) & ~3;
-            conv3x3s_wgrad_sum_kernel<CO><<<(p->in_channels * NV4 + 15) / 16, 256, 0, st>>>(
-                p->workspace, p->dweight, p->dbias, p->in_channels, nrb * p->batch);
+            const long job[8] = {1, (long)p->workspace, (long)p->dweight, (long)p->dbias, p->in_channels, (long)nrb * p->batch, CO, 0};
+            if (!mmu_defer_job(job))   // (deferred_reduce.hip)
+                conv3x3s_wgrad_sum_kernel<CO><<<(p->in_channels * NV4 + 15) / 16, 256, 0, st>>>(
+                    p->workspace, p->dweight, p->dbias, p->in_channels, nrb * p->batch);
         })
         MMU_HIP_LAUNCH_CHECK("conv3x3_small_bwd(weight sum)");
     } else if (p->dweight) {

@@ -1,0 +1,167 @@
+// deferred_reduce.hip -- the final sums of the weight gradients of a backward pass in ONE launch, for gfx950.
+//
+// Where it sits: the weight gradients of MM-UNet's projections / DSC convolutions (gemm_nt_splitk.hip), offset
+// convolutions (conv3x3_small.hip) and causal conv1d layers (causal_conv1d.hip) are produced as per-workgroup partial
+// sums plus a small kernel that adds them in a fixed order -- 131 such kernels per training step, each a few workgroups
+// of work at the ~4.6 us dependent-launch floor in the middle of the backward chain (0.65 ms of a 37 ms step).  Nothing
+// reads a weight gradient before the optimizer, so between mmu_deferred_begin() and mmu_deferred_launch() those launchers
+// only RECORD their reduction (a row of eight int64: kind, partials, destinations, shape) and one kernel runs them all,
+// with the same summation order as the kernels it replaces (bit-identical results).  The caller keeps the partial
+// buffers alive until then and provides the device copies of the job table and of the (job, workgroup) work list
+// (mm-unet_amd/deferred.py: inside a captured graph the table is written after the capture).
+#include <mutex>
+#include <vector>
+#include "mmu_common.h"
+#include "../../include/mmunet_amd.h"
+
+namespace {
+
+std::mutex g_mu;
+bool g_active = false;
+std::vector<long> g_rows;   // 8 per job
+
+constexpr int ROW = 8;
+
+// kind 0: gemm_nt_splitk slab sums.  {0, part, c, -, n, slabs, rows << 32 | cols, transpose}
+__device__ void job_gemm_nt(const long *row, int blk, float (*sums)[64]) {
+    const float *part = reinterpret_cast<const float *>(row[1]);
+    float *c = reinterpret_cast<float *>(row[2]);
+    const long n = row[4];
+    const int slabs = (int)row[5], rows = (int)(row[6] >> 32), cols = (int)(row[6] & 0xffffffff);
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blk * 64 + o;
+    float s = 0.f;
+    if (i < n) {
+        int k = g;
+        for (; k + 48 < slabs; k += 64) {
+            const float v0 = part[(long)k * n + i], v1 = part[(long)(k + 16) * n + i];
+            const float v2 = part[(long)(k + 32) * n + i], v3 = part[(long)(k + 48) * n + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < slabs; k += 16) s += part[(long)k * n + i];
+    }
+    sums[g][o] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = sums[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sums[k][o];
+        if (row[7]) {
+            const long r = i / cols, q = i - r * cols;
+            c[q * rows + r] = t;
+        } else {
+            c[i] = t;
+        }
+    }
+}
+
+// kind 1: conv3x3_small weight / bias gradient.  {1, part, dW, dbias, Cin, nblk, CO, -}; 64 results per workgroup
+__device__ void job_conv3x3s(const long *row, int blk) {
+    const float *part = reinterpret_cast<const float *>(row[1]);
+    float *dW = reinterpret_cast<float *>(row[2]);
+    float *dbias = reinterpret_cast<float *>(row[3]);
+    const int Cin = (int)row[4], nblk = (int)row[5], CO = (int)row[6];
+    const int NV = CO * 10, NV4 = (NV + 3) & ~3;
+    const int sub = threadIdx.x & 15;
+    int idx = blk * 64 + (threadIdx.x >> 4);
+    const bool live = idx < Cin * NV4;
+    idx = live ? idx : Cin * NV4 - 1;
+    float s = 0.f;
+    for (int k = sub; k < nblk; k += 16) s += part[(long)k * Cin * NV4 + idx];
+    s += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, s);
+    s += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, s);
+    s += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, s);
+    s += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, s);   // lane 15 of each row of 16 holds the total
+    const int ci = idx / NV4, e = idx - ci * NV4;
+    if (!live || sub != 15 || e >= NV) return;
+    if (e < CO * 9) {
+        const int co = e / 9, t = e - co * 9;
+        dW[((long)co * Cin + ci) * 9 + t] = s;
+    } else if (ci == 0 && dbias != nullptr) {
+        dbias[e - CO * 9] = s;
+    }
+}
+
+// kind 2: causal conv1d weight / bias gradient.  {2, ws, dweight, dbias, batch, dim, nblk, width}; a wave per channel
+__device__ void job_conv1d(const long *row, int blk) {
+    const float *ws = reinterpret_cast<const float *>(row[1]);
+    float *dweight = reinterpret_cast<float *>(row[2]);
+    float *dbias = reinterpret_cast<float *>(row[3]);
+    const int batch = (int)row[4], dim = (int)row[5], nblk = (int)row[6], width = (int)row[7];
+    const int lane = threadIdx.x & 63;
+    const int d = blk * 16 + (threadIdx.x >> 6);
+    if (d >= dim) return;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n = batch * nblk;
+    for (int i = lane; i < n; i += 64) {
+        const int b = i / nblk, k = i - b * nblk;
+        const float *r = ws + ((((long)b * dim + d) * nblk) + k) * 5;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc[m] += r[m];
+    }
+    const float v4 = wave_sum4(acc[0], acc[1], acc[2], acc[3]);
+    const float vb = wave_sum(acc[4]);
+    if (lane >= 12 && lane < 16) {
+        const int k = (lane - 12) - (4 - width);
+        if (k >= 0) dweight[(long)d * width + k] = v4;
+    }
+    if (lane == 0 && dbias) dbias[d] = vb;
+}
+
+__global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__restrict__ table, const int *__restrict__ work) {
+    __shared__ float sums[16][64];
+    const int job = work[2 * blockIdx.x], blk = work[2 * blockIdx.x + 1];
+    const long *row = table + (long)job * ROW;
+    const int kind = (int)row[0];   // workgroup-uniform
+    if (kind == 0)
+        job_gemm_nt(row, blk, sums);
+    else if (kind == 1)
+        job_conv3x3s(row, blk);
+    else
+        job_conv1d(row, blk);
+}
+
+}  // namespace
+
+// ---- used by the launchers of the three kernel families (declared in mmu_common.h)
+bool mmu_defer_job(const long (&row)[8]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_active) return false;
+    g_rows.insert(g_rows.end(), row, row + ROW);
+    return true;
+}
+
+extern "C" void mmu_deferred_begin(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_active = true;
+    g_rows.clear();
+}
+
+extern "C" void mmu_deferred_pause(int paused) {   // a call whose result is read right away (dtype conversion ...)
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_active = paused == 0;
+}
+
+extern "C" void mmu_deferred_end(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_active = false;
+    g_rows.clear();
+}
+
+extern "C" int mmu_deferred_jobs(int64_t *rows_out, int max_jobs) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int n = (int)(g_rows.size() / ROW);
+    if (rows_out != nullptr) {
+        const int m = n < max_jobs ? n : max_jobs;
+        for (long i = 0; i < (long)m * ROW; ++i) rows_out[i] = g_rows[i];
+    }
+    return n;
+}
+
+extern "C" int mmu_deferred_launch(const int64_t *table, const int32_t *work, int n_work, void *stream) {
+    MMU_CHECK(table != nullptr && work != nullptr && n_work > 0, "deferred_launch: table, work list and a positive count are required");
+    static_assert(sizeof(long) == sizeof(int64_t), "the table is read as long");
+    deferred_reduce_kernel<<<n_work, 1024, 0, (hipStream_t)stream>>>(reinterpret_cast<const long *>(table), work);
+    MMU_HIP_LAUNCH_CHECK("deferred_launch");
+    return 0;
+}

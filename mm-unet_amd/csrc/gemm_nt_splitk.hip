@@ -409,6 +409,8 @@ extern "C" int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream) {
     }
     MMU_HIP_LAUNCH_CHECK("gemm_nt_splitk");
     const long n = (long)p->m * p->n;
+    const long job[8] = {0, (long)p->workspace, (long)p->c, 0, n, slabs, ((long)a.M << 32) | (long)a.N, swap ? 1 : 0};
+    if (mmu_defer_job(job)) return 0;   // (deferred_reduce.hip: the slab sums of a whole backward pass in one launch)
     gemm_nt_reduce_kernel<<<(unsigned)((n + 63) / 64), 1024, 0, st>>>(p->workspace, p->c, n, slabs, a.M, a.N, swap ? 1 : 0);
     MMU_HIP_LAUNCH_CHECK("gemm_nt_splitk(reduce)");
     return 0;

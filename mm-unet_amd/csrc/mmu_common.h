@@ -14,6 +14,8 @@
 // ---------------------------------------------------------------------------
 extern thread_local char g_mmu_err[512];
 int mmu_fail(const char *fmt, ...);
+// deferred_reduce.hip: records a final weight-gradient reduction instead of launching it (true) when a deferred scope is open
+bool mmu_defer_job(const long (&row)[8]);
 
 #define MMU_CHECK(cond, ...)                       \
     do {                                           \

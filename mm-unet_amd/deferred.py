@@ -1,0 +1,124 @@
+"""The final ordered sums of a backward pass's weight gradients in ONE launch (csrc/deferred_reduce.hip).
+
+``gemm_nt`` (projection / DSC weight gradients), ``conv3x3_small``'s weight gradient and ``causal_conv1d_bwd`` each end in a
+small kernel that adds per-workgroup partial sums in a fixed order: 131 of them per MM-UNet training step, every one a
+dependent launch at the ~4.6 us floor in the middle of the backward chain.  Nothing reads a weight gradient before the
+optimizer, so inside a :class:`Scope` those launchers only record their reduction and ``Scope.launch()`` runs them all
+in one kernel, with the summation order of the kernels it replaces.
+
+    scope = Scope(device); scope.reserve()          # device tables (outside any capture)
+    with scope:                                     # mmu_deferred_begin ... mmu_deferred_end
+        loss.backward()                             # weight gradients are allocated, their partials kept alive
+        scope.launch()                              # one launch (capturable); the gradients are final after it
+    scope.bind()                                    # writes the job table; BEFORE the first replay of a captured graph
+
+Eagerly ``launch()`` binds by itself.  Contract: the weight gradients are leaves of the backward pass (stored into
+``param.grad``, not accumulated into or read before ``launch()``) -- ``TrainStep`` opens a scope only around the backward
+pass it captures.  Process-wide: one scope at a time.
+"""
+import torch
+
+from . import _lib
+
+_active = None
+
+
+def keep(*tensors):
+    """Called by the wrappers whose final sum may have been deferred: keeps their partial-sum buffers alive."""
+    if _active is not None:
+        _active._keep.extend(t for t in tensors if t is not None)
+
+
+def active():
+    return _active is not None
+
+
+class paused:
+    """``with paused():`` -- calls inside reduce at once although a scope is open (their result is read right away)."""
+
+    def __enter__(self):
+        if _active is not None:
+            _lib.lib().mmu_deferred_pause(1)
+
+    def __exit__(self, *exc):
+        if _active is not None:
+            _lib.lib().mmu_deferred_pause(0)
+        return False
+
+
+class Scope:
+    MAX_JOBS = 1024
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.table = self.work = None
+        self.n_jobs = self.n_work = 0
+        self._keep, self._rows, self._work = [], None, None
+        self._captured = False
+
+    def reserve(self, max_work=65536):
+        self.table = torch.zeros((self.MAX_JOBS, 8), dtype=torch.int64, device=self.device)
+        self.work = torch.zeros((max_work, 2), dtype=torch.int32, device=self.device)
+
+    def __enter__(self):
+        global _active
+        if _active is not None:
+            raise RuntimeError("deferred.Scope: another scope is open")
+        if self.table is None:
+            self.reserve()
+        self._keep = []
+        _lib.lib().mmu_deferred_begin()
+        _active = self
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        _active = None
+        _lib.lib().mmu_deferred_end()
+        return False
+
+    def _collect(self):
+        import ctypes
+        L = _lib.lib()
+        n = L.mmu_deferred_jobs(None, 0)
+        if n > self.MAX_JOBS:
+            raise RuntimeError(f"deferred.Scope: {n} deferred reductions, table holds {self.MAX_JOBS}")
+        buf = (ctypes.c_int64 * (8 * max(n, 1)))()
+        L.mmu_deferred_jobs(ctypes.cast(buf, ctypes.c_void_p), n)
+        rows = [[buf[8 * j + k] for k in range(8)] for j in range(n)]
+        work = []
+        for j, r in enumerate(rows):
+            if r[0] == 0:
+                nb = (r[4] + 63) // 64
+            elif r[0] == 1:
+                nb = (r[4] * ((r[6] * 10 + 3) & ~3) + 63) // 64
+            else:
+                nb = (r[5] + 15) // 16
+            work += [[j, b] for b in range(nb)]
+        if len(work) > self.work.shape[0]:
+            raise RuntimeError(f"deferred.Scope: {len(work)} workgroups, work list holds {self.work.shape[0]}")
+        self._rows, self._work = rows, work
+        self.n_jobs, self.n_work = len(rows), len(work)
+
+    def bind(self):
+        """Writes the recorded jobs into the device tables (not inside a capture)."""
+        if self.n_jobs:
+            self.table[:self.n_jobs].copy_(torch.tensor(self._rows, dtype=torch.int64))
+            self.work[:self.n_work].copy_(torch.tensor(self._work, dtype=torch.int32))
+
+    def launch(self):
+        """Runs every reduction recorded since ``__enter__`` (inside the scope, after the backward pass)."""
+        if _active is not self:
+            raise RuntimeError("deferred.Scope.launch: call inside the scope")
+        self._collect()
+        if self.n_jobs == 0:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.bind()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mmu_deferred_launch(self.table.data_ptr(), self.work.data_ptr(), self.n_work,
+                                                      torch.cuda.current_stream(self.device).cuda_stream))
+        if not capturing:
+            self._keep = []     # (stream order: the partial buffers may be reused by later allocations from here on)
+        _lib.lib().mmu_deferred_begin()   # further reductions of this scope start a new list

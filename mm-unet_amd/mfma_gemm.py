@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, deferred
 
 ENABLED = True   # False: callers use their ATen GEMMs (tests compare the two)
 MIN_TILES = int(os.environ.get("MMUNET_GEMM_TOKENS_MIN_TILES", "192"))   # measured break-even against hipBLASLt on the DSC shapes (csrc/gemm_tokens_mfma.hip header)
@@ -150,4 +150,7 @@ def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False, narr
     p.c, p.workspace = c.data_ptr(), ws.data_ptr()
     with torch.cuda.device(a.device):
         _lib.check(L.mmu_gemm_nt_splitk(p, _lib.stream_of(a)))
+    # inside a deferred.Scope the slab sums run later: the partials must outlive this call.  (NOT the result: an extra
+    # reference to a gradient makes autograd's AccumulateGrad clone it -- i.e. read it -- on the spot)
+    deferred.keep(ws)
     return c

@@ -16,7 +16,7 @@ buffers; shapes are fixed at capture time.
 """
 import torch
 
-from . import adamw_multi
+from . import adamw_multi, deferred
 from .dp import GradAllReducer
 
 
@@ -63,11 +63,13 @@ def set_lr(optimizer, lr):
 
 class TrainStep:
     def __init__(self, model, loss_fn, optimizer, group=None, amp_dtype=None, bucket_bytes=16 << 20, overlap=True,
-                 use_graph=False, multi_tensor_adamw=True):
+                 use_graph=False, multi_tensor_adamw=True, deferred_reductions=True):
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.amp_dtype = amp_dtype
         self.use_graph = use_graph
         self.multi_tensor_adamw = multi_tensor_adamw
+        self.deferred_reductions = deferred_reductions
+        self._scope = None
         self.reducer = GradAllReducer(model, group=group, bucket_bytes=bucket_bytes, overlap=overlap,
                                       static_grads=use_graph)
         self._graph = None
@@ -80,7 +82,13 @@ class TrainStep:
             loss = self.loss_fn(logits.float(), targets)
         else:
             loss = self.loss_fn(self.model(images), targets)
-        loss.backward()
+        scope = self._scope
+        if scope is not None:   # captured step: the final sums of the weight gradients as ONE launch (deferred.py)
+            with scope:
+                loss.backward()
+                scope.launch()
+        else:
+            loss.backward()
         return loss.detach()
 
     def _eager(self, images, targets):
@@ -99,6 +107,10 @@ class TrainStep:
         self._graph = torch.cuda.CUDAGraph()
         # one rank: AdamW is part of the graph -- as two launches over a device table of the (static) parameter / gradient
         # / state addresses (adamw_multi.py) where the optimizer allows it, as optimizer.step() (41 launches) otherwise
+        self._scope = None
+        if self.deferred_reductions and all(p.dtype == torch.float32 for p in self.model.parameters()):
+            self._scope = deferred.Scope(dev)
+            self._scope.reserve()
         self._adamw = None
         if whole and self.multi_tensor_adamw and adamw_multi.supported(self.optimizer) and \
                 all(isinstance(s.get("step"), torch.Tensor) and s["step"].is_cuda for s in self.optimizer.state.values()) \
@@ -115,6 +127,9 @@ class TrainStep:
                     self.optimizer.step()
         if self._adamw is not None:
             self._adamw.bind()                 # addresses into the table the captured launches read
+        if self._scope is not None:
+            self._scope.bind()                 # (the same for the deferred reductions' job table)
+            self._scope_captured, self._scope = self._scope, None   # its tables and partial buffers live with the graph
         self._whole = whole
         torch.cuda.synchronize(dev)
 

@@ -1545,3 +1545,59 @@ def test_multi_tensor_adamw_equals_torch_fused_adamw():
         assert float(sa["step"]) == float(sb["step"]) == 4.0
         close(sb["exp_avg"], sa["exp_avg"], 1e-5, 2e-7, f"exp_avg {i}")
         close(sb["exp_avg_sq"], sa["exp_avg_sq"], 1e-5, 1e-8, f"exp_avg_sq {i}")
+
+
+def test_deferred_weight_gradient_sums_are_bit_identical():
+    """deferred.Scope: the final ordered sums of gemm_nt (projection / DSC weight gradients), conv3x3_small's weight
+    gradient and causal_conv1d_bwd recorded during a backward pass and run by ONE launch -- same partials, same
+    summation order: the gradients must equal the immediate ones bit for bit (eager and inside a captured graph)."""
+    from mm_unet_amd import deferred
+    from mm_unet_amd import causal_conv1d_hip as cc
+    from mm_unet_amd.conv3x3_small import conv3x3_small
+    from mm_unet_amd.mfma_gemm import gemm_nt
+    gen = torch.Generator().manual_seed(5)
+    B, L = 2, 4096
+    a = torch.randn(96, B, L, generator=gen).to(DEV)
+    b = torch.randn(40, B, L, generator=gen).to(DEV)
+    x3 = torch.randn(2, 32, 24, 32, generator=gen).to(DEV)
+    w3 = (torch.randn(6, 32, 3, 3, generator=gen) * 0.2).to(DEV)
+    b3 = torch.randn(6, generator=gen).to(DEV)
+    g3 = torch.randn(2, 6, 24, 32, generator=gen).to(DEV)
+    xc = torch.randn(B, 24, L, generator=gen).to(DEV)
+    wc = torch.randn(24, 4, generator=gen).to(DEV)
+    bc = torch.randn(24, generator=gen).to(DEV)
+    gc = torch.randn(B, 24, L, generator=gen).to(DEV)
+
+    def work():
+        out = [gemm_nt(a, b, 96, 40, B, L, B * L, L, B * L, L), gemm_nt(b, a, 40, 96, B, L, B * L, L, B * L, L)]
+        w = w3.clone().requires_grad_()
+        bb = b3.clone().requires_grad_()
+        conv3x3_small(x3, w, bb).backward(g3)
+        dx, dw, db = cc.causal_conv1d_bwd(xc, wc, bc, gc, None, True)
+        return out + [w.grad, bb.grad, dw, db, dx]
+
+    ref = [t.clone() for t in work()]
+    scope = deferred.Scope(DEV)
+    with scope:
+        got = work()
+        assert deferred.active()
+        scope.launch()
+    assert scope.n_jobs == 4 and not deferred.active()
+    torch.cuda.synchronize()
+    for r, t in zip(ref, got):
+        assert torch.equal(r, t)
+    # captured: the table is written after the capture, the replays read it
+    scope2 = deferred.Scope(DEV)
+    scope2.reserve()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        with scope2:
+            got2 = work()
+            scope2.launch()
+    scope2.bind()
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        for r, t in zip(ref, got2):
+            assert torch.equal(r, t)
