@@ -210,7 +210,8 @@ int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream);
  * (one row of eight int64 per job: kind, partials, destinations, shape).  The caller keeps the partial buffers alive,
  * reads the rows with mmu_deferred_jobs (returns the number recorded; copies at most max_jobs rows; rows_out may be NULL),
  * places them and a work list of int32 pairs (job, workgroup) -- kind 0: ceil(row[4] / 64) workgroups, kind 1:
- * ceil(row[4] * ((row[6] * 10 + 3) & ~3) / 64), kind 2: ceil(row[5] / 16) -- in DEVICE memory and launches them all with
+ * ceil(row[4] * ((row[6] * 10 + 3) & ~3) / 64), kind 2: ceil(row[5] / 16), kind 3 (mmu_zigzag_inproj_bwd /
+ * mmu_coords_outproj_bwd with a workspace): ceil(row[7] / 64) -- in DEVICE memory and launches them all with
  * mmu_deferred_launch.  Same summation order as the kernels it replaces.  Process-wide state (autograd runs the
  * backward pass on its own thread): one scope at a time. */
 void mmu_deferred_begin(void);
@@ -659,7 +660,12 @@ typedef struct {
     float *dout_z;
     float *dout_proj_weight;
     float *daltho;
+    float *workspace;   /* bwd, optional: mmu_coords_bwd_workspace_floats() floats.  With it the weight gradients are per-block
+                         * partials added in a fixed order (reproducible, nothing to zero, deferrable: mmu_deferred_*);
+                         * without it they are float atomics into zero-filled targets */
 } mmu_coords_params;
+
+size_t mmu_coords_bwd_workspace_floats(int batch, int height, int width, int taps);
 
 int mmu_zigzag_inproj_fwd(const mmu_coords_params *p, void *stream);
 int mmu_zigzag_inproj_bwd(const mmu_coords_params *p, void *stream);

@@ -108,6 +108,30 @@ __device__ void job_conv1d(const long *row, int blk) {
     if (lane == 0 && dbias) dbias[d] = vb;
 }
 
+// kind 3: rows of a partial buffer.  {3, part, dst, dst2, n1, nparts, stride, ntot}: dst[i < n1], dst2[0] = value ntot - 1
+__device__ void job_rows(const long *row, int blk, float (*sums)[64]) {
+    const float *part = reinterpret_cast<const float *>(row[1]);
+    float *dst = reinterpret_cast<float *>(row[2]);
+    float *dst2 = reinterpret_cast<float *>(row[3]);
+    const int n1 = (int)row[4], nparts = (int)row[5], stride = (int)row[6], ntot = (int)row[7];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blk * 64 + o;
+    float s = 0.f;
+    if (i < ntot)
+        for (int k = g; k < nparts; k += 16) s += part[(long)k * stride + i];
+    sums[g][o] = s;
+    __syncthreads();
+    if (g == 0 && i < ntot) {
+        float t = sums[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sums[k][o];
+        if (i < n1)
+            dst[i] = t;
+        else if (i == ntot - 1 && dst2 != nullptr)
+            dst2[0] = t;
+    }
+}
+
 __global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__restrict__ table, const int *__restrict__ work) {
     __shared__ float sums[16][64];
     const int job = work[2 * blockIdx.x], blk = work[2 * blockIdx.x + 1];
@@ -117,8 +141,10 @@ __global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__res
         job_gemm_nt(row, blk, sums);
     else if (kind == 1)
         job_conv3x3s(row, blk);
-    else
+    else if (kind == 2)
         job_conv1d(row, blk);
+    else
+        job_rows(row, blk, sums);
 }
 
 }  // namespace

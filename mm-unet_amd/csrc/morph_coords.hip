@@ -39,6 +39,7 @@ struct CoordArgs {
     float *doz;          // [2K][B][L]
     float *dwout;        // [K, 2K]   zeroed, atomics
     float *daltho;       // scalar    zeroed, atomics
+    float *ws;           // NULL, or per-block partial rows [gridDim.x][NV4]: plain stores, summed in a fixed order afterwards
 };
 
 __device__ __forceinline__ int zig_of(int h, int w, int H, int W) {
@@ -77,6 +78,51 @@ __device__ __forceinline__ void block_sum_many_atomic(const float (&v)[NV], floa
         float s = lds[i] + lds[NV4 + i] + lds[2 * NV4 + i] + lds[3 * NV4 + i];
         if (i == NV - 1) s *= last_scale;
         atomicAdd(dst + i, s);
+    }
+}
+
+// The same sums written to this block's row of a partial buffer (plain stores: no zero fill, no atomics; the rows are
+// added in a fixed order by coords_partials_sum_kernel / the deferred reduction).  All NV values are stored.
+template <int NV>
+__device__ __forceinline__ void block_sum_many_store(const float (&v)[NV], float *lds /* [4][NV4] */, float *row,
+                                                     float last_scale = 1.f) {
+    constexpr int NV4 = (NV + 3) & ~3;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV4; i += 4) {
+        const float r = wave_sum4_swap(v[i], i + 1 < NV ? v[i + 1] : 0.f, i + 2 < NV ? v[i + 2] : 0.f,
+                                  i + 3 < NV ? v[i + 3] : 0.f);
+        if (lane >= 12 && lane < 16) lds[w * NV4 + i + lane - 12] = r;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += blockDim.x) {
+        float s = lds[i] + lds[NV4 + i] + lds[2 * NV4 + i] + lds[3 * NV4 + i];
+        if (i == NV - 1) s *= last_scale;
+        row[i] = s;
+    }
+}
+
+// dst[i] = sum over the rows of part[r][i] (i < n1), dst2[0] = the same for the LAST of the ntot values (if ntot > n1):
+// 16 row groups in parallel, each a strided serial sum, the 16 group sums added in order.  One workgroup per 64 values.
+__global__ __launch_bounds__(1024) void coords_partials_sum_kernel(const float *__restrict__ part, float *__restrict__ dst,
+                                                                   float *__restrict__ dst2, int n1, int nparts,
+                                                                   int stride, int ntot) {
+    __shared__ float sums[16][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (i < ntot)
+        for (int k = g; k < nparts; k += 16) s += part[(long)k * stride + i];
+    sums[g][o] = s;
+    __syncthreads();
+    if (g == 0 && i < ntot) {
+        float t = sums[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sums[k][o];
+        if (i < n1)
+            dst[i] = t;
+        else if (i == ntot - 1 && dst2 != nullptr)
+            dst2[0] = t;
     }
 }
 
@@ -144,7 +190,10 @@ __global__ __launch_bounds__(256) void zigzag_inproj_bwd_kernel(CoordArgs p) {
             p.doff[(((long)b * 2 * K + K + k) * p.H + h) * p.W + w] = 0.f;
         }
     }
-    block_sum_many_atomic<4 * K * K>(dw, red, p.dwin, 4 * K * K);
+    if (p.ws)
+        block_sum_many_store<4 * K * K>(dw, red, p.ws + (long)blockIdx.x * ((4 * K * K + 3) & ~3));
+    else
+        block_sum_many_atomic<4 * K * K>(dw, red, p.dwin, 4 * K * K);
 }
 
 __device__ __forceinline__ float coord_weight(float altho, float &dwgt_daltho) {
@@ -253,6 +302,10 @@ __global__ __launch_bounds__(256) void coords_outproj_bwd_kernel(CoordArgs p) {
 #pragma unroll
     for (int i = 0; i < 2 * K * K; ++i) vals[i] = dwo[i];
     vals[NV - 1] = dwg;
+    if (p.ws) {   // (the last value is this block's share of d altho)
+        block_sum_many_store<NV>(vals, red, p.ws + (long)blockIdx.x * NV4, dwgt_da);
+        return;
+    }
     block_sum_many_atomic<NV>(vals, red, p.dwout, 2 * K * K);
     if (threadIdx.x == 0)
         atomicAdd(p.daltho, (red[NV - 1] + red[NV4 + NV - 1] + red[2 * NV4 + NV - 1] + red[3 * NV4 + NV - 1]) * dwgt_da);
@@ -272,6 +325,7 @@ CoordArgs to_args(const mmu_coords_params *p) {
     a.off = p->offset; a.win = p->in_proj_weight; a.wout = p->out_proj_weight; a.altho = p->altho;
     a.xz = p->xz; a.dxz = p->dxz; a.oz = p->out_z; a.y = p->y; a.dy = p->dy; a.doff = p->doffset;
     a.dwin = p->din_proj_weight; a.doz = p->dout_z; a.dwout = p->dout_proj_weight; a.daltho = p->daltho;
+    a.ws = p->workspace;
     return a;
 }
 
@@ -310,10 +364,19 @@ extern "C" int mmu_zigzag_inproj_bwd(const mmu_coords_params *p, void *stream) {
               "zigzag_inproj_bwd: offset, in_proj_weight, dxz, doffset, din_proj_weight required");
     CoordArgs a = to_args(p);
     hipStream_t st = (hipStream_t)stream;
-    if (mmu_zero_async(a.dwin, (size_t)4 * p->taps * p->taps, st) != hipSuccess)
+    const unsigned nb = reduce_blocks((long)a.B * a.H * a.W);
+    if (a.ws == nullptr && mmu_zero_async(a.dwin, (size_t)4 * p->taps * p->taps, st) != hipSuccess)
         return mmu_fail("zigzag_inproj_bwd: memset failed");
-    DISPATCH_K(zigzag_inproj_bwd_kernel, reduce_blocks((long)a.B * a.H * a.W), st, a);
+    DISPATCH_K(zigzag_inproj_bwd_kernel, nb, st, a);
     MMU_HIP_LAUNCH_CHECK("zigzag_inproj_bwd");
+    if (a.ws) {   // ordered sum of the per-block partials: with the other weight-gradient sums of the pass, or now
+        const int nv = 4 * p->taps * p->taps, nv4 = (nv + 3) & ~3;
+        const long job[8] = {3, (long)a.ws, (long)a.dwin, 0, nv, nb, nv4, nv};
+        if (!mmu_defer_job(job)) {
+            coords_partials_sum_kernel<<<(nv + 63) / 64, 1024, 0, st>>>(a.ws, a.dwin, nullptr, nv, (int)nb, nv4, nv);
+            MMU_HIP_LAUNCH_CHECK("zigzag_inproj_bwd(sum)");
+        }
+    }
     return 0;
 }
 
@@ -336,10 +399,24 @@ extern "C" int mmu_coords_outproj_bwd(const mmu_coords_params *p, void *stream) 
     hipStream_t st = (hipStream_t)stream;
     const size_t nw = (size_t)2 * p->taps * p->taps;
     const bool together = a.daltho == a.dwout + nw;   // one allocation: one zero fill
-    if (mmu_zero_async(a.dwout, nw + (together ? 1 : 0), st) != hipSuccess ||
-        (!together && mmu_zero_async(a.daltho, 1, st) != hipSuccess))
+    const unsigned nb = reduce_blocks((long)a.B * a.H * a.W);
+    if (a.ws == nullptr && (mmu_zero_async(a.dwout, nw + (together ? 1 : 0), st) != hipSuccess ||
+                            (!together && mmu_zero_async(a.daltho, 1, st) != hipSuccess)))
         return mmu_fail("coords_outproj_bwd: memset failed");
-    DISPATCH_K(coords_outproj_bwd_kernel, reduce_blocks((long)a.B * a.H * a.W), st, a);
+    DISPATCH_K(coords_outproj_bwd_kernel, nb, st, a);
     MMU_HIP_LAUNCH_CHECK("coords_outproj_bwd");
+    if (a.ws) {
+        const int nv = (int)nw + 1, nv4 = (nv + 3) & ~3;
+        const long job[8] = {3, (long)a.ws, (long)a.dwout, (long)a.daltho, (long)nw, nb, nv4, nv};
+        if (!mmu_defer_job(job)) {
+            coords_partials_sum_kernel<<<(nv + 63) / 64, 1024, 0, st>>>(a.ws, a.dwout, a.daltho, (int)nw, (int)nb, nv4, nv);
+            MMU_HIP_LAUNCH_CHECK("coords_outproj_bwd(sum)");
+        }
+    }
     return 0;
+}
+
+extern "C" size_t mmu_coords_bwd_workspace_floats(int batch, int height, int width, int taps) {
+    if (batch <= 0 || height <= 0 || width <= 0 || taps <= 0) return 0;
+    return (size_t)reduce_blocks((long)batch * height * width) * ((4 * taps * taps + 3) & ~3);
 }

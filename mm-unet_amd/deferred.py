@@ -92,8 +92,10 @@ class Scope:
                 nb = (r[4] + 63) // 64
             elif r[0] == 1:
                 nb = (r[4] * ((r[6] * 10 + 3) & ~3) + 63) // 64
-            else:
+            elif r[0] == 2:
                 nb = (r[5] + 15) // 16
+            else:
+                nb = (r[7] + 63) // 64
             work += [[j, b] for b in range(nb)]
         if len(work) > self.work.shape[0]:
             raise RuntimeError(f"deferred.Scope: {len(work)} workgroups, work list holds {self.work.shape[0]}")

@@ -12,7 +12,7 @@ float32, K in {1, 3}; anything else takes MMConv's un-fused path.
 """
 import torch
 
-from . import _lib
+from . import _lib, deferred
 
 
 ENABLED = True   # False: MMConv builds its coordinate map with tensor ops (fused_paths.plain_aten)
@@ -49,6 +49,11 @@ def _check_offset(offset, rows, w, what):
     return offset.float().contiguous(), w.float().contiguous()
 
 
+def _bwd_workspace(offset, K):
+    B, _, H, W = offset.shape
+    return torch.empty(_lib.lib().mmu_coords_bwd_workspace_floats(B, H, W, K), device=offset.device, dtype=torch.float32)
+
+
 class ZigzagInProjFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, offset, w_in):
@@ -76,8 +81,11 @@ class ZigzagInProjFn(torch.autograd.Function):
         p = _params(offset, K)
         p.in_proj_weight, p.dxz, p.doffset, p.din_proj_weight = w.data_ptr(), g.data_ptr(), doff.data_ptr(), \
             dw.data_ptr()
+        ws = _bwd_workspace(offset, K)     # per-block partials: ordered sums (no atomics, no zero fill), deferrable
+        p.workspace = ws.data_ptr()
         with torch.cuda.device(offset.device):
             _lib.check(_lib.lib().mmu_zigzag_inproj_bwd(p, _lib.stream_of(offset)))
+        deferred.keep(ws)
         return doff.to(ctx.off_dtype), dw.to(ctx.w_dtype)
 
 
@@ -118,8 +126,11 @@ class CoordsOutProjFn(torch.autograd.Function):
         p.out_proj_weight, p.altho, p.out_z, p.dy = w.data_ptr(), al.data_ptr(), oz.data_ptr(), g.data_ptr()
         p.doffset, p.dout_z, p.dout_proj_weight, p.daltho = doff.data_ptr(), doz.data_ptr(), dw.data_ptr(), \
             da.data_ptr()
+        ws = _bwd_workspace(offset, K)
+        p.workspace = ws.data_ptr()
         with torch.cuda.device(offset.device):
             _lib.check(_lib.lib().mmu_coords_outproj_bwd(p, _lib.stream_of(offset)))
+        deferred.keep(ws)
         return (doff.to(ctx.off_dtype), doz.permute(1, 0, 2).to(ctx.oz_dtype), dw.to(ctx.w_dtype),
                 da.reshape(ctx.a_shape).to(ctx.a_dtype), None)
 
