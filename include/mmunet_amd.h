@@ -663,6 +663,8 @@ typedef struct {
     float *workspace;   /* bwd, optional: mmu_coords_bwd_workspace_floats() floats.  With it the weight gradients are per-block
                          * partials added in a fixed order (reproducible, nothing to zero, deferrable: mmu_deferred_*);
                          * without it they are float atomics into zero-filled targets */
+    int32_t accumulate_doffset;   /* mmu_zigzag_inproj_bwd: doffset already holds mmu_coords_outproj_bwd's d offset of the
+                                   * same offsets: add to it (autograd then has one gradient to route, not two to add) */
 } mmu_coords_params;
 
 size_t mmu_coords_bwd_workspace_floats(int batch, int height, int width, int taps);

@@ -175,7 +175,7 @@ class CoordsParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "height", "width", "taps")] + [("extend_scope", ctypes.c_float)]
                 + [(n, _vp) for n in ("offset", "in_proj_weight", "out_proj_weight", "altho", "xz", "dxz", "out_z",
                                       "y", "dy", "doffset", "din_proj_weight", "dout_z", "dout_proj_weight",
-                                      "daltho", "workspace")])
+                                      "daltho", "workspace")] + [("accumulate_doffset", _i32)])
 
 
 class ConvS2Params(ctypes.Structure):

@@ -39,6 +39,7 @@ struct CoordArgs {
     float *doz;          // [2K][B][L]
     float *dwout;        // [K, 2K]   zeroed, atomics
     float *daltho;       // scalar    zeroed, atomics
+    int acc_doff;        // zigzag_inproj_bwd: add to doff instead of writing it
     float *ws;           // NULL, or per-block partial rows [gridDim.x][NV4]: plain stores, summed in a fixed order afterwards
 };
 
@@ -186,8 +187,12 @@ __global__ __launch_bounds__(256) void zigzag_inproj_bwd_kernel(CoordArgs p) {
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            p.doff[(((long)b * 2 * K + k) * p.H + h) * p.W + w] = g[k];
-            p.doff[(((long)b * 2 * K + K + k) * p.H + h) * p.W + w] = 0.f;
+            if (p.acc_doff) {   // the other consumer of the offsets (coords_outproj) has already written its share here
+                p.doff[(((long)b * 2 * K + k) * p.H + h) * p.W + w] += g[k];
+            } else {
+                p.doff[(((long)b * 2 * K + k) * p.H + h) * p.W + w] = g[k];
+                p.doff[(((long)b * 2 * K + K + k) * p.H + h) * p.W + w] = 0.f;
+            }
         }
     }
     if (p.ws)
@@ -326,6 +331,7 @@ CoordArgs to_args(const mmu_coords_params *p) {
     a.xz = p->xz; a.dxz = p->dxz; a.oz = p->out_z; a.y = p->y; a.dy = p->dy; a.doff = p->doffset;
     a.dwin = p->din_proj_weight; a.doz = p->dout_z; a.dwout = p->dout_proj_weight; a.daltho = p->daltho;
     a.ws = p->workspace;
+    a.acc_doff = p->accumulate_doffset;
     return a;
 }
 

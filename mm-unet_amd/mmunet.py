@@ -145,11 +145,12 @@ class MMConv(nn.Module):
                 # small maps (16 x 16, 32 x 32): the whole chain below as ONE kernel each way
                 return mamba_small_fused.mamba_rows(offset, m, self.altho, self.extend_scope, A=neg_exp(m.A_log),
                                                     combine=combine)
-            xz = morph_coords.zigzag_inproj(offset, m.in_proj.weight)
+            oslot = morph_coords.OffsetGradSlot()   # the two consumers of the offsets hand their d(offset) over
+            xz = morph_coords.zigzag_inproj(offset, m.in_proj.weight, oslot)
             out_z = mamba_inner_fn_no_out_proj(xz, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
                                                m.dt_proj.weight, neg_exp(m.A_log), None, None,
                                                m.D.float(), delta_bias=m.dt_proj.bias.float(), delta_softplus=True)
-            return morph_coords.coords_outproj(offset, out_z, m.out_proj.weight, self.altho, self.extend_scope)
+            return morph_coords.coords_outproj(offset, out_z, m.out_proj.weight, self.altho, self.extend_scope, oslot)
 
     def _offset_conv(self, input, slot=None):
         return _small_conv3x3(self.offset_conv, input, slot)   # 6 output channels: direct kernels
@@ -158,8 +159,13 @@ class MMConv(nn.Module):
         """GroupNorm(K x 1 DSC conv(deformable samples)) -- MMUNet.py:244-265."""
         pre, bias = self.forward_pre_gn(input)
         if norm_fused.supported(pre, self.gn):
-            return norm_fused.gn_bn_act(pre, self.gn, pre_bias=bias, grad_channel_major=self.morph == 0)
+            return norm_fused.gn_bn_act(pre, self.gn, pre_bias=bias, grad_channel_major=self.grad_channel_major(input))
         return self.gn(pre if bias is None else pre + bias.view(1, -1, 1, 1))
+
+    def grad_channel_major(self, input):
+        """Layout the block's producer of ``pre`` wants its gradient in: the tokens-last DSC GEMM reads a [C][B][HW]
+        gradient in place; the mix-first sampler (and dsc_conv_y) a batch-major one."""
+        return self.morph == 0 and not morph_mix.wanted(input, self.dsc_conv_x, self.kernel_size)
 
     def forward_pre_gn(self, input):
         """Everything of forward() before the final GroupNorm (run_fused joins that GroupNorm with the
@@ -223,7 +229,7 @@ def run_fused(seq, x, residual=None):
             if norm_fused.supported(pre, m.gn, bn):
                 last = residual is not None and not relu and i + 2 == len(mods)   # ... -> BN, then + residual, ReLU
                 x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if (relu or last) else None, pre_bias=bias,
-                                         grad_channel_major=m.morph == 0, residual=residual if last else None)
+                                         grad_channel_major=m.grad_channel_major(x), residual=residual if last else None)
                 if last:
                     return x
                 i += 3 if relu else 2

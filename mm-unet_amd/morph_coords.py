@@ -49,6 +49,17 @@ def _check_offset(offset, rows, w, what):
     return offset.float().contiguous(), w.float().contiguous()
 
 
+class OffsetGradSlot:
+    """Hand-over of d(offset) between the two consumers of MMConv's offsets: ``coords_outproj`` (whose backward runs
+    first -- it depends on nothing of the Mamba chain) parks its share here and returns None, ``zigzag_inproj``'s backward
+    adds its own share in the same kernel and returns the sum: one gradient for autograd to route instead of two to add
+    (an elementwise launch per MMConv backward).  Armed by ``zigzag_inproj``'s forward when its backward will run."""
+    __slots__ = ("armed", "grad")
+
+    def __init__(self):
+        self.armed, self.grad = False, None
+
+
 def _bwd_workspace(offset, K):
     B, _, H, W = offset.shape
     return torch.empty(_lib.lib().mmu_coords_bwd_workspace_floats(B, H, W, K), device=offset.device, dtype=torch.float32)
@@ -56,7 +67,7 @@ def _bwd_workspace(offset, K):
 
 class ZigzagInProjFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, offset, w_in):
+    def forward(ctx, offset, w_in, slot=None):
         ctx.off_dtype = offset.dtype
         offset, w = _check_offset(offset, lambda K: (4 * K, K), w_in, "zigzag_inproj")
         B, C2, H, W = offset.shape
@@ -68,6 +79,9 @@ class ZigzagInProjFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_zigzag_inproj_fwd(p, _lib.stream_of(offset)))
         ctx.save_for_backward(offset, w)
         ctx.w_dtype = w_in.dtype
+        ctx.slot = slot
+        if slot is not None:
+            slot.armed = bool(ctx.needs_input_grad[0]) and ctx.off_dtype == torch.float32
         return buf.permute(1, 0, 2)
 
     @staticmethod
@@ -76,22 +90,27 @@ class ZigzagInProjFn(torch.autograd.Function):
         B, C2, H, W = offset.shape
         K = C2 // 2
         g = _dbl(dxz.float(), 4 * K, B, H * W)
-        doff = torch.empty_like(offset)
+        slot = ctx.slot
+        parked = None
+        if slot is not None and slot.grad is not None:
+            parked, slot.grad = slot.grad, None
+        doff = parked if parked is not None else torch.empty_like(offset)
         dw = torch.empty_like(w)
         p = _params(offset, K)
         p.in_proj_weight, p.dxz, p.doffset, p.din_proj_weight = w.data_ptr(), g.data_ptr(), doff.data_ptr(), \
             dw.data_ptr()
+        p.accumulate_doffset = int(parked is not None)
         ws = _bwd_workspace(offset, K)     # per-block partials: ordered sums (no atomics, no zero fill), deferrable
         p.workspace = ws.data_ptr()
         with torch.cuda.device(offset.device):
             _lib.check(_lib.lib().mmu_zigzag_inproj_bwd(p, _lib.stream_of(offset)))
         deferred.keep(ws)
-        return doff.to(ctx.off_dtype), dw.to(ctx.w_dtype)
+        return doff.to(ctx.off_dtype), dw.to(ctx.w_dtype), None
 
 
 class CoordsOutProjFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, offset, out_z, w_out, altho, scope):
+    def forward(ctx, offset, out_z, w_out, altho, scope, slot=None):
         ctx.off_dtype, ctx.oz_dtype = offset.dtype, out_z.dtype
         offset, w = _check_offset(offset, lambda K: (K, 2 * K), w_out, "coords_outproj")
         if altho.numel() != 1:
@@ -109,6 +128,7 @@ class CoordsOutProjFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_coords_outproj_fwd(p, _lib.stream_of(offset)))
         ctx.save_for_backward(offset, oz, w, al)
         ctx.scope, ctx.w_dtype, ctx.a_shape, ctx.a_dtype = scope, w_out.dtype, altho.shape, altho.dtype
+        ctx.slot = slot
         return y
 
     @staticmethod
@@ -131,13 +151,17 @@ class CoordsOutProjFn(torch.autograd.Function):
         with torch.cuda.device(offset.device):
             _lib.check(_lib.lib().mmu_coords_outproj_bwd(p, _lib.stream_of(offset)))
         deferred.keep(ws)
-        return (doff.to(ctx.off_dtype), doz.permute(1, 0, 2).to(ctx.oz_dtype), dw.to(ctx.w_dtype),
-                da.reshape(ctx.a_shape).to(ctx.a_dtype), None)
+        doff = doff.to(ctx.off_dtype)
+        slot = ctx.slot
+        if slot is not None and slot.armed and slot.grad is None and doff.dtype == torch.float32:
+            slot.grad, doff = doff, None       # zigzag_inproj's backward adds its share to it and returns the sum
+        return (doff, doz.permute(1, 0, 2).to(ctx.oz_dtype), dw.to(ctx.w_dtype),
+                da.reshape(ctx.a_shape).to(ctx.a_dtype), None, None)
 
 
-def zigzag_inproj(offset, in_proj_weight):
-    return ZigzagInProjFn.apply(offset, in_proj_weight)
+def zigzag_inproj(offset, in_proj_weight, slot=None):
+    return ZigzagInProjFn.apply(offset, in_proj_weight, slot)
 
 
-def coords_outproj(offset, out_z, out_proj_weight, altho, extend_scope=1.0):
-    return CoordsOutProjFn.apply(offset, out_z, out_proj_weight, altho, extend_scope)
+def coords_outproj(offset, out_z, out_proj_weight, altho, extend_scope=1.0, slot=None):
+    return CoordsOutProjFn.apply(offset, out_z, out_proj_weight, altho, extend_scope, slot)

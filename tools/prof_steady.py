@@ -9,7 +9,7 @@ skip = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
 f = glob.glob(d + '/*/*kernel_trace.csv')[0]
 df = pd.read_csv(f).sort_values('Start_Timestamp').reset_index(drop=True)
-adam = df.index[df.Kernel_Name.str.contains('FusedAdam')].tolist()
+adam = df.index[df.Kernel_Name.str.contains('FusedAdam|adamw_multi_kernel')].tolist()
 # the optimizer step launches several multi-tensor kernels back to back; a step ends at the last one of a burst
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
 print('optimizer bursts (step ends) at rows', ends, 'of', len(df))
