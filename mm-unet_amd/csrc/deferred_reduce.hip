@@ -108,7 +108,7 @@ __device__ void job_conv1d(const long *row, int blk) {
     if (lane == 0 && dbias) dbias[d] = vb;
 }
 
-// kind 3: rows of a partial buffer.  {3, part, dst, dst2, n1, nparts, stride, ntot}: dst[i < n1], dst2[0] = value ntot - 1
+// kind 3: rows of a partial buffer.  {3, part, dst, dst2, n1, nparts, stride, ntot}: dst[i < n1], dst2[i - n1] for the rest
 __device__ void job_rows(const long *row, int blk, float (*sums)[64]) {
     const float *part = reinterpret_cast<const float *>(row[1]);
     float *dst = reinterpret_cast<float *>(row[2]);
@@ -127,8 +127,8 @@ __device__ void job_rows(const long *row, int blk, float (*sums)[64]) {
         for (int k = 1; k < 16; ++k) t += sums[k][o];
         if (i < n1)
             dst[i] = t;
-        else if (i == ntot - 1 && dst2 != nullptr)
-            dst2[0] = t;
+        else if (dst2 != nullptr)
+            dst2[i - n1] = t;
     }
 }
 

@@ -265,11 +265,17 @@ extern "C" int mmu_mamba_post_small(const mmu_mamba_post_params *p, void *stream
         mamba_post_small_kernel<6, 33><<<nblk, 256, 0, st>>>(p->ddelta, p->dt, p->dx_dbl, p->conv_out, p->dconv_out,
                                                              p->x_proj_weight, p->dt_proj_weight, p->workspace, p->tokens);
         MMU_HIP_LAUNCH_CHECK("mamba_post_small");
+        const long job[8] = {3, (long)p->workspace, (long)p->dx_proj_weight, (long)p->ddt_proj_weight, 33 * 6, nblk,
+                             (33 * 6 + 6 + 3) & ~3, 33 * 6 + 6};
+        if (mmu_defer_job(job)) return 0;   // (deferred_reduce.hip: with the other weight-gradient sums of the pass)
         mamba_post_small_sum_kernel<6, 33><<<(33 * 6 + 6 + 3) / 4, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
     } else {
         mamba_post_small_kernel<2, 33><<<nblk, 256, 0, st>>>(p->ddelta, p->dt, p->dx_dbl, p->conv_out, p->dconv_out,
                                                              p->x_proj_weight, p->dt_proj_weight, p->workspace, p->tokens);
         MMU_HIP_LAUNCH_CHECK("mamba_post_small");
+        const long job[8] = {3, (long)p->workspace, (long)p->dx_proj_weight, (long)p->ddt_proj_weight, 33 * 2, nblk,
+                             (33 * 2 + 2 + 3) & ~3, 33 * 2 + 2};
+        if (mmu_defer_job(job)) return 0;
         mamba_post_small_sum_kernel<2, 33><<<(33 * 2 + 2 + 3) / 4, 256, 0, st>>>(p->workspace, p->dx_proj_weight, p->ddt_proj_weight, nblk);
     }
     MMU_HIP_LAUNCH_CHECK("mamba_post_small(sum)");

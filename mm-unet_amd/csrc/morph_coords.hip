@@ -103,7 +103,7 @@ __device__ __forceinline__ void block_sum_many_store(const float (&v)[NV], float
     }
 }
 
-// dst[i] = sum over the rows of part[r][i] (i < n1), dst2[0] = the same for the LAST of the ntot values (if ntot > n1):
+// dst[i] = sum over the rows of part[r][i] (i < n1), dst2[i - n1] = the same for the values n1 .. ntot - 1:
 // 16 row groups in parallel, each a strided serial sum, the 16 group sums added in order.  One workgroup per 64 values.
 __global__ __launch_bounds__(1024) void coords_partials_sum_kernel(const float *__restrict__ part, float *__restrict__ dst,
                                                                    float *__restrict__ dst2, int n1, int nparts,
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(1024) void coords_partials_sum_kernel(const float *
         for (int k = 1; k < 16; ++k) t += sums[k][o];
         if (i < n1)
             dst[i] = t;
-        else if (i == ntot - 1 && dst2 != nullptr)
-            dst2[0] = t;
+        else if (dst2 != nullptr)
+            dst2[i - n1] = t;
     }
 }
 

@@ -31,7 +31,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _lib, causal_conv1d_hip, selective_scan_hip
+from . import _lib, causal_conv1d_hip, deferred, selective_scan_hip
 from .tall_gemm import nt_splitk
 
 try:  # torch >= 2.4
@@ -195,6 +195,7 @@ def _post_small(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_weight,
     p.dx_proj_weight, p.ddt_proj_weight, p.workspace = dwx.data_ptr(), dwdt.data_ptr(), ws.data_ptr()
     with torch.cuda.device(ddelta.device):
         _lib.check(_lib.lib().mmu_mamba_post_small(p, _lib.stream_of(ddelta)))
+    deferred.keep(ws)    # (inside a deferred.Scope the sum over the workgroups' partials runs later)
     return dwx, dwdt
 
 
