@@ -567,6 +567,11 @@ typedef struct {
 
 int mmu_sum_parts(const mmu_sum_parts_params *p, void *stream);
 
+/* Bias gradient of a convolution (nn.Conv2d / nn.ConvTranspose2d with bias: RCG's up- / down-sampling, MMUNet.py:360-375):
+ * out[c] = sum over (b, h, w) of g[b, c, h, w]; g float32 NCHW contiguous, 16-byte aligned, hw = h * w a multiple of 4;
+ * workspace: batch * channels floats.  Ordered sums (reproducible). */
+int mmu_channel_sum(const float *g, int batch, int channels, int64_t hw, float *workspace, float *out, void *stream);
+
 /* ---- nn.Conv2d(C, 1, kernel_size=1): one output channel (RCG's gate, the side outputs) --------------------------- */
 /* src/UM_Net/MMUNet.py:346,386: out[b, p] = bias + sum_c weight[c] * input[b, c, p] over hw pixels; float32, contiguous
  * NCHW, channels in {16, 64}, hw % 4 == 0.  bwd: dinput[b, c, p] = dout[b, p] weight[c] (optional), dweight [C] and

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, conv_s2
 
 # The hi/lo bf16 split drops the lo*lo term: ~2^-16 relative per product against 2^-24 on the library's float32 path
 # (tests pin 5e-5 / 1e-4 on randn data).  ENABLED = False (or MMUNET_CONV3X3_MFMA=0 in the environment) routes every
@@ -91,7 +91,7 @@ class Conv3x3MfmaFn(torch.autograd.Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and wgrad_supported(x, cout) and g.data_ptr() % 16 == 0:
             dw = _wgrad(x, g, cout)
-            db = g.sum(dim=(0, 2, 3)) if need_b else None
+            db = conv_s2._bias_grad(g) if need_b else None   # (streaming channel sums, csrc/sum_parts.hip)
         elif ctx.needs_input_grad[1] or need_b:
             _, dw, db = torch.ops.aten.convolution_backward(
                 g, x, weight, [cout] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,

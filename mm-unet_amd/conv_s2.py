@@ -49,6 +49,19 @@ def _wgrad(high, low, k):
     return dw
 
 
+def _bias_grad(g):
+    """sum over (batch, height, width) of a float32 NCHW gradient: a streaming pass (csrc/sum_parts.hip) where the shape
+    allows it, ATen's reduction otherwise."""
+    B, C, H, W = g.shape
+    if (H * W) % 4 != 0 or g.data_ptr() % 16 != 0 or not g.is_contiguous():
+        return g.sum(dim=(0, 2, 3))
+    ws = torch.empty(B * C, device=g.device, dtype=torch.float32)
+    out = torch.empty(C, device=g.device, dtype=torch.float32)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().mmu_channel_sum(g.data_ptr(), B, C, H * W, ws.data_ptr(), out.data_ptr(), _lib.stream_of(g)))
+    return out
+
+
 def _wgrad_ok(c_high, c_low, wo, low):
     return c_high % 64 == 0 and c_low % 64 == 0 and wo % 4 == 0 and low.data_ptr() % 16 == 0
 
@@ -113,7 +126,7 @@ class ConvS2Fn(torch.autograd.Function):
                 dw = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
         if need_b:
-            db = g.sum(dim=(0, 2, 3))
+            db = _bias_grad(g)
         return dx, dw, db
 
 
@@ -153,7 +166,7 @@ class ConvT2Fn(torch.autograd.Function):
                 dw = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1,
                                                          [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = g.sum(dim=(0, 2, 3))
+            db = _bias_grad(g)
         return dx, dw, db
 
 

@@ -39,7 +39,51 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(SumArgs a) {
     }
 }
 
+// Bias gradient of a convolution: out[c] = sum over (b, h, w) of g[b, c, h, w].  Stage 1: one workgroup per (b, c) row
+// (1,024 threads, 16-byte loads: the rows are contiguous) writes the row sum; stage 2 adds the B row sums of a channel in
+// order.  (ATen's generic reduction took 145 us for [8, 64, 256, 256] = 0.9 TB/s; this is a streaming pass.)
+__global__ __launch_bounds__(1024) void channel_sum_rows_kernel(const float *__restrict__ g, float *__restrict__ rows, long hw) {
+    __shared__ float red[16];
+    const float *r = g + (long)blockIdx.x * hw;
+    float s = 0.f;
+    const long n4 = hw / 4;
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(r + 4 * i);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < hw; i += 1024) s += r[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        rows[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void channel_sum_batch_kernel(const float *__restrict__ rows, float *__restrict__ out,
+                                                                int batch, int channels) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= channels) return;
+    float t = 0.f;
+    for (int b = 0; b < batch; ++b) t += rows[(long)b * channels + c];
+    out[c] = t;
+}
+
 }  // namespace
+
+extern "C" int mmu_channel_sum(const float *g, int batch, int channels, int64_t hw, float *workspace, float *out, void *stream) {
+    MMU_CHECK(g && workspace && out && batch > 0 && channels > 0 && hw > 0, "channel_sum: g, workspace, out and positive sizes required");
+    MMU_CHECK(((uintptr_t)g & 15) == 0 && hw % 4 == 0, "channel_sum: g must be 16-byte aligned and hw a multiple of 4");
+    MMU_CHECK((long)batch * channels < (1L << 31), "channel_sum: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    channel_sum_rows_kernel<<<(unsigned)(batch * channels), 1024, 0, st>>>(g, workspace, hw);
+    MMU_HIP_LAUNCH_CHECK("channel_sum(rows)");
+    channel_sum_batch_kernel<<<(channels + 255) / 256, 256, 0, st>>>(workspace, out, batch, channels);
+    MMU_HIP_LAUNCH_CHECK("channel_sum");
+    return 0;
+}
 
 extern "C" int mmu_sum_parts(const mmu_sum_parts_params *p, void *stream) {
     MMU_CHECK(p != nullptr, "sum_parts: null params");
