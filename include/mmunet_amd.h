@@ -550,9 +550,16 @@ typedef struct {
     const float *dout;                    /* [planes, out_height, out_width] */
     const void *indices;                  /* int64, same shape as dout */
     float *dinput;                        /* [planes, height, width] */
+    const float *input;                   /* fwd: [planes, height, width] */
+    float *out;                           /* fwd: [planes, out_height, out_width] */
+    uint8_t *codes;                       /* fwd (written) / bwd_codes (read): arg-max position 3 * dy + dx inside the window */
 } mmu_maxpool_params;
 
 int mmu_maxpool3s2_bwd(const mmu_maxpool_params *p, void *stream);
+/* The pooling itself with one-byte arg-max codes (first maximum in row-major window order, NaN wins: ATen's choice), and
+ * the gather backward from those codes. */
+int mmu_maxpool3s2_fwd(const mmu_maxpool_params *p, void *stream);
+int mmu_maxpool3s2_bwd_codes(const mmu_maxpool_params *p, void *stream);
 
 /* ---- out = sum of up to four float32 tensors, as float32 or bfloat16 (the state-group sums of a d_state > 16 scan) -- */
 /* selective_scan_hip._fwd_groups / _bwd_groups: the per-token outputs of a d_state-64 scan are the sums of its four

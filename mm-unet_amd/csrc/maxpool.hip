@@ -1,5 +1,6 @@
 // maxpool.hip -- backward of nn.MaxPool2d(kernel_size=3, stride=2, padding=1) as a gather.
 //
+// (round 3: also the forward, with one-byte arg-max codes, and a backward that reads them -- mmu_maxpool3s2_fwd / _bwd_codes.)
 // Where it sits: MM_Net's stem (src/UM_Net/MMUNet.py:493,537 `self.maxpool`, applied to the 64 x 256 x 256 stem map).  The
 // forward stays ATen's (0.09 ms; it returns the arg-max indices); ATen's backward zero-fills d input and scatters the
 // output gradients with float atomics (windows overlap): 18 + 221 us for [8, 64, 128, 128] -> [8, 64, 256, 256].
@@ -52,7 +53,239 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float *__rest
     }
 }
 
+// Forward with the arg-max kept as ONE byte per output (position 3 * dy + dx inside its window; ATen: an int64 plane
+// index, 8x the bytes, and 97 us for [8, 64, 256, 256]).  Same choice as ATen's kernel among equal values: the first in
+// row-major window order (strict >), NaN wins.  thread = one output element.
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                             unsigned char *__restrict__ code, int H, int W, int OH, int OW,
+                                                             long planes) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)OH * OW;
+    if (t >= planes * per) return;
+    const long plane = t / per;
+    const int o = (int)(t - plane * per);
+    const int oy = o / OW, ox = o - oy * OW;
+    const float *xp = x + plane * H * W;
+    float best = -INFINITY;
+    int bc = 0;
+    bool first = true;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int y = 2 * oy - 1 + dy;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = 2 * ox - 1 + dx;
+            if (xx < 0 || xx >= W) continue;
+            const float v = xp[(long)y * W + xx];
+            if (first || v > best || v != v) {   // (the first valid element stands in for ATen's -inf start)
+                best = v;
+                bc = dy * 3 + dx;
+                first = false;
+            }
+        }
+    }
+    out[t] = best;
+    code[t] = (unsigned char)bc;
+}
+
+// Backward from the byte codes: every input pixel adds the gradients of the (at most four) windows whose code points at it.
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_code_kernel(const float *__restrict__ g,
+                                                                  const unsigned char *__restrict__ code,
+                                                                  float *__restrict__ dx, int H, int W, int OH, int OW,
+                                                                  unsigned total) {
+    const int wq = (W + 3) / 4;
+    const unsigned t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int q = (int)(t % (unsigned)wq);
+    const unsigned r = t / (unsigned)wq;
+    const int y = (int)(r % (unsigned)H);
+    const long plane = r / (unsigned)H;
+    const float *gp = g + plane * OH * OW;
+    const unsigned char *cp = code + plane * OH * OW;
+    const int oy0 = y >> 1, oy1 = (y + 1) >> 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = q * 4 + j;
+        if (x >= W) break;
+        const int ox0 = x >> 1, ox1 = (x + 1) >> 1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = a == 0 ? oy0 : oy1;
+            if ((a == 1 && oy1 == oy0) || oy >= OH) continue;
+            const int dy = y - (2 * oy - 1);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ox = b == 0 ? ox0 : ox1;
+                if ((b == 1 && ox1 == ox0) || ox >= OW) continue;
+                const int o = oy * OW + ox;
+                if (cp[o] == dy * 3 + (x - (2 * ox - 1))) acc[j] += gp[o];
+            }
+        }
+    }
+    float *dst = dx + (plane * H + y) * W + q * 4;
+    if ((W & 3) == 0) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+        for (int j = 0; j < 4 && q * 4 + j < W; ++j) dst[j] = acc[j];
+    }
+}
+
+// The same two for W % 8 == 0 and even H (the stem: 256 x 256), vector loads and stores.
+// Forward: thread = four neighbouring outputs of one row; per input row two float4 (columns 8q .. 8q+7) and the column left
+// of them.
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_v4_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                                unsigned char *__restrict__ code, int H, int W, int OH,
+                                                                unsigned total) {
+    const unsigned t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int OW = W >> 1, oq = OW >> 2;
+    const int q = (int)(t % (unsigned)oq);
+    const unsigned r = t / (unsigned)oq;
+    const int oy = (int)(r % (unsigned)OH);
+    const long plane = r / (unsigned)OH;
+    const float *xp = x + plane * H * W + 8 * q;
+    float v[3][9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int y = min(max(2 * oy - 1 + dy, 0), H - 1);       // (clamped: the row above the image is masked below)
+        const float *row = xp + (long)y * W;
+        const float4 a = *reinterpret_cast<const float4 *>(row);
+        const float4 b = *reinterpret_cast<const float4 *>(row + 4);
+        v[dy][0] = row[q > 0 ? -1 : 0];
+        v[dy][1] = a.x; v[dy][2] = a.y; v[dy][3] = a.z; v[dy][4] = a.w;
+        v[dy][5] = b.x; v[dy][6] = b.y; v[dy][7] = b.z; v[dy][8] = b.w;
+    }
+    float best[4];
+    unsigned codes = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float bv = 0.f;
+        int bc = 0;
+        bool first = true;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if (dy == 0 && oy == 0) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (j == 0 && dx == 0 && q == 0) continue;
+                const float val = v[dy][2 * j + dx];
+                if (first || val > bv || val != val) {
+                    bv = val;
+                    bc = dy * 3 + dx;
+                    first = false;
+                }
+            }
+        }
+        best[j] = bv;
+        codes |= (unsigned)bc << (8 * j);
+    }
+    const long o = ((plane * OH + oy) * OW) + 4 * q;
+    *reinterpret_cast<float4 *>(out + o) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<unsigned *>(code + o) = codes;
+}
+
+// Backward: thread = input rows 2r, 2r+1, columns 8q .. 8q+7; it needs gradient rows r, r+1 at columns 4q .. 4q+4.
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_code_v8_kernel(const float *__restrict__ g,
+                                                                     const unsigned char *__restrict__ code,
+                                                                     float *__restrict__ dx, int H, int W, unsigned total) {
+    const unsigned t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int OH = H >> 1, OW = W >> 1, wq = W >> 3;
+    const int q = (int)(t % (unsigned)wq);
+    const unsigned rr = t / (unsigned)wq;
+    const int r = (int)(rr % (unsigned)OH);
+    const long plane = rr / (unsigned)OH;
+    const bool row1 = r + 1 < OH, col4 = 4 * q + 4 < OW;
+    float gv[2][5];
+    int cv[2][5];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const long o = (plane * OH + min(r + a, OH - 1)) * OW + 4 * q;
+        const float4 g4 = *reinterpret_cast<const float4 *>(g + o);
+        const unsigned c4 = *reinterpret_cast<const unsigned *>(code + o);
+        const float g1 = g[o + (col4 ? 4 : 0)];
+        const int c1 = code[o + (col4 ? 4 : 0)];
+        const bool ok = a == 0 || row1;
+        gv[a][0] = g4.x; gv[a][1] = g4.y; gv[a][2] = g4.z; gv[a][3] = g4.w; gv[a][4] = g1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cv[a][i] = ok ? (int)((c4 >> (8 * i)) & 255u) : 255;
+        cv[a][4] = ok && col4 ? c1 : 255;
+    }
+    float top[8], bot[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int o0 = i >> 1, o1 = (i + 1) >> 1;        // windows left / right of the pixel (the same one for even i)
+        const int dx0 = (i & 1) ? 2 : 1;                 // position of the pixel inside window o0; inside o1 (odd i): 0
+        // row 2r: window row r, dy = 1
+        float s = cv[0][o0] == 3 + dx0 ? gv[0][o0] : 0.f;
+        if (i & 1) s += cv[0][o1] == 3 ? gv[0][o1] : 0.f;
+        top[i] = s;
+        // row 2r+1: window row r with dy = 2, then window row r + 1 with dy = 0
+        s = cv[0][o0] == 6 + dx0 ? gv[0][o0] : 0.f;
+        if (i & 1) s += cv[0][o1] == 6 ? gv[0][o1] : 0.f;
+        s += cv[1][o0] == dx0 ? gv[1][o0] : 0.f;
+        if (i & 1) s += cv[1][o1] == 0 ? gv[1][o1] : 0.f;
+        bot[i] = s;
+    }
+    float *dst = dx + (plane * H + 2 * r) * W + 8 * q;
+    *reinterpret_cast<float4 *>(dst) = make_float4(top[0], top[1], top[2], top[3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4(top[4], top[5], top[6], top[7]);
+    *reinterpret_cast<float4 *>(dst + W) = make_float4(bot[0], bot[1], bot[2], bot[3]);
+    *reinterpret_cast<float4 *>(dst + W + 4) = make_float4(bot[4], bot[5], bot[6], bot[7]);
+}
+
+inline bool maxpool_vector_ok(const mmu_maxpool_params *p) {
+    static const bool off = getenv("MMU_MAXPOOL_VEC") && atoi(getenv("MMU_MAXPOOL_VEC")) == 0;
+    return !off && p->width % 8 == 0 && p->height % 2 == 0;
+}
+
 }  // namespace
+
+extern "C" int mmu_maxpool3s2_fwd(const mmu_maxpool_params *p, void *stream) {
+    MMU_CHECK(p != nullptr, "maxpool3s2_fwd: null params");
+    MMU_CHECK(p->planes > 0 && p->height > 0 && p->width > 0, "maxpool3s2_fwd: empty tensor");
+    MMU_CHECK(p->out_height == (p->height - 1) / 2 + 1 && p->out_width == (p->width - 1) / 2 + 1,
+              "maxpool3s2_fwd: output size must be that of kernel 3 / stride 2 / padding 1");
+    MMU_CHECK(p->input && p->out && p->codes, "maxpool3s2_fwd: input, out, codes are required");
+    const long total = (long)p->planes * p->out_height * p->out_width;
+    MMU_CHECK(total < (1L << 40), "maxpool3s2_fwd: tensor too large");
+    if (maxpool_vector_ok(p) && total / 4 < (1L << 32) && ((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->out & 15) == 0 &&
+        ((uintptr_t)p->codes & 3) == 0) {
+        const unsigned n = (unsigned)(total / 4);
+        maxpool3s2_fwd_v4_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(p->input, p->out, p->codes, p->height,
+                                                                                   p->width, p->out_height, n);
+        MMU_HIP_LAUNCH_CHECK("maxpool3s2_fwd");
+        return 0;
+    }
+    maxpool3s2_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        p->input, p->out, p->codes, p->height, p->width, p->out_height, p->out_width, p->planes);
+    MMU_HIP_LAUNCH_CHECK("maxpool3s2_fwd");
+    return 0;
+}
+
+extern "C" int mmu_maxpool3s2_bwd_codes(const mmu_maxpool_params *p, void *stream) {
+    MMU_CHECK(p != nullptr, "maxpool3s2_bwd_codes: null params");
+    MMU_CHECK(p->planes > 0 && p->height > 0 && p->width > 0, "maxpool3s2_bwd_codes: empty tensor");
+    MMU_CHECK(p->out_height == (p->height - 1) / 2 + 1 && p->out_width == (p->width - 1) / 2 + 1,
+              "maxpool3s2_bwd_codes: output size must be that of kernel 3 / stride 2 / padding 1");
+    MMU_CHECK(p->dout && p->codes && p->dinput, "maxpool3s2_bwd_codes: dout, codes, dinput are required");
+    MMU_CHECK(((uintptr_t)p->dinput & 15) == 0, "maxpool3s2_bwd_codes: dinput must be 16-byte aligned");
+    const long total = (long)p->planes * p->height * ((p->width + 3) / 4);
+    MMU_CHECK(total < (1L << 32), "maxpool3s2_bwd_codes: tensor too large");
+    if (maxpool_vector_ok(p) && ((uintptr_t)p->dout & 15) == 0 && ((uintptr_t)p->codes & 3) == 0) {
+        const unsigned n = (unsigned)((long)p->planes * (p->height / 2) * (p->width / 8));
+        maxpool3s2_bwd_code_v8_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(p->dout, p->codes, p->dinput,
+                                                                                        p->height, p->width, n);
+        MMU_HIP_LAUNCH_CHECK("maxpool3s2_bwd_codes");
+        return 0;
+    }
+    maxpool3s2_bwd_code_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        p->dout, p->codes, p->dinput, p->height, p->width, p->out_height, p->out_width, (unsigned)total);
+    MMU_HIP_LAUNCH_CHECK("maxpool3s2_bwd_codes");
+    return 0;
+}
 
 extern "C" int mmu_maxpool3s2_bwd(const mmu_maxpool_params *p, void *stream) {
     MMU_CHECK(p != nullptr, "maxpool3s2_bwd: null params");

@@ -1,6 +1,7 @@
-"""``max_pool3s2`` -- ``nn.MaxPool2d(kernel_size=3, stride=2, padding=1)`` (src/UM_Net/MMUNet.py:493,537) with ATen's
-forward (it returns the arg-max indices) and a gather backward (csrc/maxpool.hip): no atomics, no zero fill,
-bit-reproducible; ATen's scatter backward takes 18 + 221 us at [8, 64, 256, 256], this one a quarter of that.
+"""``max_pool3s2`` -- ``nn.MaxPool2d(kernel_size=3, stride=2, padding=1)`` (src/UM_Net/MMUNet.py:493,537): forward with
+one-byte arg-max codes (ATen's choice among equal values) and a gather backward from them (csrc/maxpool.hip): no
+atomics, no zero fill, bit-reproducible; ATen: 97 us forward (int64 indices), 18 + 221 us scatter backward at
+[8, 64, 256, 256].
 float32 contiguous NCHW on the GPU; anything else is the module's own path."""
 import torch
 import torch.nn.functional as F
@@ -23,22 +24,30 @@ class MaxPool3s2Fn(torch.autograd.Function):
         if x.dim() != 4 or x.dtype != torch.float32:
             raise RuntimeError("max_pool3s2: float32 (B, C, H, W) tensor required")
         x = x.contiguous()
-        out, idx = F.max_pool2d(x, 3, 2, 1, return_indices=True)
-        ctx.save_for_backward(idx)
+        B, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((B, C, OH, OW), device=x.device, dtype=torch.float32)
+        codes = torch.empty((B, C, OH, OW), device=x.device, dtype=torch.uint8)   # arg-max position inside the window
+        p = _lib.MaxPoolParams()
+        p.planes, p.height, p.width, p.out_height, p.out_width = B * C, H, W, OH, OW
+        p.input, p.out, p.codes = x.data_ptr(), out.data_ptr(), codes.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_maxpool3s2_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(codes)
         ctx.in_shape = x.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
-        idx, = ctx.saved_tensors
+        codes, = ctx.saved_tensors
         B, C, H, W = ctx.in_shape
         g = g.float().contiguous()
         dx = torch.empty(ctx.in_shape, device=g.device, dtype=torch.float32)
         p = _lib.MaxPoolParams()
         p.planes, p.height, p.width, p.out_height, p.out_width = B * C, H, W, g.shape[2], g.shape[3]
-        p.dout, p.indices, p.dinput = g.data_ptr(), idx.data_ptr(), dx.data_ptr()
+        p.dout, p.codes, p.dinput = g.data_ptr(), codes.data_ptr(), dx.data_ptr()
         with torch.cuda.device(g.device):
-            _lib.check(_lib.lib().mmu_maxpool3s2_bwd(p, _lib.stream_of(g)))
+            _lib.check(_lib.lib().mmu_maxpool3s2_bwd_codes(p, _lib.stream_of(g)))
         return dx
 
 

@@ -1291,7 +1291,8 @@ def test_tri_block_channels_first_bf16_route_vs_bld_route():
         assert rel <= 6e-2, (k, rel)
 
 
-@pytest.mark.parametrize("shape", [(8, 64, 256, 256), (2, 3, 17, 23), (1, 5, 8, 6), (3, 2, 33, 64)])
+@pytest.mark.parametrize("shape", [(8, 64, 256, 256), (2, 3, 17, 23), (1, 5, 8, 6), (3, 2, 33, 64), (2, 3, 16, 24),
+                                   (1, 2, 2, 8)])
 def test_max_pool3s2_vs_module(shape):
     """maxpool.max_pool3s2 == nn.MaxPool2d(3, 2, 1) (MMUNet.py:493,537): same output, the gather backward against
     ATen's scatter backward (ties included: values on a coarse grid), bit-reproducible."""
@@ -1314,6 +1315,11 @@ def test_max_pool3s2_vs_module(shape):
     close(grads[0], xr.grad, 1e-6, 1e-6, "d input")
     assert torch.equal(grads[0], grads[1])
     assert not maxpool.module_supported(torch.nn.MaxPool2d(2, 2), x)
+    # NaN wins its windows, as in ATen; -inf planes stay -inf
+    xn = x.clone()
+    xn.view(-1)[::7] = float("nan")
+    xn[0, 0] = float("-inf")
+    assert torch.equal(torch.nan_to_num(maxpool.pool_module(m, xn), nan=12345.0), torch.nan_to_num(m(xn), nan=12345.0))
 
 
 @pytest.mark.parametrize("shape", [(8, 256, 256), (2, 13, 9), (1, 5, 40), (3, 64, 64)])
