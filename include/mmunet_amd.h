@@ -269,6 +269,8 @@ typedef struct {
     void *dinput;        /* bwd: [planes, in_h, in_w] */
     int32_t dtype;       /* element type of all four: MMU_DTYPE_F32 (0, the default of a zeroed struct) or
                           * MMU_DTYPE_BF16; the interpolation itself is float32 */
+    const void *dinput_addend; /* bwd, optional: [planes, in_h, in_w] added to the gathered gradient (another consumer's
+                                * gradient of the same input; may be dinput itself) */
 } mmu_resize_params;
 
 int mmu_bilinear_resize_fwd(const mmu_resize_params *p, void *stream);
@@ -496,6 +498,8 @@ typedef struct {
     const float *dmean, *dmax;   /* bwd, MMU_STATS_PIXELS */
     const float *dout;     /* bwd, MMU_STATS_CHANNELS */
     float *dinput;         /* bwd */
+    const float *dinput_addend;  /* bwd, optional: added to the statistics' gradient (another consumer's gradient of the
+                                  * same input; may be dinput itself) */
 } mmu_cbam_stats_params;
 
 int mmu_cbam_stats_fwd(const mmu_cbam_stats_params *p, void *stream);
@@ -517,6 +521,12 @@ typedef struct {
     const float *dout;     /* bwd */
     float *dinput;         /* bwd, optional */
     float *dgate;          /* bwd, optional */
+    /* bwd, MMU_GATE_CHANNEL, optional (both or neither): the gradient that reaches `out` through CBAM's channel
+     * statistics of it (mmu_cbam_stats, MMU_STATS_CHANNELS) is added to dout on the fly --
+     * dout'[b][c][p] = dout + (stats_dout[b][1][p] / channels + [c == stats_argmax[b][p]] stats_dout[b][0][p]) --
+     * instead of being materialised and added by two more passes over the map */
+    const float *stats_dout;     /* [batch, 2, hw] */
+    const int32_t *stats_argmax; /* [batch, hw] */
 } mmu_gated_mul_params;
 
 int mmu_gated_mul_fwd(const mmu_gated_mul_params *p, void *stream);
@@ -553,6 +563,7 @@ typedef struct {
     const float *input;                   /* fwd: [planes, height, width] */
     float *out;                           /* fwd: [planes, out_height, out_width] */
     uint8_t *codes;                       /* fwd (written) / bwd_codes (read): arg-max position 3 * dy + dx inside the window */
+    const float *dinput_addend;           /* bwd_codes, optional: added to the gathered gradient (may be dinput itself) */
 } mmu_maxpool_params;
 
 int mmu_maxpool3s2_bwd(const mmu_maxpool_params *p, void *stream);

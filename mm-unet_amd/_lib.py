@@ -74,7 +74,7 @@ class MorphParams(ctypes.Structure):
 class ResizeParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("planes", "in_h", "in_w", "out_h", "out_w")]
                 + [(n, _vp) for n in ("input", "out", "dout", "dinput")]
-                + [("dtype", _i32)])
+                + [("dtype", _i32), ("dinput_addend", _vp)])
 
 
 class Conv3x3sParams(ctypes.Structure):
@@ -131,12 +131,12 @@ class GemmNtParams(ctypes.Structure):
 
 class CbamStatsParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("channels", _i32), ("mode", _i32), ("hw", _i64)] + \
-               [(n, _vp) for n in ("input", "mean", "max", "out", "argmax", "dmean", "dmax", "dout", "dinput")]
+               [(n, _vp) for n in ("input", "mean", "max", "out", "argmax", "dmean", "dmax", "dout", "dinput", "dinput_addend")]
 
 
 class GatedMulParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("channels", _i32), ("mode", _i32), ("hw", _i64)] + \
-               [(n, _vp) for n in ("input", "gate", "out", "dout", "dinput", "dgate")]
+               [(n, _vp) for n in ("input", "gate", "out", "dout", "dinput", "dgate", "stats_dout", "stats_argmax")]
 
 
 class Conv7x7Params(ctypes.Structure):
@@ -146,7 +146,7 @@ class Conv7x7Params(ctypes.Structure):
 
 class MaxPoolParams(ctypes.Structure):
     _fields_ = [("planes", _i64)] + [(n, _i32) for n in ("height", "width", "out_height", "out_width")] + \
-               [(n, _vp) for n in ("dout", "indices", "dinput", "input", "out", "codes")]
+               [(n, _vp) for n in ("dout", "indices", "dinput", "input", "out", "codes", "dinput_addend")]
 
 
 class SumPartsParams(ctypes.Structure):

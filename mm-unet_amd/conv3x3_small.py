@@ -36,6 +36,55 @@ class GradSlot:
         self.armed, self.grad = False, None
 
 
+class SharedGrad:
+    """The same hand-over for ANY number of consumers of one tensor (MM_Net: the CBAM edge map feeds three RCG blocks and
+    the line head; the stem features feed the max-pool and CBAM).  Every consumer whose backward produces an input
+    gradient calls ``join()`` in its forward; in its backward it ``take()``s what the consumers before it left (None for
+    the first), writes ``own + taken`` in one kernel and hands the result to ``give()``, which parks it and returns None
+    while consumers are still to come and returns the total to the last one -- autograd routes one gradient and adds
+    nothing (each add it would run is a 400 MB pass at 256 x 256 x 64 x 8)."""
+    __slots__ = ("pending", "grad")
+
+    def __init__(self):
+        self.pending, self.grad = 0, None
+
+    def join(self):
+        self.pending += 1
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
+
+    def give(self, total):
+        self.pending -= 1
+        if self.pending > 0:
+            self.grad = total
+            return None
+        return total
+
+
+class _JoinGradFn(torch.autograd.Function):
+    """Identity that makes whatever consumes its output a member of a SharedGrad without kernel support: first in line it
+    parks the gradient as it is; later it adds what was parked with an ATen add (the order autograd runs MM_Net's
+    branches in makes it the first)."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        slot.join()
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        parked = ctx.slot.take()
+        return ctx.slot.give(g if parked is None else parked.add_(g)), None
+
+
+def shared_input(x, slot):
+    """``x`` for a consumer that cannot add a parked gradient itself (see SharedGrad)."""
+    return _JoinGradFn.apply(x, slot) if (slot is not None and x.requires_grad and torch.is_grad_enabled()) else x
+
+
 class Conv3x3SmallFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, slot=None):
@@ -65,7 +114,12 @@ class Conv3x3SmallFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
         ctx.slot = slot
-        if slot is not None:
+        if isinstance(slot, SharedGrad):
+            if ctx.needs_input_grad[0]:
+                slot.join()
+            else:
+                ctx.slot = None
+        elif slot is not None:
             slot.armed = bool(ctx.needs_input_grad[0])
         return out
 
@@ -79,8 +133,11 @@ class Conv3x3SmallFn(torch.autograd.Function):
         dx = dw = db = None
         if need_x:
             parked = None
-            if ctx.slot is not None and ctx.slot.grad is not None:
+            if isinstance(ctx.slot, SharedGrad):
+                parked = ctx.slot.take()
+            elif ctx.slot is not None and ctx.slot.grad is not None:
                 parked, ctx.slot.grad = ctx.slot.grad, None
+            if parked is not None:
                 if parked.shape != x.shape or parked.dtype != x.dtype or not parked.is_contiguous():
                     raise RuntimeError("conv3x3_small: parked input gradient does not match the input")
             dx = parked if parked is not None else torch.empty_like(x)     # (in place on the parked gradient)
@@ -92,6 +149,8 @@ class Conv3x3SmallFn(torch.autograd.Function):
             p.in_dtype = _lib.dtype_code(x)
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
+            if isinstance(ctx.slot, SharedGrad):
+                dx = ctx.slot.give(dx)
         if need_w or need_b:
             if WEIGHT_GRAD_NATIVE:
                 dw = torch.empty(ctx.wshape, device=x.device, dtype=torch.float32)

@@ -55,16 +55,21 @@ __global__ __launch_bounds__(1024) void cs_rows_fwd_kernel(const float *__restri
 }
 
 __global__ __launch_bounds__(256) void cs_rows_bwd_kernel(const float *__restrict__ gmean, const float *__restrict__ gmax,
-                                                          const int *__restrict__ amax, float *__restrict__ dx, long hw,
-                                                          long total4) {
+                                                          const int *__restrict__ amax, float *dx, const float *addend,
+                                                          long hw, long total4) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const long row = i / (hw / 4);
     const int p0 = (int)((i - row * (hw / 4)) * 4);
     const float a = gmean[row] / (float)hw, m = gmax[row];
     const int am = amax[row];
-    reinterpret_cast<float4 *>(dx)[i] = make_float4(a + (am == p0 ? m : 0.f), a + (am == p0 + 1 ? m : 0.f),
-                                                    a + (am == p0 + 2 ? m : 0.f), a + (am == p0 + 3 ? m : 0.f));
+    float4 v = make_float4(a + (am == p0 ? m : 0.f), a + (am == p0 + 1 ? m : 0.f), a + (am == p0 + 2 ? m : 0.f),
+                           a + (am == p0 + 3 ? m : 0.f));
+    if (addend) {
+        const float4 o = reinterpret_cast<const float4 *>(addend)[i];
+        v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+    }
+    reinterpret_cast<float4 *>(dx)[i] = v;
 }
 
 // ---- over the channels of a pixel --------------------------------------------------------------------------------------
@@ -92,19 +97,26 @@ __global__ __launch_bounds__(256) void cs_chan_fwd_kernel(const float *__restric
 }
 
 __global__ __launch_bounds__(256) void cs_chan_bwd_kernel(const float *__restrict__ g, const int *__restrict__ amax,
-                                                          float *__restrict__ dx, int C, long HW4) {
+                                                          float *dx, const float *addend, int C, long HW4) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= HW4) return;
     const int b = blockIdx.y;
     const float4 *gp = reinterpret_cast<const float4 *>(g) + (long)b * 2 * HW4 + q;
+    const float4 *ap = addend ? reinterpret_cast<const float4 *>(addend) + (long)b * C * HW4 + q : nullptr;
     const float4 gm = gp[0], ga = gp[HW4];
     const int4 am = reinterpret_cast<const int4 *>(amax)[b * HW4 + q];
     const float inv = 1.f / (float)C;
     const float4 a = make_float4(ga.x * inv, ga.y * inv, ga.z * inv, ga.w * inv);
     float4 *dp = reinterpret_cast<float4 *>(dx) + (long)b * C * HW4 + q;
-    for (int c = 0; c < C; ++c)
-        dp[c * HW4] = make_float4(a.x + (am.x == c ? gm.x : 0.f), a.y + (am.y == c ? gm.y : 0.f),
-                                  a.z + (am.z == c ? gm.z : 0.f), a.w + (am.w == c ? gm.w : 0.f));
+    for (int c = 0; c < C; ++c) {
+        float4 v = make_float4(a.x + (am.x == c ? gm.x : 0.f), a.y + (am.y == c ? gm.y : 0.f),
+                               a.z + (am.z == c ? gm.z : 0.f), a.w + (am.w == c ? gm.w : 0.f));
+        if (ap) {
+            const float4 o = ap[c * HW4];
+            v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        }
+        dp[c * HW4] = v;
+    }
 }
 
 int check(const mmu_cbam_stats_params *p, const char *name) {
@@ -141,17 +153,18 @@ extern "C" int mmu_cbam_stats_bwd(const mmu_cbam_stats_params *p, void *stream) 
     if (int r = check(p, "cbam_stats_bwd")) return r;
     MMU_CHECK(p->argmax && p->dinput && ((uintptr_t)p->dinput & 15) == 0 && ((uintptr_t)p->argmax & 15) == 0,
               "cbam_stats_bwd: argmax and dinput (16-byte aligned) are required");
+    MMU_CHECK(((uintptr_t)p->dinput_addend & 15) == 0, "cbam_stats_bwd: dinput_addend must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long HW4 = p->hw / 4;
     if (p->mode == MMU_STATS_PIXELS) {
         MMU_CHECK(p->dmean && p->dmax, "cbam_stats_bwd: dmean and dmax are required");
         const long total4 = (long)p->batch * p->channels * HW4;
-        cs_rows_bwd_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, st>>>(p->dmean, p->dmax, p->argmax, p->dinput, p->hw,
-                                                                           total4);
+        cs_rows_bwd_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, st>>>(p->dmean, p->dmax, p->argmax, p->dinput,
+                                                                           p->dinput_addend, p->hw, total4);
     } else {
         MMU_CHECK(p->dout && ((uintptr_t)p->dout & 15) == 0, "cbam_stats_bwd: dout (16-byte aligned) is required");
         cs_chan_bwd_kernel<<<dim3((unsigned)((HW4 + 255) / 256), p->batch), 256, 0, st>>>(p->dout, p->argmax, p->dinput,
-                                                                                         p->channels, HW4);
+                                                                                         p->dinput_addend, p->channels, HW4);
     }
     MMU_HIP_LAUNCH_CHECK("cbam_stats_bwd");
     return 0;

@@ -35,15 +35,31 @@ __global__ __launch_bounds__(256) void gm_channel_fwd_kernel(const float *__rest
 
 __global__ __launch_bounds__(1024) void gm_channel_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gate,
                                                               const float *__restrict__ g, float *__restrict__ dx,
-                                                              float *__restrict__ dgate, long HW4) {
+                                                              float *__restrict__ dgate, long HW4,
+                                                              const float *__restrict__ sg, const int *__restrict__ sam,
+                                                              int C) {
     __shared__ float red[16];
     const long row = blockIdx.x;
     const float gv = gate[row];
+    // (sg, sam: the gradient through the channel statistics of this product, added to g on the fly)
+    const int bi = (int)(row / C), c = (int)(row - (long)bi * C);
+    const float4 *sgm = sg ? reinterpret_cast<const float4 *>(sg) + (long)bi * 2 * HW4 : nullptr;
+    const int4 *samp = sg ? reinterpret_cast<const int4 *>(sam) + (long)bi * HW4 : nullptr;
+    const float invC = 1.f / (float)C;
     const float4 *xp = reinterpret_cast<const float4 *>(x) + row * HW4, *gp = reinterpret_cast<const float4 *>(g) + row * HW4;
     float4 *dp = dx ? reinterpret_cast<float4 *>(dx) + row * HW4 : nullptr;
     float s = 0.f;
     for (long i = threadIdx.x; i < HW4; i += blockDim.x) {
-        const float4 a = xp[i], b = gp[i];
+        const float4 a = xp[i];
+        float4 b = gp[i];
+        if (sgm) {
+            const float4 gm = sgm[i], ga = sgm[HW4 + i];
+            const int4 am = samp[i];
+            b.x += ga.x * invC + (am.x == c ? gm.x : 0.f);
+            b.y += ga.y * invC + (am.y == c ? gm.y : 0.f);
+            b.z += ga.z * invC + (am.z == c ? gm.z : 0.f);
+            b.w += ga.w * invC + (am.w == c ? gm.w : 0.f);
+        }
         s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
         if (dp) dp[i] = make_float4(b.x * gv, b.y * gv, b.z * gv, b.w * gv);
     }
@@ -121,12 +137,16 @@ extern "C" int mmu_gated_mul_bwd(const mmu_gated_mul_params *p, void *stream) {
     MMU_CHECK(p->dout && (p->dinput || p->dgate), "gated_mul_bwd: dout and at least one of dinput / dgate are required");
     const void *ptrs[] = {p->input, p->gate, p->dout, p->dinput, p->dgate};
     for (const void *q : ptrs) MMU_CHECK(((uintptr_t)q & 15) == 0, "gated_mul_bwd: tensors must be 16-byte aligned");
+    MMU_CHECK((p->stats_dout == nullptr) == (p->stats_argmax == nullptr) && (!p->stats_dout || p->mode == MMU_GATE_CHANNEL) &&
+                  ((uintptr_t)p->stats_dout & 15) == 0 && ((uintptr_t)p->stats_argmax & 15) == 0,
+              "gated_mul_bwd: stats_dout / stats_argmax come together (16-byte aligned), for the channel gate only");
     hipStream_t st = (hipStream_t)stream;
     const long HW4 = p->hw / 4;
     if (p->mode == MMU_GATE_CHANNEL) {
         const int threads = HW4 >= 2048 ? 1024 : 256;
         gm_channel_bwd_kernel<<<(unsigned)(p->batch * p->channels), threads, 0, st>>>(p->input, p->gate, p->dout, p->dinput,
-                                                                                     p->dgate, HW4);
+                                                                                     p->dgate, HW4, p->stats_dout,
+                                                                                     p->stats_argmax, p->channels);
     } else {
         gm_spatial_bwd_kernel<<<dim3((unsigned)((HW4 + 255) / 256), p->batch), 256, 0, st>>>(p->input, p->gate, p->dout,
                                                                                             p->dinput, p->dgate, p->channels, HW4);

@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float *__rest
 // Backward from the byte codes: every input pixel adds the gradients of the (at most four) windows whose code points at it.
 __global__ __launch_bounds__(256) void maxpool3s2_bwd_code_kernel(const float *__restrict__ g,
                                                                   const unsigned char *__restrict__ code,
-                                                                  float *__restrict__ dx, int H, int W, int OH, int OW,
-                                                                  unsigned total) {
+                                                                  float *dx, const float *addend, int H, int W, int OH,
+                                                                  int OW, unsigned total) {
     const int wq = (W + 3) / 4;
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_code_kernel(const float *_
         }
     }
     float *dst = dx + (plane * H + y) * W + q * 4;
+    if (addend) {
+        const float *ad = addend + (plane * H + y) * W + q * 4;
+        for (int j = 0; j < 4 && q * 4 + j < W; ++j) acc[j] += ad[j];
+    }
     if ((W & 3) == 0) {
         *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     } else {
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_v4_kernel(const float *__r
 // Backward: thread = input rows 2r, 2r+1, columns 8q .. 8q+7; it needs gradient rows r, r+1 at columns 4q .. 4q+4.
 __global__ __launch_bounds__(256) void maxpool3s2_bwd_code_v8_kernel(const float *__restrict__ g,
                                                                      const unsigned char *__restrict__ code,
-                                                                     float *__restrict__ dx, int H, int W, unsigned total) {
+                                                                     float *dx, const float *addend, int H, int W,
+                                                                     unsigned total) {
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int OH = H >> 1, OW = W >> 1, wq = W >> 3;
@@ -230,6 +235,13 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_code_v8_kernel(const float
         bot[i] = s;
     }
     float *dst = dx + (plane * H + 2 * r) * W + 8 * q;
+    if (addend) {
+        const float *ad = addend + (plane * H + 2 * r) * W + 8 * q;
+        const float4 a0 = *reinterpret_cast<const float4 *>(ad), a1 = *reinterpret_cast<const float4 *>(ad + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(ad + W), b1 = *reinterpret_cast<const float4 *>(ad + W + 4);
+        top[0] += a0.x; top[1] += a0.y; top[2] += a0.z; top[3] += a0.w; top[4] += a1.x; top[5] += a1.y; top[6] += a1.z; top[7] += a1.w;
+        bot[0] += b0.x; bot[1] += b0.y; bot[2] += b0.z; bot[3] += b0.w; bot[4] += b1.x; bot[5] += b1.y; bot[6] += b1.z; bot[7] += b1.w;
+    }
     *reinterpret_cast<float4 *>(dst) = make_float4(top[0], top[1], top[2], top[3]);
     *reinterpret_cast<float4 *>(dst + 4) = make_float4(top[4], top[5], top[6], top[7]);
     *reinterpret_cast<float4 *>(dst + W) = make_float4(bot[0], bot[1], bot[2], bot[3]);
@@ -274,15 +286,16 @@ extern "C" int mmu_maxpool3s2_bwd_codes(const mmu_maxpool_params *p, void *strea
     MMU_CHECK(((uintptr_t)p->dinput & 15) == 0, "maxpool3s2_bwd_codes: dinput must be 16-byte aligned");
     const long total = (long)p->planes * p->height * ((p->width + 3) / 4);
     MMU_CHECK(total < (1L << 32), "maxpool3s2_bwd_codes: tensor too large");
-    if (maxpool_vector_ok(p) && ((uintptr_t)p->dout & 15) == 0 && ((uintptr_t)p->codes & 3) == 0) {
+    if (maxpool_vector_ok(p) && ((uintptr_t)p->dout & 15) == 0 && ((uintptr_t)p->codes & 3) == 0 &&
+        ((uintptr_t)p->dinput_addend & 15) == 0) {
         const unsigned n = (unsigned)((long)p->planes * (p->height / 2) * (p->width / 8));
-        maxpool3s2_bwd_code_v8_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(p->dout, p->codes, p->dinput,
-                                                                                        p->height, p->width, n);
+        maxpool3s2_bwd_code_v8_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+            p->dout, p->codes, p->dinput, p->dinput_addend, p->height, p->width, n);
         MMU_HIP_LAUNCH_CHECK("maxpool3s2_bwd_codes");
         return 0;
     }
     maxpool3s2_bwd_code_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        p->dout, p->codes, p->dinput, p->height, p->width, p->out_height, p->out_width, (unsigned)total);
+        p->dout, p->codes, p->dinput, p->dinput_addend, p->height, p->width, p->out_height, p->out_width, (unsigned)total);
     MMU_HIP_LAUNCH_CHECK("maxpool3s2_bwd_codes");
     return 0;
 }

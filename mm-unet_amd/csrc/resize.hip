@@ -16,11 +16,13 @@ namespace {
 
 struct ResizeArgs {
     int planes, H, W, OH, OW;
-    float ry, rx;  // (H-1)/(OH-1), (W-1)/(OW-1)
+    float ry, rx;    // (H-1)/(OH-1), (W-1)/(OW-1)
+    float iry, irx;  // their reciprocals (0 where the ratio is 0)
     const void *in;     // io_t (float or bf16_t), all four
     void *out;
     const void *dout;
     void *din;
+    const void *addend;   // bwd: added to the gathered gradient (may be din itself)
 };
 
 __device__ __forceinline__ void tap(int o, float r, int n, int &i0, int &i1, float &w) {
@@ -70,16 +72,16 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs p) {
 
 // outputs o with floor(r*o) in {i-1, i} contribute to input i: the range [lo, hi] of such o (r > 0), or all
 // o when r == 0 (single input row/col; only i == 0 exists then)
-__device__ __forceinline__ void src_range(int i, float r, int n_out, int &lo, int &hi) {
+__device__ __forceinline__ void src_range(int i, float r, float inv_r, int n_out, int &lo, int &hi) {
     if (r <= 0.f) {
         lo = 0;
         hi = n_out - 1;
         return;
     }
-    // o with i-1 <= r*o < i+1, widened by one on each side against rounding; the caller verifies each
-    // candidate through its taps
-    lo = (int)ceilf((float)(i - 1) / r) - 1;
-    hi = (int)ceilf((float)(i + 1) / r);
+    // o with i-1 <= r*o < i+1, widened by one on each side against rounding (and the reciprocal's); the caller verifies
+    // each candidate through its taps
+    lo = (int)ceilf((float)(i - 1) * inv_r) - 1;
+    hi = (int)ceilf((float)(i + 1) * inv_r);
     lo = lo < 0 ? 0 : lo;
     hi = hi > n_out - 1 ? n_out - 1 : hi;
 }
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
     const int y = (int)(r % p.H);
     const long plane = r / p.H;
     int ylo, yhi, xlo, xhi;
-    src_range(y, p.ry, p.OH, ylo, yhi);
-    src_range(x, p.rx, p.OW, xlo, xhi);
+    src_range(y, p.ry, p.iry, p.OH, ylo, yhi);
+    src_range(x, p.rx, p.irx, p.OW, xlo, xhi);
     // separable: the x weights do not depend on oy -- keep up to 8 of them in registers (x2 upsampling has 6)
     constexpr int XC = 8;
     const int nx = xhi - xlo + 1;
@@ -137,77 +139,120 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
         }
         acc = fmaf(cy, row, acc);
     }
+    if (p.addend) acc += to_f32(static_cast<const io_t *>(p.addend)[idx]);
     static_cast<io_t *>(p.din)[idx] = from_f32<io_t>(acc);
 }
 
-// The same gather through LDS, for the up-sampling ratios the model uses (<= ~2.3 per axis).  A thread of the kernel
-// above reads every candidate output itself: 4-6 rows x 8 columns of scalar loads per input pixel, 32+ load instructions
-// for 16 bytes of unique data -- the x2 up-sampling to 512 x 512 of 64 channels took 245 us for 671 MB (bound by
-// load issue, not HBM).  Here a workgroup owns 64 x 8 input pixels of a plane, loads the outputs their footprints
-// cover once (coalesced along x, ~1.4x the unique data) and gathers from LDS.
-constexpr int RT_TX = 64, RT_TY = 8, RT_MAXR = 26, RT_MAXC = 152;
+// The same gather through LDS, for the ratios the model uses (x2 up-sampling; the 256 x 256 edge map down to 128 / 64 /
+// 32).  A thread of the kernel above reads every candidate output itself: 4-6 rows x 8 columns of scalar loads per input
+// pixel -- the x2 up-sampling to 512 x 512 of 64 channels took 245 us for 671 MB (bound by load issue, not HBM).  Here a
+// workgroup owns 64 x TY input pixels of a plane, loads the outputs their footprints cover once (coalesced along x) and
+// gathers from LDS.  Round 3: the interpolation is separable, so the workgroup first writes, per input column and per
+// input row of its tile, the list of outputs with a NON-ZERO coefficient (tile-relative index + coefficient, at most NZ
+// of them: 2 when down-sampling, 5 for x2); a pixel is then NZ_y x NZ_x LDS reads and FMAs.  Before, every thread
+// derived its 4-8 column and 2 x 4-8 row candidates itself (divisions, float->int conversions, ~150 instructions per
+// pixel: 170 us for the 134 MB gradient of the edge map, 8x its write time).
+constexpr int RT_TX = 64, RT_MAXR = 26, RT_MAXC = 152;
 
-// XC: candidate outputs per input pixel and axis (8 covers x2 up-sampling, 4 every down-sampling ratio >= 2)
-template <typename io_t, int XC>
+template <typename io_t, int NZ, int TY>
 __global__ __launch_bounds__(256) void resize_bwd_tiled_kernel(ResizeArgs p) {
     __shared__ float tile[RT_MAXR][RT_MAXC + 1];
-    const int x0 = blockIdx.x * RT_TX, y0 = blockIdx.y * RT_TY;
+    __shared__ float xco[RT_TX][NZ], yco[TY][NZ];
+    __shared__ int xix[RT_TX][NZ], yix[TY][NZ], ycnt[TY];
+    const int x0 = blockIdx.x * RT_TX, y0 = blockIdx.y * TY;
     const long plane = blockIdx.z;
-    const int xl = min(x0 + RT_TX, p.W) - 1, yl = min(y0 + RT_TY, p.H) - 1;     // last input pixel of the tile
+    const int xl = min(x0 + RT_TX, p.W) - 1, yl = min(y0 + TY, p.H) - 1;       // last input pixel of the tile
     int txlo, txhi, tylo, tyhi, t0, t1;
-    src_range(x0, p.rx, p.OW, txlo, t0);
-    src_range(xl, p.rx, p.OW, t1, txhi);
-    src_range(y0, p.ry, p.OH, tylo, t0);
-    src_range(yl, p.ry, p.OH, t1, tyhi);
+    src_range(x0, p.rx, p.irx, p.OW, txlo, t0);
+    src_range(xl, p.rx, p.irx, p.OW, t1, txhi);
+    src_range(y0, p.ry, p.iry, p.OH, tylo, t0);
+    src_range(yl, p.ry, p.iry, p.OH, t1, tyhi);
     const int cols = txhi - txlo + 1, rows = tyhi - tylo + 1;                     // host: <= RT_MAXC, RT_MAXR
     const io_t *g = static_cast<const io_t *>(p.dout) + (plane * p.OH + tylo) * p.OW + txlo;
     for (int e = threadIdx.x; e < rows * cols; e += 256) {
         const int r = e / cols, c = e - r * cols;
         tile[r][c] = to_f32(g[(long)r * p.OW + c]);
     }
-    __syncthreads();
-    const int x = x0 + (threadIdx.x & 63);
-    if (x >= p.W) return;
-    int xlo, xhi;
-    src_range(x, p.rx, p.OW, xlo, xhi);            // host: at most XC candidates
-    float cxs[XC];
-#pragma unroll
-    for (int j = 0; j < XC; ++j) {
-        int a0, a1;
-        float wx;
-        const int ox = xlo + j <= xhi ? xlo + j : xhi;
-        tap(ox, p.rx, p.W, a0, a1, wx);
-        const float cx = (a0 == x ? 1.f - wx : 0.f) + (a1 == x ? wx : 0.f);
-        cxs[j] = xlo + j <= xhi ? cx : 0.f;
+    if (threadIdx.x < RT_TX + TY) {                  // wave 0: the columns' lists; the first TY threads of wave 1: the rows'
+        const bool isx = threadIdx.x < RT_TX;
+        const int t = isx ? threadIdx.x : threadIdx.x - RT_TX;
+        const int i = (isx ? x0 : y0) + t;
+        const int n_in = isx ? p.W : p.H, n_out = isx ? p.OW : p.OH, origin = isx ? txlo : tylo;
+        const float r = isx ? p.rx : p.ry, ir = isx ? p.irx : p.iry;
+        float *co = isx ? xco[t] : yco[t];
+        int *ix = isx ? xix[t] : yix[t];
+        int n = 0;
+        if (i < n_in) {
+            int lo, hi;
+            src_range(i, r, ir, n_out, lo, hi);
+            for (int o = lo; o <= hi; ++o) {
+                int a0, a1;
+                float w;
+                tap(o, r, n_in, a0, a1, w);
+                const float c = (a0 == i ? 1.f - w : 0.f) + (a1 == i ? w : 0.f);
+                if (c != 0.f && n < NZ) {            // (host: NZ bounds the outputs that can reach one input)
+                    co[n] = c;
+                    ix[n] = o - origin;
+                    ++n;
+                }
+            }
+        }
+        if (!isx) ycnt[t] = n;
+        for (; n < NZ; ++n) {
+            co[n] = 0.f;
+            ix[n] = 0;
+        }
     }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, x = x0 + tx;
+    if (x >= p.W) return;
+    float cx[NZ];
+    int jx[NZ];
 #pragma unroll
-    for (int k = 0; k < RT_TY / 4; ++k) {
-        const int y = y0 + (threadIdx.x >> 6) + 4 * k;
+    for (int j = 0; j < NZ; ++j) {
+        cx[j] = xco[tx][j];
+        jx[j] = xix[tx][j];
+    }
+    const io_t *add = static_cast<const io_t *>(p.addend);
+#pragma unroll
+    for (int k = 0; k < TY / 4; ++k) {
+        const int ty = (threadIdx.x >> 6) + 4 * k, y = y0 + ty;
         if (y >= p.H) continue;
-        int ylo, yhi;
-        src_range(y, p.ry, p.OH, ylo, yhi);
+        const int ny = ycnt[ty];                     // (the same row for the whole wave: a uniform loop)
         float acc = 0.f;
-        for (int oy = ylo; oy <= yhi; ++oy) {
-            int b0, b1;
-            float wy;
-            tap(oy, p.ry, p.H, b0, b1, wy);
-            const float cy = (b0 == y ? 1.f - wy : 0.f) + (b1 == y ? wy : 0.f);
-            const float *row = &tile[oy - tylo][xlo - txlo];
+        for (int j = 0; j < ny; ++j) {
+            const float *row = tile[yix[ty][j]];
             float rs = 0.f;
 #pragma unroll
-            for (int j = 0; j < XC; ++j) rs = fmaf(cxs[j], row[xlo + j <= xhi ? j : xhi - xlo], rs);
-            acc = fmaf(cy, rs, acc);
+            for (int i = 0; i < NZ; ++i) rs = fmaf(cx[i], row[jx[i]], rs);
+            acc = fmaf(yco[ty][j], rs, acc);
         }
-        static_cast<io_t *>(p.din)[(plane * p.H + y) * p.W + x] = from_f32<io_t>(acc);
+        const long o = (plane * p.H + y) * p.W + x;
+        if (add) acc += to_f32(add[o]);
+        static_cast<io_t *>(p.din)[o] = from_f32<io_t>(acc);
     }
 }
 
-// footprints of a 64 x 8 tile and of one pixel, worst case over the positions (src_range widens by one on each side)
-inline int resize_bwd_candidates(const ResizeArgs &a) { return (int)ceilf(2.f / a.rx) + 3; }
-inline bool resize_bwd_tiled_ok(const ResizeArgs &a) {
+// how many outputs can reach one input pixel along an axis: the multiples of r inside a half-open interval of length 2
+inline int resize_bwd_reach(float r) { return (int)floorf(2.f / r + 1e-3f) + 1; }
+inline bool resize_bwd_tiled_ok(const ResizeArgs &a, int ty) {
     if (a.rx <= 0.f || a.ry <= 0.f || a.planes > 65535) return false;
-    const int cols = (int)ceilf((RT_TX + 1) / a.rx) + 3, rows = (int)ceilf((RT_TY + 1) / a.ry) + 3;
-    return cols <= RT_MAXC && rows <= RT_MAXR && resize_bwd_candidates(a) <= 8;
+    const int cols = (int)ceilf((RT_TX + 1) / a.rx) + 3, rows = (int)ceilf((ty + 1) / a.ry) + 3;
+    return cols <= RT_MAXC && rows <= RT_MAXR;
+}
+
+template <typename io_t>
+bool resize_bwd_tiled_launch(const ResizeArgs &a, hipStream_t st) {
+    if (a.rx <= 0.f || a.ry <= 0.f) return false;
+    const int reach = max(resize_bwd_reach(a.rx), resize_bwd_reach(a.ry));
+    const int ty = reach <= 2 && resize_bwd_tiled_ok(a, 32) ? 32 : 8;
+    if (!resize_bwd_tiled_ok(a, ty) || reach > 8) return false;
+    dim3 grid((a.W + RT_TX - 1) / RT_TX, (a.H + ty - 1) / ty, a.planes);
+    if (reach <= 2 && ty == 32) resize_bwd_tiled_kernel<io_t, 2, 32><<<grid, 256, 0, st>>>(a);
+    else if (reach <= 2) resize_bwd_tiled_kernel<io_t, 2, 8><<<grid, 256, 0, st>>>(a);
+    else if (reach <= 5) resize_bwd_tiled_kernel<io_t, 5, 8><<<grid, 256, 0, st>>>(a);
+    else resize_bwd_tiled_kernel<io_t, 8, 8><<<grid, 256, 0, st>>>(a);
+    return true;
 }
 
 int fill(const mmu_resize_params *p, ResizeArgs &a, const char *name) {
@@ -217,6 +262,8 @@ int fill(const mmu_resize_params *p, ResizeArgs &a, const char *name) {
     MMU_CHECK(p->dtype == MMU_DTYPE_F32 || p->dtype == MMU_DTYPE_BF16, "%s: unsupported dtype %d", name, p->dtype);
     a.ry = a.OH > 1 ? (float)(a.H - 1) / (float)(a.OH - 1) : 0.f;
     a.rx = a.OW > 1 ? (float)(a.W - 1) / (float)(a.OW - 1) : 0.f;
+    a.iry = a.ry > 0.f ? 1.f / a.ry : 0.f;
+    a.irx = a.rx > 0.f ? 1.f / a.rx : 0.f;
     return 0;
 }
 
@@ -242,21 +289,15 @@ extern "C" int mmu_bilinear_resize_bwd(const mmu_resize_params *p, void *stream)
     MMU_CHECK(p->dout && p->dinput, "bilinear_resize_bwd: dout and dinput are required");
     a.dout = p->dout; a.din = p->dinput;
     const long total = (long)a.planes * a.H * a.W;
+    a.addend = p->dinput_addend;
     static const bool tiled_on = []() { const char *e = getenv("MMU_RESIZE_BWD_TILED"); return !e || e[0] != '0'; }();
-    if (tiled_on && resize_bwd_tiled_ok(a)) {
-        dim3 grid((a.W + RT_TX - 1) / RT_TX, (a.H + RT_TY - 1) / RT_TY, a.planes);
-        const bool few = resize_bwd_candidates(a) <= 4;
-        if (p->dtype == MMU_DTYPE_BF16) {
-            if (few) resize_bwd_tiled_kernel<bf16_t, 4><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-            else resize_bwd_tiled_kernel<bf16_t, 8><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-        } else {
-            if (few) resize_bwd_tiled_kernel<float, 4><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-            else resize_bwd_tiled_kernel<float, 8><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-        }
-    } else if (p->dtype == MMU_DTYPE_BF16)
-        resize_bwd_kernel<bf16_t><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
-    else
-        resize_bwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+    hipStream_t st = (hipStream_t)stream;
+    bool done = false;
+    if (tiled_on) done = p->dtype == MMU_DTYPE_BF16 ? resize_bwd_tiled_launch<bf16_t>(a, st) : resize_bwd_tiled_launch<float>(a, st);
+    if (!done) {
+        if (p->dtype == MMU_DTYPE_BF16) resize_bwd_kernel<bf16_t><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+        else resize_bwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+    }
     MMU_HIP_LAUNCH_CHECK("bilinear_resize_bwd");
     return 0;
 }

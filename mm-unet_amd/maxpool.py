@@ -19,7 +19,7 @@ def module_supported(m, x):
 
 class MaxPool3s2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot=None):
         _lib.require_gpu(x)
         if x.dim() != 4 or x.dtype != torch.float32:
             raise RuntimeError("max_pool3s2: float32 (B, C, H, W) tensor required")
@@ -35,6 +35,10 @@ class MaxPool3s2Fn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_maxpool3s2_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(codes)
         ctx.in_shape = x.shape
+        # slot: a conv3x3_small.SharedGrad of all consumers of x -- their input gradients leave as one
+        ctx.slot = slot if (slot is not None and ctx.needs_input_grad[0]) else None
+        if ctx.slot is not None:
+            ctx.slot.join()
         return out
 
     @staticmethod
@@ -42,19 +46,23 @@ class MaxPool3s2Fn(torch.autograd.Function):
         codes, = ctx.saved_tensors
         B, C, H, W = ctx.in_shape
         g = g.float().contiguous()
-        dx = torch.empty(ctx.in_shape, device=g.device, dtype=torch.float32)
+        parked = ctx.slot.take() if ctx.slot is not None else None
+        if parked is not None and (parked.shape != ctx.in_shape or parked.dtype != torch.float32 or not parked.is_contiguous()):
+            raise RuntimeError("max_pool3s2: parked input gradient does not match the input")
+        dx = parked if parked is not None else torch.empty(ctx.in_shape, device=g.device, dtype=torch.float32)   # (in place)
         p = _lib.MaxPoolParams()
         p.planes, p.height, p.width, p.out_height, p.out_width = B * C, H, W, g.shape[2], g.shape[3]
-        p.dout, p.codes, p.dinput = g.data_ptr(), codes.data_ptr(), dx.data_ptr()
+        p.dout, p.codes, p.dinput, p.dinput_addend = g.data_ptr(), codes.data_ptr(), dx.data_ptr(), _lib.ptr(parked)
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().mmu_maxpool3s2_bwd_codes(p, _lib.stream_of(g)))
-        return dx
+        return (ctx.slot.give(dx) if ctx.slot is not None else dx), None
 
 
-def max_pool3s2(x):
-    return MaxPool3s2Fn.apply(x)
+def max_pool3s2(x, slot=None):
+    return MaxPool3s2Fn.apply(x, slot)
 
 
-def pool_module(m, x):
-    """``m(x)`` for an ``nn.MaxPool2d``: the gather-backward form when :func:`module_supported`, the module otherwise."""
-    return max_pool3s2(x) if module_supported(m, x) else m(x)
+def pool_module(m, x, slot=None):
+    """``m(x)`` for an ``nn.MaxPool2d``: the gather-backward form when :func:`module_supported`, the module otherwise.
+    ``slot``: a conv3x3_small.SharedGrad shared by all consumers of ``x``."""
+    return max_pool3s2(x, slot) if module_supported(m, x) else m(x)

@@ -309,15 +309,20 @@ class CBAM(nn.Module):
         # [8, 64, 256, 256] stem map (one thread per output element); same value, and like the pooling
         # op the gradient goes to one arg-max element.
         fused = pointwise.stats_supported(x)
+        # hand-overs of the backward pass (no activation-sized gradient adds): x feeds the pooled statistics and the
+        # first product; y1 the spatial statistics and the second product
+        share = fused and pointwise.GATED_MUL and torch.is_grad_enabled() and x.requires_grad
+        xs = conv3x3_small.SharedGrad() if share else None
+        ss = pointwise.ChannelStatsSlot() if share else None
         if fused:    # mean and max (+ arg-max) in one pass each way (csrc/cbam_stats.hip)
-            x_avg, x_max = pointwise.pixel_mean_max(x)
+            x_avg, x_max = pointwise.pixel_mean_max(x, xs)
         else:
             x_avg = self.avg_pool(x)
             x_max = x.flatten(2).max(dim=2)[0].unsqueeze(-1).unsqueeze(-1)
         c_out = self.sigmoid(self.mlp(x_avg) + self.mlp(x_max))
-        y1 = pointwise.gated_mul(x, c_out)
+        y1 = pointwise.gated_mul(x, c_out, xs, ss)
         if fused:
-            s_cat = pointwise.channel_max_mean(y1)
+            s_cat = pointwise.channel_max_mean(y1, ss)
         else:
             s_avg = torch.mean(y1, dim=1, keepdim=True)
             s_max, _ = torch.max(y1, dim=1, keepdim=True)
@@ -351,9 +356,10 @@ class RCG(nn.Module):
         self.mamba.return_branch_outputs = False   # forward() below keeps only the block output (MMUNet.py:409)
         self.mlp = nn.Sequential(nn.Conv2d(64, 1, kernel_size=1), nn.Sigmoid())
 
-    def forward(self, pre, edge, f):
+    def forward(self, pre, edge, f, edge_slot=None):
+        """``edge_slot``: a conv3x3_small.SharedGrad of all consumers of ``edge`` (MM_Net: three RCG blocks + the line head)."""
         r = (1 - torch.sigmoid(pre)) * f
-        edge1 = bilinear_resize(edge, size=f.size()[2:])
+        edge1 = bilinear_resize(edge, size=f.size()[2:], slot=edge_slot)
         x2 = run_fused(self.conv1, torch.cat((edge1, r), 1))
         # tri-directional Mamba at 2x resolution (MMUNet.py:398-412)
         x0 = conv_s2.module_call(self.upsample, x2)      # ConvTranspose2d(64, 64, 4, 2, 1) on the matrix cores
@@ -460,22 +466,27 @@ class MM_Net(nn.Module):
         size = x.size()[2:]
         up = lambda t: bilinear_resize(t, size=size)  # noqa: E731
         e1 = run_fused(self.encoder1, x)
-        e2 = self.encoder2(maxpool_op.pool_module(self.maxpool, e1))
+        # e1 feeds the max-pool and CBAM, the edge map c1 three RCG blocks and the line head: their input gradients are
+        # handed from consumer to consumer (conv3x3_small.SharedGrad) instead of added by autograd
+        share = torch.is_grad_enabled() and e1.requires_grad
+        s1 = conv3x3_small.SharedGrad() if share else None
+        e2 = self.encoder2(maxpool_op.pool_module(self.maxpool, e1, s1))
         e3 = self.encoder3(e2)
         e4 = self.encoder4(e3)
         e5 = self.encoder5(e4)
         e3, e4, e5 = run_fused(self.down3, e3), run_fused(self.down4, e4), run_fused(self.down5, e5)
         d5 = self.decoder5(e5)
         out5 = self.side5(d5)
-        c1 = run_fused(self.cbam, e1)   # contour branch on the stride-2 stem features
-        p_c = _small_conv3x3(self.line_predict, c1)
-        r4 = self.rcg4(out5, c1, e4)
+        c1 = run_fused(self.cbam, conv3x3_small.shared_input(e1, s1))   # contour branch on the stride-2 stem features
+        sc = conv3x3_small.SharedGrad() if share else None
+        p_c = _small_conv3x3(self.line_predict, c1, sc)
+        r4 = self.rcg4(out5, c1, e4, sc)
         d4 = self.decoder4(torch.cat((d5, r4), dim=1))
         out4 = self.side4(d4)
-        r3 = self.rcg3(out4, c1, e3)
+        r3 = self.rcg3(out4, c1, e3, sc)
         d3 = self.decoder3(torch.cat((d4, r3), dim=1))
         out3 = self.side3(d3)
-        r2 = self.rcg2(out3, c1, e2)
+        r2 = self.rcg2(out3, c1, e2, sc)
         d2 = self.decoder2(torch.cat((d3, r2), dim=1))
         out2 = self.side2(d2)
         return up(out2) + up(out3) + up(out4) + up(out5) + up(p_c)

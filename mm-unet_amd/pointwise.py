@@ -151,9 +151,20 @@ def _gate_mode(x, gate):
     return None
 
 
+class ChannelStatsSlot:
+    """Hand-over between ``channel_max_mean(y)`` and the ``gated_mul`` that produced ``y`` (CBAM: y1 = x * c_out feeds the
+    spatial statistics and the second product): the statistics' backward parks its two small operands here and returns
+    no gradient; the product's backward adds the gradient they stand for to its ``dout`` on the fly (csrc/gated_mul.hip)
+    -- the 134 MB statistics gradient of the stem map is neither written nor added."""
+    __slots__ = ("armed", "parked")
+
+    def __init__(self):
+        self.armed, self.parked = False, None
+
+
 class GatedMulFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gate, mode):
+    def forward(ctx, x, gate, mode, x_slot=None, stats_slot=None):
         _lib.require_gpu(x, gate)
         _need_f32_nchw("gated_mul", x)
         if gate.dtype != torch.float32 or mode not in (0, 1) or tuple(gate.shape) != (
@@ -170,6 +181,13 @@ class GatedMulFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_gated_mul_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, gate)
         ctx.mode = mode
+        # x_slot: a conv3x3_small.SharedGrad of the consumers of x; stats_slot: see ChannelStatsSlot
+        ctx.x_slot = x_slot if (x_slot is not None and ctx.needs_input_grad[0]) else None
+        if ctx.x_slot is not None:
+            ctx.x_slot.join()
+        ctx.stats_slot = stats_slot if mode == 0 else None
+        if ctx.stats_slot is not None:
+            ctx.stats_slot.armed = True
         return out
 
     @staticmethod
@@ -178,23 +196,36 @@ class GatedMulFn(torch.autograd.Function):
         B, C, H, W = x.shape
         g = g.float().contiguous()
         need_x, need_g = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        stats = None
+        if ctx.stats_slot is not None and ctx.stats_slot.parked is not None:
+            stats, ctx.stats_slot.parked = ctx.stats_slot.parked, None
         if not (need_x or need_g):
-            return None, None, None
+            return None, None, None, None, None
         dx = torch.empty_like(x) if need_x else None
         dgate = torch.empty_like(gate) if need_g else None
         p = _lib.GatedMulParams()
         p.batch, p.channels, p.mode, p.hw = B, C, ctx.mode, H * W
         p.input, p.gate, p.dout = x.data_ptr(), gate.data_ptr(), g.data_ptr()
         p.dinput, p.dgate = _lib.ptr(dx), _lib.ptr(dgate)
+        if stats is not None:
+            sg, sam = stats
+            if sg.shape != (B, 2, H, W) or sam.shape != (B, H, W) or sg.dtype != torch.float32 or sam.dtype != torch.int32:
+                raise RuntimeError("gated_mul: parked channel statistics do not match the product")
+            p.stats_dout, p.stats_argmax = sg.data_ptr(), sam.data_ptr()
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_gated_mul_bwd(p, _lib.stream_of(x)))
-        return dx, dgate, None
+        if ctx.x_slot is not None:
+            parked = ctx.x_slot.take()
+            dx = ctx.x_slot.give(dx if parked is None else parked.add_(dx))
+        return dx, dgate, None, None, None
 
 
-def gated_mul(x, gate):
-    """``x * gate`` (broadcast); the one-pass HIP form for channel / spatial gates of a float32 NCHW tensor, else ATen."""
+def gated_mul(x, gate, x_slot=None, stats_slot=None):
+    """``x * gate`` (broadcast); the one-pass HIP form for channel / spatial gates of a float32 NCHW tensor, else ATen.
+    ``x_slot``: a conv3x3_small.SharedGrad of the consumers of ``x``; ``stats_slot``: a ChannelStatsSlot shared with the
+    ``channel_max_mean`` of the product."""
     mode = _gate_mode(x, gate)
-    return GatedMulFn.apply(x, gate, mode) if mode is not None else x * gate
+    return GatedMulFn.apply(x, gate, mode, x_slot, stats_slot) if mode is not None else x * gate
 
 
 # ---- CBAM's pooled statistics (MMUNet.py:327-333): mean and max in one pass, one-pass backward ---------------------------
@@ -211,7 +242,7 @@ class _PixelStatsFn(torch.autograd.Function):
     """x (B, C, H, W) -> (mean, max) over the pixels, each (B, C, 1, 1)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, x_slot=None):
         _lib.require_gpu(x)
         _need_f32_nchw("pixel_mean_max", x)
         x = x.contiguous()
@@ -226,6 +257,9 @@ class _PixelStatsFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_cbam_stats_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(am)
         ctx.shape = x.shape
+        ctx.x_slot = x_slot if (x_slot is not None and ctx.needs_input_grad[0]) else None
+        if ctx.x_slot is not None:
+            ctx.x_slot.join()
         return mean, mx
 
     @staticmethod
@@ -233,20 +267,24 @@ class _PixelStatsFn(torch.autograd.Function):
         am, = ctx.saved_tensors
         B, C, H, W = ctx.shape
         gmean, gmax = gmean.float().contiguous(), gmax.float().contiguous()
-        dx = torch.empty(ctx.shape, device=am.device, dtype=torch.float32)
+        parked = ctx.x_slot.take() if ctx.x_slot is not None else None
+        if parked is not None and (parked.shape != ctx.shape or parked.dtype != torch.float32 or not parked.is_contiguous()):
+            raise RuntimeError("pixel_mean_max: parked input gradient does not match the input")
+        dx = parked if parked is not None else torch.empty(ctx.shape, device=am.device, dtype=torch.float32)   # (in place)
         p = _lib.CbamStatsParams()
         p.batch, p.channels, p.mode, p.hw = B, C, 0, H * W
         p.argmax, p.dmean, p.dmax, p.dinput = am.data_ptr(), gmean.data_ptr(), gmax.data_ptr(), dx.data_ptr()
+        p.dinput_addend = _lib.ptr(parked)
         with torch.cuda.device(am.device):
             _lib.check(_lib.lib().mmu_cbam_stats_bwd(p, _lib.stream_of(am)))
-        return dx
+        return (ctx.x_slot.give(dx) if ctx.x_slot is not None else dx), None
 
 
 class _ChannelStatsFn(torch.autograd.Function):
     """x (B, C, H, W) -> (B, 2, H, W): max over the channels, then their mean (the order of MMUNet.py:333)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, stats_slot=None):
         _lib.require_gpu(x)
         _need_f32_nchw("channel_max_mean", x)
         x = x.contiguous()
@@ -260,6 +298,7 @@ class _ChannelStatsFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_cbam_stats_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(am)
         ctx.shape = x.shape
+        ctx.stats_slot = stats_slot if (stats_slot is not None and stats_slot.armed and ctx.needs_input_grad[0]) else None
         return out
 
     @staticmethod
@@ -267,20 +306,25 @@ class _ChannelStatsFn(torch.autograd.Function):
         am, = ctx.saved_tensors
         B, C, H, W = ctx.shape
         g = g.float().contiguous()
+        if ctx.stats_slot is not None:       # the product that made x adds this gradient itself (ChannelStatsSlot)
+            ctx.stats_slot.parked = (g, am)
+            return None, None
         dx = torch.empty(ctx.shape, device=am.device, dtype=torch.float32)
         p = _lib.CbamStatsParams()
         p.batch, p.channels, p.mode, p.hw = B, C, 1, H * W
         p.argmax, p.dout, p.dinput = am.data_ptr(), g.data_ptr(), dx.data_ptr()
         with torch.cuda.device(am.device):
             _lib.check(_lib.lib().mmu_cbam_stats_bwd(p, _lib.stream_of(am)))
-        return dx
+        return dx, None
 
 
-def pixel_mean_max(x):
-    """(avg_pool(x), max_pool(x)) of CBAM's channel attention, each (B, C, 1, 1)."""
-    return _PixelStatsFn.apply(x)
+def pixel_mean_max(x, x_slot=None):
+    """(avg_pool(x), max_pool(x)) of CBAM's channel attention, each (B, C, 1, 1).  ``x_slot``: a conv3x3_small.SharedGrad
+    of the consumers of ``x``."""
+    return _PixelStatsFn.apply(x, x_slot)
 
 
-def channel_max_mean(x):
-    """cat((max over channels, mean over channels), 1) of CBAM's spatial attention, (B, 2, H, W)."""
-    return _ChannelStatsFn.apply(x)
+def channel_max_mean(x, stats_slot=None):
+    """cat((max over channels, mean over channels), 1) of CBAM's spatial attention, (B, 2, H, W).  ``stats_slot``: the
+    ChannelStatsSlot the ``gated_mul`` that produced ``x`` was given."""
+    return _ChannelStatsFn.apply(x, stats_slot)

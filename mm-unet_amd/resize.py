@@ -13,7 +13,7 @@ from . import _lib
 
 class BilinearResizeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, out_h, out_w):
+    def forward(ctx, x, out_h, out_w, slot=None):
         _lib.require_gpu(x)
         if x.dim() != 4:
             raise RuntimeError("bilinear_resize: input must be (B, C, H, W)")
@@ -27,27 +27,37 @@ class BilinearResizeFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_bilinear_resize_fwd(p, _lib.stream_of(xf)))
         ctx.shape, ctx.dtype, ctx.io_dtype = (B, C, H, W), x.dtype, xf.dtype
+        # slot: a conv3x3_small.SharedGrad of all consumers of x -- their input gradients leave as one
+        ctx.slot = slot if (slot is not None and ctx.needs_input_grad[0] and x.dtype == xf.dtype) else None
+        if ctx.slot is not None:
+            ctx.slot.join()
         return out.to(x.dtype)
 
     @staticmethod
     def backward(ctx, dout):
         B, C, H, W = ctx.shape
         g = dout.to(ctx.io_dtype).contiguous()
-        dx = torch.empty((B, C, H, W), device=g.device, dtype=ctx.io_dtype)
+        parked = ctx.slot.take() if ctx.slot is not None else None
+        if parked is not None and (parked.shape != (B, C, H, W) or parked.dtype != ctx.io_dtype or not parked.is_contiguous()):
+            raise RuntimeError("bilinear_resize: parked input gradient does not match the input")
+        dx = parked if parked is not None else torch.empty((B, C, H, W), device=g.device, dtype=ctx.io_dtype)   # (in place)
         p = _lib.ResizeParams()
         p.planes, p.in_h, p.in_w, p.out_h, p.out_w = B * C, H, W, g.shape[2], g.shape[3]
-        p.dout, p.dinput = g.data_ptr(), dx.data_ptr()
+        p.dout, p.dinput, p.dinput_addend = g.data_ptr(), dx.data_ptr(), _lib.ptr(parked)
         p.dtype = _lib.dtype_code(g)
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().mmu_bilinear_resize_bwd(p, _lib.stream_of(g)))
-        return dx.to(ctx.dtype), None, None
+        if ctx.slot is not None:
+            return ctx.slot.give(dx), None, None, None
+        return dx.to(ctx.dtype), None, None, None
 
 
 ENABLED = True   # False: F.interpolate itself (fused_paths.plain_aten)
 
 
-def bilinear_resize(x, size=None, scale_factor=None):
-    """``F.interpolate(x, size=size | scale_factor=..., mode="bilinear", align_corners=True)``."""
+def bilinear_resize(x, size=None, scale_factor=None, slot=None):
+    """``F.interpolate(x, size=size | scale_factor=..., mode="bilinear", align_corners=True)``.  ``slot``: a
+    conv3x3_small.SharedGrad shared by all consumers of ``x``."""
     if (size is None) == (scale_factor is None):
         raise ValueError("bilinear_resize: give exactly one of size / scale_factor")
     if not ENABLED:
@@ -55,4 +65,4 @@ def bilinear_resize(x, size=None, scale_factor=None):
         return F.interpolate(x, size=size, scale_factor=scale_factor, mode="bilinear", align_corners=True)
     if size is None:
         size = (int(x.shape[2] * scale_factor), int(x.shape[3] * scale_factor))
-    return BilinearResizeFn.apply(x, int(size[0]), int(size[1]))
+    return BilinearResizeFn.apply(x, int(size[0]), int(size[1]), slot)

@@ -1322,6 +1322,52 @@ def test_max_pool3s2_vs_module(shape):
     assert torch.equal(torch.nan_to_num(maxpool.pool_module(m, xn), nan=12345.0), torch.nan_to_num(m(xn), nan=12345.0))
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 32, 32), (1, 3, 18, 20), (8, 64, 256, 256)])
+def test_shared_input_gradient_hand_over_equals_autograd_sum(shape):
+    """conv3x3_small.SharedGrad: the consumers of one tensor (MM_Net: the edge map -> three resizes + the line head; the
+    stem features -> max-pool + CBAM) hand their input gradients from one backward kernel to the next instead of leaving
+    autograd to add them.  Same total as the plain route, whichever order autograd runs the consumers in."""
+    from mm_unet_amd import conv3x3_small, maxpool, pointwise
+    from mm_unet_amd.resize import bilinear_resize
+    B, C, H, W = shape
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    x = torch.randn(*shape, device=DEV, generator=gen)
+    w = 0.2 * torch.randn(1, C, 3, 3, device=DEV, generator=gen)
+    gate = torch.rand(B, C, 1, 1, device=DEV, generator=gen)
+
+    def run(shared, order):
+        xi = x.clone().requires_grad_()
+        slot = conv3x3_small.SharedGrad() if shared else None
+        heads = {
+            "r2": lambda: bilinear_resize(xi, size=(H // 2, W // 2), slot=slot),
+            "r4": lambda: bilinear_resize(xi, size=(max(H // 4, 1), max(W // 4, 1)), slot=slot),
+            "up": lambda: bilinear_resize(xi, size=(H + 3, W + 5), slot=slot),
+            "conv": lambda: conv3x3_small.conv3x3_small(xi, w, None, slot),
+            "pool": lambda: maxpool.max_pool3s2(xi, slot),
+            "join": lambda: conv3x3_small.shared_input(xi, slot) * 0.5,
+            "stats": lambda: sum(pointwise.pixel_mean_max(xi, slot)),
+            "gate": lambda: pointwise.gated_mul(xi, gate, slot),
+        }
+        gg = torch.Generator(device=DEV).manual_seed(5)
+        total = 0
+        outs = {k: heads[k]() for k in order}
+        for k in sorted(outs):                       # the same cotangent per head whatever the order
+            o = outs[k]
+            total = total + (o * torch.randn(o.shape, device=DEV, generator=gg)).sum()
+        total.backward()
+        if shared:
+            assert slot.pending == 0 and slot.grad is None
+        return xi.grad
+
+    names = ["r2", "r4", "up", "conv", "pool", "join", "stats", "gate"]
+    ref = run(False, names)
+    scale = float(ref.abs().max())
+    for order in (names, names[::-1], ["pool", "join"], ["conv", "r2", "r4", "up"]):
+        want = ref if len(order) == len(names) else run(False, order)
+        got = run(True, order)
+        close(got, want, 1e-5, 1e-5 * scale, f"shared gradient, order {order}")
+
+
 @pytest.mark.parametrize("shape", [(8, 256, 256), (2, 13, 9), (1, 5, 40), (3, 64, 64)])
 def test_conv7x7_2to1_vs_conv2d(shape):
     """csrc/conv7x7_small.hip == nn.Conv2d(2, 1, 7, padding=3, bias=False) (CBAM's spatial attention, MMUNet.py:323,335):
