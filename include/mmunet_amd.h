@@ -502,6 +502,26 @@ typedef struct {
                                   * same input; may be dinput itself) */
 } mmu_cbam_stats_params;
 
+/* CBAM's channel gate from the pooled vectors: gate = sigmoid(mlp(avg) + mlp(max)), mlp = Conv2d(C, R, 1, bias=False) ->
+ * ReLU -> Conv2d(R, C, 1, bias=False) (src/UM_Net/MMUNet.py:319-329), one launch each way.  float32, contiguous;
+ * batch * (channels + 4 * hidden) floats must fit 48 KB. */
+typedef struct {
+    int32_t batch, channels, hidden;
+    const float *avg;      /* [batch, channels] */
+    const float *max;      /* [batch, channels] */
+    const float *w1;       /* [hidden, channels] */
+    const float *w2;       /* [channels, hidden] */
+    float *gate;           /* [batch, channels]: fwd written, bwd read */
+    const float *dgate;    /* bwd */
+    float *davg;           /* bwd, optional */
+    float *dmax;           /* bwd, optional */
+    float *dw1;            /* bwd, optional */
+    float *dw2;            /* bwd, optional */
+} mmu_cbam_gate_params;
+
+int mmu_cbam_gate_fwd(const mmu_cbam_gate_params *p, void *stream);
+int mmu_cbam_gate_bwd(const mmu_cbam_gate_params *p, void *stream);
+
 int mmu_cbam_stats_fwd(const mmu_cbam_stats_params *p, void *stream);
 int mmu_cbam_stats_bwd(const mmu_cbam_stats_params *p, void *stream);
 

@@ -119,6 +119,93 @@ __global__ __launch_bounds__(256) void cs_chan_bwd_kernel(const float *__restric
     }
 }
 
+// ---- channel attention's shared MLP on the pooled vectors: gate = sigmoid(mlp(avg) + mlp(max)) ------------------------
+// mlp = Conv2d(C, R, 1, bias=False) -> ReLU -> Conv2d(R, C, 1, bias=False) on [B, C, 1, 1] (MMUNet.py:319-329): 64 -> 4 ->
+// 64 on 8 vectors.  As modules that is 8 launches forward and 15 backward (MIOpen's naive 1x1 kernels, two adds for the
+// weights used twice), each at the launch floor; here one workgroup does either direction.
+__device__ __forceinline__ void gate_hidden(const mmu_cbam_gate_params &p, float *h /* [2][B][R] */) {
+    const int B = p.batch, C = p.channels, R = p.hidden;
+    for (int e = threadIdx.x; e < 2 * B * R; e += blockDim.x) {
+        const int sidx = e / (B * R), b = (e / R) % B, r = e % R;
+        const float *v = (sidx ? p.max : p.avg) + (long)b * C, *w = p.w1 + (long)r * C;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(w[c], v[c], a);
+        h[e] = fmaxf(a, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void cbam_gate_fwd_kernel(mmu_cbam_gate_params p) {
+    extern __shared__ float gsm[];
+    const int B = p.batch, C = p.channels, R = p.hidden;
+    float *h = gsm;
+    gate_hidden(p, h);
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * C; e += blockDim.x) {
+        const int b = e / C, c = e % C;
+        const float *w = p.w2 + (long)c * R, *ha = h + b * R, *hm = h + (B + b) * R;
+        float oa = 0.f, om = 0.f;
+        for (int r = 0; r < R; ++r) {
+            oa = fmaf(w[r], ha[r], oa);
+            om = fmaf(w[r], hm[r], om);
+        }
+        p.gate[e] = 1.f / (1.f + __expf(-(oa + om)));
+    }
+}
+
+__global__ __launch_bounds__(256) void cbam_gate_bwd_kernel(mmu_cbam_gate_params p) {
+    extern __shared__ float gsm[];
+    const int B = p.batch, C = p.channels, R = p.hidden;
+    float *h = gsm, *dh = h + 2 * B * R, *dz = dh + 2 * B * R;     // [2][B][R] | [2][B][R] | [B][C]
+    gate_hidden(p, h);
+    for (int e = threadIdx.x; e < B * C; e += blockDim.x) {
+        const float g = p.gate[e];
+        dz[e] = p.dgate[e] * g * (1.f - g);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * B * R; e += blockDim.x) {
+        const int b = (e / R) % B, r = e % R;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(p.w2[(long)c * R + r], dz[b * C + c], a);
+        dh[e] = h[e] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * C; e += blockDim.x) {        // d avg, d max
+        const int b = e / C, c = e % C;
+        float da = 0.f, dm = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float w = p.w1[(long)r * C + c];
+            da = fmaf(w, dh[b * R + r], da);
+            dm = fmaf(w, dh[(B + b) * R + r], dm);
+        }
+        if (p.davg) p.davg[e] = da;
+        if (p.dmax) p.dmax[e] = dm;
+    }
+    for (int e = threadIdx.x; e < C * R; e += blockDim.x) {        // d w2 [C][R], d w1 [R][C]
+        if (p.dw2) {
+            const int c = e / R, r = e % R;
+            float a = 0.f;
+            for (int b = 0; b < B; ++b) a = fmaf(dz[b * C + c], h[b * R + r] + h[(B + b) * R + r], a);
+            p.dw2[e] = a;
+        }
+        if (p.dw1) {
+            const int r = e / C, c = e % C;
+            float a = 0.f;
+            for (int b = 0; b < B; ++b)
+                a += dh[b * R + r] * p.avg[(long)b * C + c] + dh[(B + b) * R + r] * p.max[(long)b * C + c];
+            p.dw1[e] = a;
+        }
+    }
+}
+
+int gate_check(const mmu_cbam_gate_params *p, const char *name, size_t &lds) {
+    MMU_CHECK(p != nullptr, "%s: null params", name);
+    MMU_CHECK(p->batch > 0 && p->channels > 0 && p->hidden > 0, "%s: empty problem", name);
+    MMU_CHECK(p->avg && p->max && p->w1 && p->w2 && p->gate, "%s: avg, max, w1, w2, gate are required", name);
+    lds = ((size_t)4 * p->batch * p->hidden + (size_t)p->batch * p->channels) * sizeof(float);
+    MMU_CHECK(lds <= 48 * 1024, "%s: batch * (channels + 4 * hidden) floats must fit 48 KB of LDS", name);
+    return 0;
+}
+
 int check(const mmu_cbam_stats_params *p, const char *name) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
     MMU_CHECK(p->batch > 0 && p->batch < 65536 && p->channels > 0 && p->hw > 0 && p->hw % 4 == 0 && p->hw < (1L << 31),
@@ -167,5 +254,22 @@ extern "C" int mmu_cbam_stats_bwd(const mmu_cbam_stats_params *p, void *stream) 
                                                                                          p->dinput_addend, p->channels, HW4);
     }
     MMU_HIP_LAUNCH_CHECK("cbam_stats_bwd");
+    return 0;
+}
+
+extern "C" int mmu_cbam_gate_fwd(const mmu_cbam_gate_params *p, void *stream) {
+    size_t lds = 0;
+    if (int r = gate_check(p, "cbam_gate_fwd", lds)) return r;
+    cbam_gate_fwd_kernel<<<1, 256, lds, (hipStream_t)stream>>>(*p);
+    MMU_HIP_LAUNCH_CHECK("cbam_gate_fwd");
+    return 0;
+}
+
+extern "C" int mmu_cbam_gate_bwd(const mmu_cbam_gate_params *p, void *stream) {
+    size_t lds = 0;
+    if (int r = gate_check(p, "cbam_gate_bwd", lds)) return r;
+    MMU_CHECK(p->dgate, "cbam_gate_bwd: dgate is required");
+    cbam_gate_bwd_kernel<<<1, 256, lds, (hipStream_t)stream>>>(*p);
+    MMU_HIP_LAUNCH_CHECK("cbam_gate_bwd");
     return 0;
 }

@@ -143,6 +143,42 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
     static_cast<io_t *>(p.din)[idx] = from_f32<io_t>(acc);
 }
 
+// Large up-sampling ratios on few pixels (the side outputs: 1 channel, 16 x 16 ... 128 x 128 -> 512 x 512): an input pixel
+// gathers from (2 x ratio)^2 outputs -- 4,096 at x32 -- and there are only a few thousand pixels, so one THREAD per pixel
+// (the kernel above) is a handful of waves in long loops: 51 us for 8 MB of gradient.  Here a WAVE owns the pixel, its
+// lanes stride over the candidate rectangle (contiguous along x) and the sum is a wave reduction in a fixed order.
+template <typename io_t>
+__global__ __launch_bounds__(256) void resize_bwd_wave_kernel(ResizeArgs p) {
+    const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= (long)p.planes * p.H * p.W) return;
+    const int x = (int)(idx % p.W);
+    const long r = idx / p.W;
+    const int y = (int)(r % p.H);
+    const long plane = r / p.H;
+    int ylo, yhi, xlo, xhi;
+    src_range(y, p.ry, p.iry, p.OH, ylo, yhi);
+    src_range(x, p.rx, p.irx, p.OW, xlo, xhi);
+    const int nx = xhi - xlo + 1, total = (yhi - ylo + 1) * nx;
+    const io_t *g = static_cast<const io_t *>(p.dout) + plane * p.OH * p.OW;
+    float acc = 0.f;
+    for (int e = lane; e < total; e += 64) {
+        const int ey = e / nx, oy = ylo + ey, ox = xlo + (e - ey * nx);
+        int a0, a1, b0, b1;
+        float wx, wy;
+        tap(oy, p.ry, p.H, b0, b1, wy);
+        tap(ox, p.rx, p.W, a0, a1, wx);
+        const float cy = (b0 == y ? 1.f - wy : 0.f) + (b1 == y ? wy : 0.f);
+        const float cx = (a0 == x ? 1.f - wx : 0.f) + (a1 == x ? wx : 0.f);
+        acc = fmaf(cy * cx, to_f32(g[(long)oy * p.OW + ox]), acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (p.addend) acc += to_f32(static_cast<const io_t *>(p.addend)[idx]);
+        static_cast<io_t *>(p.din)[idx] = from_f32<io_t>(acc);
+    }
+}
+
 // The same gather through LDS, for the ratios the model uses (x2 up-sampling; the 256 x 256 edge map down to 128 / 64 /
 // 32).  A thread of the kernel above reads every candidate output itself: 4-6 rows x 8 columns of scalar loads per input
 // pixel -- the x2 up-sampling to 512 x 512 of 64 channels took 245 us for 671 MB (bound by load issue, not HBM).  Here a
@@ -294,6 +330,13 @@ extern "C" int mmu_bilinear_resize_bwd(const mmu_resize_params *p, void *stream)
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
     if (tiled_on) done = p->dtype == MMU_DTYPE_BF16 ? resize_bwd_tiled_launch<bf16_t>(a, st) : resize_bwd_tiled_launch<float>(a, st);
+    // more than 64 candidates per pixel and few enough pixels that a wave each still fills the chip
+    if (!done && a.rx > 0.f && a.ry > 0.f && 4.f / (a.rx * a.ry) >= 64.f && total <= (1L << 20)) {
+        const unsigned blocks = (unsigned)((total + 3) / 4);
+        if (p->dtype == MMU_DTYPE_BF16) resize_bwd_wave_kernel<bf16_t><<<blocks, 256, 0, st>>>(a);
+        else resize_bwd_wave_kernel<float><<<blocks, 256, 0, st>>>(a);
+        done = true;
+    }
     if (!done) {
         if (p->dtype == MMU_DTYPE_BF16) resize_bwd_kernel<bf16_t><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
         else resize_bwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);

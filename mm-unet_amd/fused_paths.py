@@ -15,7 +15,7 @@ from . import (conv3x3_mfma, conv3x3_small, conv_s2, mamba_simple, mamba_small_f
 _FLAGS = ((conv3x3_mfma, "ENABLED"), (conv3x3_small, "ENABLED"), (conv_s2, "ENABLED"), (mamba_simple, "BCL_ENABLED"),
           (mamba_small_fused, "ENABLED"), (maxpool, "ENABLED"), (mfma_gemm, "ENABLED"), (mfma_gemm, "NT_ENABLED"),
           (morph_coords, "ENABLED"), (morph_mix, "ENABLED"), (morph_sample, "ENABLED"), (norm_fused, "ENABLED"), (pointwise, "ENABLED"),
-          (pointwise, "GATED_MUL"), (pointwise, "STATS"), (resize, "ENABLED"), (tall_gemm, "STRIDE2_ENABLED"),
+          (pointwise, "GATED_MUL"), (pointwise, "STATS"), (pointwise, "CBAM_GATE"), (resize, "ENABLED"), (tall_gemm, "STRIDE2_ENABLED"),
           (tri_order, "ENABLED"), (selective_scan_interface, "PRE_SMALL_FUSED"),
           (selective_scan_interface, "POST_SMALL_FUSED"))
 

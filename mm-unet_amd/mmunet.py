@@ -319,7 +319,10 @@ class CBAM(nn.Module):
         else:
             x_avg = self.avg_pool(x)
             x_max = x.flatten(2).max(dim=2)[0].unsqueeze(-1).unsqueeze(-1)
-        c_out = self.sigmoid(self.mlp(x_avg) + self.mlp(x_max))
+        if fused and pointwise.cbam_gate_supported(self.mlp, x_avg):    # the shared MLP + sigmoid: one launch each way
+            c_out = pointwise.cbam_gate(self.mlp, x_avg, x_max)
+        else:
+            c_out = self.sigmoid(self.mlp(x_avg) + self.mlp(x_max))
         y1 = pointwise.gated_mul(x, c_out, xs, ss)
         if fused:
             s_cat = pointwise.channel_max_mean(y1, ss)

@@ -318,6 +318,69 @@ class _ChannelStatsFn(torch.autograd.Function):
         return dx, None
 
 
+class _CbamGateFn(torch.autograd.Function):
+    """(avg, max) (B, C, 1, 1), w1 (R, C, 1, 1), w2 (C, R, 1, 1) -> sigmoid(mlp(avg) + mlp(max)) (B, C, 1, 1)."""
+
+    @staticmethod
+    def forward(ctx, avg, mx, w1, w2):
+        _lib.require_gpu(avg, mx, w1, w2)
+        B, C = avg.shape[:2]
+        R = w1.shape[0]
+        ts = (avg, mx, w1, w2)
+        if any(t.dtype != torch.float32 for t in ts) or tuple(avg.shape) != (B, C, 1, 1) or mx.shape != avg.shape or \
+                tuple(w1.shape) != (R, C, 1, 1) or tuple(w2.shape) != (C, R, 1, 1):
+            raise RuntimeError("cbam_gate: float32 (B, C, 1, 1) vectors with (R, C, 1, 1) / (C, R, 1, 1) weights required")
+        avg, mx, w1, w2 = (t.contiguous() for t in ts)
+        gate = torch.empty_like(avg)
+        p = _lib.CbamGateParams()
+        p.batch, p.channels, p.hidden = B, C, R
+        p.avg, p.max, p.w1, p.w2, p.gate = avg.data_ptr(), mx.data_ptr(), w1.data_ptr(), w2.data_ptr(), gate.data_ptr()
+        with torch.cuda.device(avg.device):
+            _lib.check(_lib.lib().mmu_cbam_gate_fwd(p, _lib.stream_of(avg)))
+        ctx.save_for_backward(avg, mx, w1, w2, gate)
+        return gate
+
+    @staticmethod
+    def backward(ctx, g):
+        avg, mx, w1, w2, gate = ctx.saved_tensors
+        B, C = avg.shape[:2]
+        g = g.float().contiguous()
+        need = ctx.needs_input_grad
+        davg = torch.empty_like(avg) if need[0] else None
+        dmax = torch.empty_like(mx) if need[1] else None
+        dw1 = torch.empty_like(w1) if need[2] else None
+        dw2 = torch.empty_like(w2) if need[3] else None
+        p = _lib.CbamGateParams()
+        p.batch, p.channels, p.hidden = B, C, w1.shape[0]
+        p.avg, p.max, p.w1, p.w2, p.gate = avg.data_ptr(), mx.data_ptr(), w1.data_ptr(), w2.data_ptr(), gate.data_ptr()
+        p.dgate, p.davg, p.dmax, p.dw1, p.dw2 = g.data_ptr(), _lib.ptr(davg), _lib.ptr(dmax), _lib.ptr(dw1), _lib.ptr(dw2)
+        with torch.cuda.device(avg.device):
+            _lib.check(_lib.lib().mmu_cbam_gate_bwd(p, _lib.stream_of(avg)))
+        return davg, dmax, dw1, dw2
+
+
+CBAM_GATE = os.environ.get("MMUNET_CBAM_GATE", "1") != "0"
+
+
+def cbam_gate_supported(mlp, v):
+    """CBAM's shared MLP as the reference builds it (two bias-free 1 x 1 convolutions around a ReLU) on float32 pooled
+    vectors small enough for one workgroup."""
+    import torch.nn as nn
+    if not (ENABLED and CBAM_GATE and v.is_cuda and v.dtype == torch.float32 and v.dim() == 4 and v.shape[2:] == (1, 1)
+            and not torch.is_autocast_enabled() and isinstance(mlp, nn.Sequential) and len(mlp) == 3):
+        return False
+    a, r, b = mlp
+    ok = lambda c: (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)   # noqa: E731
+                    and c.groups == 1 and c.bias is None and c.weight.dtype == torch.float32)
+    return (ok(a) and ok(b) and isinstance(r, nn.ReLU) and a.in_channels == v.shape[1] and b.out_channels == v.shape[1]
+            and a.out_channels == b.in_channels and v.shape[0] * (v.shape[1] + 4 * a.out_channels) * 4 <= 48 * 1024)
+
+
+def cbam_gate(mlp, avg, mx):
+    """``sigmoid(mlp(avg) + mlp(mx))`` (MMUNet.py:329) in one launch each way."""
+    return _CbamGateFn.apply(avg, mx, mlp[0].weight, mlp[2].weight)
+
+
 def pixel_mean_max(x, x_slot=None):
     """(avg_pool(x), max_pool(x)) of CBAM's channel attention, each (B, C, 1, 1).  ``x_slot``: a conv3x3_small.SharedGrad
     of the consumers of ``x``."""

@@ -40,7 +40,7 @@ def test_param_structs_match_header_field_order():
             stmt = stmt.strip()
             if not stmt:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|float|double|int32_t|int64_t)\s*", "", stmt)
+            decl = re.sub(r"^(const\s+)?(void|float|double|int32_t|int64_t|uint8_t)\s*", "", stmt)
             names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
         return names
 
@@ -63,7 +63,8 @@ def test_param_structs_match_header_field_order():
                         ("mmu_mamba_small_params", _lib.MambaSmallParams),
                         ("mmu_conv_s2_params", _lib.ConvS2Params),
                         ("mmu_morph_mix_params", _lib.MorphMixParams),
-                        ("mmu_adamw_params", _lib.AdamWParams)):
+                        ("mmu_adamw_params", _lib.AdamWParams),
+                        ("mmu_cbam_gate_params", _lib.CbamGateParams)):
         # (mmu_cbam_stats_params declares two pointers per line: not parsed by this check)
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 

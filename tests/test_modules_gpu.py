@@ -540,7 +540,9 @@ def test_morph_sample_tokens_last_layout():
                                   # the LDS-tiled backward (ratios <= ~2.3): ragged 64 x 8 tiles, x2 and non-integer ratios
                                   ((1, 2, 70, 100), (140, 200)), ((2, 1, 30, 70), (66, 150)), ((1, 3, 9, 130), (13, 259)),
                                   # ... and its few-candidates form (down-sampling by >= 2)
-                                  ((1, 2, 140, 200), (70, 100)), ((2, 1, 64, 256), (16, 32)), ((1, 2, 100, 90), (37, 41))])
+                                  ((1, 2, 140, 200), (70, 100)), ((2, 1, 64, 256), (16, 32)), ((1, 2, 100, 90), (37, 41)),
+                                  # a wave per input pixel (large up-sampling ratios, the side outputs)
+                                  ((2, 1, 16, 16), (512, 512)), ((1, 2, 9, 7), (100, 131)), ((2, 1, 64, 64), (256, 256))])
 def test_bilinear_resize_vs_interpolate(case):
     """bilinear_resize == F.interpolate(mode="bilinear", align_corners=True) evaluated on CPU
     (MMUNet.py:362,384,571-575), forward and input gradient, up- and down-sampling, degenerate sizes."""
@@ -1320,6 +1322,33 @@ def test_max_pool3s2_vs_module(shape):
     xn.view(-1)[::7] = float("nan")
     xn[0, 0] = float("-inf")
     assert torch.equal(torch.nan_to_num(maxpool.pool_module(m, xn), nan=12345.0), torch.nan_to_num(m(xn), nan=12345.0))
+
+
+@pytest.mark.parametrize("case", [(8, 64, 4), (3, 32, 2), (1, 16, 1), (5, 48, 7)])
+def test_cbam_gate_vs_modules(case):
+    """pointwise.cbam_gate == sigmoid(mlp(avg) + mlp(max)) with CBAM's shared bias-free 1 x 1 MLP (MMUNet.py:319-329):
+    output and all four gradients against the module calls in float64."""
+    from mm_unet_amd import pointwise
+    B, C, R = case
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    mlp = torch.nn.Sequential(torch.nn.Conv2d(C, R, 1, bias=False), torch.nn.ReLU(inplace=True),
+                              torch.nn.Conv2d(R, C, 1, bias=False)).to(DEV)
+    avg = torch.randn(B, C, 1, 1, device=DEV, generator=gen).requires_grad_()
+    mx = (avg.detach() + torch.rand(B, C, 1, 1, device=DEV, generator=gen)).requires_grad_()
+    g = torch.randn(B, C, 1, 1, device=DEV, generator=gen)
+    assert pointwise.cbam_gate_supported(mlp, avg)
+    out = pointwise.cbam_gate(mlp, avg, mx)
+    got = torch.autograd.grad(out, [avg, mx, mlp[0].weight, mlp[2].weight], g)
+    m64 = torch.nn.Sequential(torch.nn.Conv2d(C, R, 1, bias=False), torch.nn.ReLU(), torch.nn.Conv2d(R, C, 1, bias=False)).double()
+    m64.load_state_dict({k: v.detach().double().cpu() for k, v in mlp.state_dict().items()})
+    a64, x64 = avg.detach().double().cpu().requires_grad_(), mx.detach().double().cpu().requires_grad_()
+    ref = torch.sigmoid(m64(a64) + m64(x64))
+    want = torch.autograd.grad(ref, [a64, x64, m64[0].weight, m64[2].weight], g.double().cpu())
+    close(out, ref.float(), 1e-5, 1e-6, "gate")
+    for name, a, b in zip(("d avg", "d max", "d w1", "d w2"), got, want):
+        close(a, b.float(), 1e-4, 1e-6, name)
+    assert not pointwise.cbam_gate_supported(torch.nn.Sequential(torch.nn.Conv2d(C, R, 1), torch.nn.ReLU(),
+                                                                 torch.nn.Conv2d(R, C, 1, bias=False)).to(DEV), avg)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 32, 32), (1, 3, 18, 20), (8, 64, 256, 256)])
