@@ -119,6 +119,8 @@ typedef struct {
     int64_t A_ds, A_ns;
     int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns;
     int64_t dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
+    int32_t dA_times_A;      /* non-zero: dA receives dA * A, the gradient of a parameter a with A = -exp(a) (Mamba's A_log,
+                              * mamba_simple.py:209); needs a contiguous A.  0: dA as the reference returns it */
 } mmu_scan_bwd_params;
 
 int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream);

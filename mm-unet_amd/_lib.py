@@ -37,6 +37,7 @@ class ScanBwdParams(ctypes.Structure):
                                "du_bs", "du_ds", "ddelta_bs", "ddelta_ds", "dz_bs", "dz_ds", "out_z_bs",
                                "out_z_ds", "A_ds", "A_ns", "B_bs", "B_gs", "B_ns", "C_bs", "C_gs", "C_ns",
                                "dB_bs", "dB_gs", "dB_ns", "dC_bs", "dC_gs", "dC_ns")]
+        + [("dA_times_A", _i32)]
     )
 
 

@@ -132,8 +132,76 @@ __device__ void job_rows(const long *row, int blk, float (*sums)[64]) {
     }
 }
 
+// kinds 4 / 5: the selective scan's dA / dD / d delta_bias from its per-(batch, tile) partials -- reduce_partials_w8 (+
+// reduce_slices_w8) of selective_scan_bwd_w8.hip and reduce_partials (+ reduce_slices) of selective_scan.hip, same order:
+// per slice of 512 rows eight strided row sums met in order, then the slices in order.  One workgroup per channel d; its
+// four quarters take four slices at a time.
+//   {4, part8, dA, dD, dbias, BT, dim, A or 0}: part8[bt][d][wave 0..7][4] = (dA[2w], dA[2w+1], dD share, dbias share)
+//   {5, part,  dA, dD, dbias, BC, dim | N << 32, A or 0}: part[bc][d][N + 2] = (dA[0..N), dD, dbias)
+// A given: dA is stored multiplied by A (the gradient of A_log, see mmu_scan_bwd_params.dA_times_A).
+__device__ void job_scan(const long *row, int d, float *red /* 1024 */, float *tot /* 32 */, bool w8) {
+    const float *part = reinterpret_cast<const float *>(row[1]);
+    float *dA = reinterpret_cast<float *>(row[2]);
+    float *dD = reinterpret_cast<float *>(row[3]);
+    float *dbias = reinterpret_cast<float *>(row[4]);
+    const int BT = (int)row[5], dim = (int)(row[6] & 0xffffffff);
+    const int N = w8 ? 16 : (int)(row[6] >> 32), M = w8 ? 32 : N + 2;
+    const float *Asc = reinterpret_cast<const float *>(row[7]);
+    const int n_slices = (BT + 511) / 512;
+    const int lt = threadIdx.x & 255, sw = threadIdx.x >> 8;
+    const int jl = lt & 31, r = lt >> 5;
+    for (int j0 = 0; j0 < M; j0 += 32) {
+        const int j = j0 + jl;
+        float total = 0.f;
+        for (int s0 = 0; s0 < n_slices; s0 += 4) {
+            const int sl = s0 + sw;
+            float s = 0.f;
+            if (sl < n_slices && j < M) {
+                const int r0 = sl * 512, r1 = min(r0 + 512, BT);
+                for (int bt = r0 + r; bt < r1; bt += 8) s += part[((long)bt * dim + d) * M + j];
+            }
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (threadIdx.x < 32) {
+                for (int q = 0; q < 4 && s0 + q < n_slices; ++q) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t += red[q * 256 + k * 32 + threadIdx.x];
+                    total = (s0 + q == 0) ? t : total + t;
+                }
+            }
+            __syncthreads();
+        }
+        if (w8) {
+            if (threadIdx.x < 32) tot[threadIdx.x] = total;
+        } else if (threadIdx.x < 32) {
+            if (j < N)
+                dA[(long)d * N + j] = Asc ? total * Asc[(long)d * N + j] : total;
+            else if (j == N) {
+                if (dD) dD[d] = total;
+            } else if (j == N + 1) {
+                if (dbias) dbias[d] = total;
+            }
+        }
+    }
+    if (!w8) return;
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < 16) {
+        const float v = tot[(j >> 1) * 4 + (j & 1)];
+        dA[(long)d * 16 + j] = Asc ? v * Asc[(long)d * 16 + j] : v;
+    } else if (j < 18) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) s += tot[wv * 4 + 2 + (j - 16)];
+        float *o = j == 16 ? dD : dbias;
+        if (o) o[d] = s;
+    }
+}
+
 __global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__restrict__ table, const int *__restrict__ work) {
     __shared__ float sums[16][64];
+    __shared__ float tot[32];
     const int job = work[2 * blockIdx.x], blk = work[2 * blockIdx.x + 1];
     const long *row = table + (long)job * ROW;
     const int kind = (int)row[0];   // workgroup-uniform
@@ -143,6 +211,8 @@ __global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__res
         job_conv3x3s(row, blk);
     else if (kind == 2)
         job_conv1d(row, blk);
+    else if (kind == 4 || kind == 5)
+        job_scan(row, blk, &sums[0][0], tot, kind == 4);
     else
         job_rows(row, blk, sums);
 }

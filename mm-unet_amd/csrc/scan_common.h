@@ -103,4 +103,4 @@ int mmu_scan_fwd_stream(const ScanArgs &a, int dtype, hipStream_t st);
 // its dA / dD / dbias partials have their own layout and reduction
 int mmu_scan_bwd_apply_w8(const ScanArgs &a, int dtype, hipStream_t st);
 int mmu_scan_bwd_reduce_w8(const float *part8, float *part2, int batch, int dim, int seqlen, float *dA, float *dD,
-                           float *dbias, hipStream_t st);
+                           float *dbias, const float *Asc, hipStream_t st);

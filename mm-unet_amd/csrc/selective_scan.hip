@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(256, 2) void chunk_apply_bwd_p4_kernel(ScanArgs p) 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int BC, int dim, int N,
                                                               float *dA, float *dD, float *dbias,
-                                                              float *__restrict__ part2) {
+                                                              float *__restrict__ part2, const float *__restrict__ Asc) {
     __shared__ float red[256];
     const int d = blockIdx.x;
     const int bc0 = blockIdx.y * 512;
@@ -1472,7 +1472,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
             if (part2) {
                 if (j < M) part2[((long)blockIdx.y * dim + d) * M + j] = t;
             } else if (j < N) {
-                dA[(long)d * N + j] = t;
+                dA[(long)d * N + j] = Asc ? t * Asc[(long)d * N + j] : t;
             } else if (j == N) {
                 if (dD) dD[d] = t;
             } else if (j == N + 1) {
@@ -1484,13 +1484,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
 }
 
 __global__ __launch_bounds__(64) void reduce_slices_kernel(const float *__restrict__ part2, int n_slices, int dim, int N,
-                                                           float *dA, float *dD, float *dbias) {
+                                                           float *dA, float *dD, float *dbias,
+                                                           const float *__restrict__ Asc) {
     const int d = blockIdx.x, M = N + 2;
     for (int j = threadIdx.x; j < M; j += 64) {
         float t = 0.f;
         for (int sl = 0; sl < n_slices; ++sl) t += part2[((long)sl * dim + d) * M + j];
         if (j < N)
-            dA[(long)d * N + j] = t;
+            dA[(long)d * N + j] = Asc ? t * Asc[(long)d * N + j] : t;
         else if (j == N) {
             if (dD) dD[d] = t;
         } else if (dbias)
@@ -1863,22 +1864,31 @@ extern "C" int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream
     }
     if (r) return r;
     const size_t xs = (size_t)p->batch * p->dim * p->n_chunks * 2 * p->dstate;
+    const float *Asc = nullptr;   // dA * A wanted: A read as a dense [dim][dstate] matrix
+    if (p->dA_times_A) {
+        MMU_CHECK(p->A_ns == 1 && p->A_ds == p->dstate, "selective_scan_bwd: dA_times_A needs a contiguous A");
+        Asc = p->A;
+    }
     if (w8_layout) {
         const size_t parts = (size_t)p->batch * p->n_chunks * p->dim * (p->dstate + 2);
         return mmu_scan_bwd_reduce_w8(p->workspace + xs, p->workspace + xs + parts + (have_x ? 0 : xs), p->batch, p->dim,
-                                      p->seqlen, p->dA, p->dD, p->ddelta_bias, st);
+                                      p->seqlen, p->dA, p->dD, p->ddelta_bias, Asc, st);
     }
     {
         const int BC = p->batch * p->n_chunks;
         const int n_slices = (BC + 511) / 512;
         const size_t parts = (size_t)BC * p->dim * (p->dstate + 2);
+        // inside a deferred scope: with the other parameter-gradient sums of the pass (deferred_reduce.hip, kind 5)
+        const long job[8] = {5, (long)(p->workspace + xs), (long)p->dA, (long)p->dD, (long)p->ddelta_bias, BC,
+                             (long)p->dim | ((long)p->dstate << 32), (long)Asc};
+        if (mmu_defer_job(job)) return 0;
         float *part2 = n_slices > 1 ? p->workspace + xs + parts + (have_x ? 0 : xs) : nullptr;
         dim3 g5(p->dim, n_slices);
         reduce_partials_kernel<<<g5, 256, 0, st>>>(p->workspace + xs, BC, p->dim, p->dstate, p->dA, p->dD,
-                                                   p->ddelta_bias, part2);
+                                                   p->ddelta_bias, part2, Asc);
         if (part2)
             reduce_slices_kernel<<<p->dim, 64, 0, st>>>(part2, n_slices, p->dim, p->dstate, p->dA, p->dD,
-                                                        p->ddelta_bias);
+                                                        p->ddelta_bias, Asc);
     }
     MMU_HIP_LAUNCH_CHECK("reduce_partials");
     return 0;

@@ -409,10 +409,12 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
 // bt = (batch, tile) in a fixed order.  grid (dim, n_slices), block 256.  One slice: straight to the outputs;
 // several: slice sums to part2[slice][d][32], added by reduce_slices_w8_kernel.  No atomics.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void w8_emit(const float *t32 /* LDS, 32 column sums */, int d, float *dA, float *dD, float *dbias) {
+__device__ __forceinline__ void w8_emit(const float *t32 /* LDS, 32 column sums */, int d, float *dA, float *dD, float *dbias,
+                                        const float *Asc /* optional: dA *= A */) {
     const int j = threadIdx.x;
     if (j < 16) {
-        dA[(long)d * 16 + j] = t32[(j >> 1) * 4 + (j & 1)];
+        const float v = t32[(j >> 1) * 4 + (j & 1)];
+        dA[(long)d * 16 + j] = Asc ? v * Asc[(long)d * 16 + j] : v;
     } else if (j < 18) {
         float s = 0.f;
 #pragma unroll
@@ -423,7 +425,8 @@ __device__ __forceinline__ void w8_emit(const float *t32 /* LDS, 32 column sums 
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_w8_kernel(const float *__restrict__ part8, int BT, int dim, float *dA,
-                                                                 float *dD, float *dbias, float *__restrict__ part2) {
+                                                                 float *dD, float *dbias, float *__restrict__ part2,
+                                                                 const float *__restrict__ Asc) {
     __shared__ float red[256];
     __shared__ float t32[32];
     const int d = blockIdx.x;
@@ -444,11 +447,11 @@ __global__ __launch_bounds__(256) void reduce_partials_w8_kernel(const float *__
             t32[threadIdx.x] = t;
     }
     __syncthreads();
-    if (!part2) w8_emit(t32, d, dA, dD, dbias);
+    if (!part2) w8_emit(t32, d, dA, dD, dbias, Asc);
 }
 
 __global__ __launch_bounds__(64) void reduce_slices_w8_kernel(const float *__restrict__ part2, int n_slices, int dim, float *dA,
-                                                              float *dD, float *dbias) {
+                                                              float *dD, float *dbias, const float *__restrict__ Asc) {
     __shared__ float t32[32];
     const int d = blockIdx.x;
     if (threadIdx.x < 32) {
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(64) void reduce_slices_w8_kernel(const float *__res
         t32[threadIdx.x] = t;
     }
     __syncthreads();
-    w8_emit(t32, d, dA, dD, dbias);
+    w8_emit(t32, d, dA, dD, dbias, Asc);
 }
 
 unsigned long long g_lds_done[2][3];
@@ -512,12 +515,16 @@ int mmu_scan_bwd_apply_w8(const ScanArgs &a, int dtype, hipStream_t st) {
 
 // K5 of the w8 layout.  `part8` = the partial region of the workspace, `part2` = its slice region.
 int mmu_scan_bwd_reduce_w8(const float *part8, float *part2, int batch, int dim, int seqlen, float *dA, float *dD,
-                           float *dbias, hipStream_t st) {
+                           float *dbias, const float *Asc, hipStream_t st) {
     const int BT = batch * (seqlen / W8_TT);
     const int n_slices = (BT + 511) / 512;
+    {   // inside a deferred scope: with the other parameter-gradient sums of the pass (deferred_reduce.hip, kind 4)
+        const long job[8] = {4, (long)part8, (long)dA, (long)dD, (long)dbias, BT, dim, (long)Asc};
+        if (mmu_defer_job(job)) return 0;
+    }
     dim3 g5(dim, n_slices);
-    reduce_partials_w8_kernel<<<g5, 256, 0, st>>>(part8, BT, dim, dA, dD, dbias, n_slices > 1 ? part2 : nullptr);
-    if (n_slices > 1) reduce_slices_w8_kernel<<<dim, 64, 0, st>>>(part2, n_slices, dim, dA, dD, dbias);
+    reduce_partials_w8_kernel<<<g5, 256, 0, st>>>(part8, BT, dim, dA, dD, dbias, n_slices > 1 ? part2 : nullptr, Asc);
+    if (n_slices > 1) reduce_slices_w8_kernel<<<dim, 64, 0, st>>>(part2, n_slices, dim, dA, dD, dbias, Asc);
     MMU_HIP_LAUNCH_CHECK("reduce_partials_w8");
     return 0;
 }

@@ -33,6 +33,28 @@ def active():
     return _active is not None
 
 
+# Gradients of A that already carry the factor A (the scan's dA_times_A): mamba_simple._NegExpAll.backward passes them
+# through as d A_log instead of multiplying.  Keyed by storage address between a scan's backward and _NegExpAll's, which
+# empties the set (as does every model forward).
+_PRESCALED = set()
+
+
+def mark_prescaled(t):
+    _PRESCALED.add(t.data_ptr())
+
+
+def take_prescaled(t):
+    ptr = t.data_ptr()
+    if ptr in _PRESCALED:
+        _PRESCALED.discard(ptr)
+        return True
+    return False
+
+
+def clear_prescaled():
+    _PRESCALED.clear()
+
+
 class paused:
     """``with paused():`` -- calls inside reduce at once although a scope is open (their result is read right away)."""
 
@@ -94,6 +116,8 @@ class Scope:
                 nb = (r[4] * ((r[6] * 10 + 3) & ~3) + 63) // 64
             elif r[0] == 2:
                 nb = (r[5] + 15) // 16
+            elif r[0] in (4, 5):
+                nb = r[6] & 0xffffffff          # a workgroup per channel
             else:
                 nb = (r[7] + 63) // 64
             work += [[j, b] for b in range(nb)]

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from .causal_conv1d_interface import causal_conv1d_fn
 from .selective_scan_interface import _dbl_view, mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn
-from . import tri_order
+from . import deferred, tri_order
 from .tall_gemm import proj_bcl, proj_tokens
 
 
@@ -41,6 +41,8 @@ class _NegExpAll(torch.autograd.Function):
     def forward(ctx, *params):
         outs = torch._foreach_exp([p.detach().float() for p in params])
         torch._foreach_neg_(outs)
+        for o, p in zip(outs, params):     # a scan may return d A_log = dA * A for these (selective_scan_interface)
+            o._mmu_neg_exp = p.dtype == torch.float32
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*outs)
         ctx.dtypes = [p.dtype for p in params]
@@ -49,8 +51,19 @@ class _NegExpAll(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         outs = ctx.saved_tensors
-        idx = [i for i, g in enumerate(grads) if g is not None]
         res = [None] * len(grads)
+        idx = []
+        for i, g in enumerate(grads):
+            if g is None:
+                continue
+            if deferred.take_prescaled(g):      # already d A_log (possibly still to be filled by a deferred.Scope)
+                res[i] = g
+            else:
+                idx.append(i)
+        if deferred._PRESCALED:
+            deferred.clear_prescaled()
+            raise RuntimeError("_NegExpAll: a pre-scaled dA did not arrive as it was returned (accumulated with another "
+                               "gradient?)")
         if idx:
             prod = torch._foreach_mul([grads[i] for i in idx], [outs[i] for i in idx])     # dA_log = dA * A
             for i, v in zip(idx, prod):
@@ -69,6 +82,7 @@ class precomputed_A:
                 self.params += m.used_A_params()
 
     def __enter__(self):
+        deferred.clear_prescaled()
         if self.params and all(p.is_cuda for p in self.params):
             for p, a in zip(self.params, _NegExpAll.apply(*self.params)):
                 _A_CACHE[id(p)] = a

@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, deferred
 
 
 def _check(cond, msg):
@@ -104,13 +104,16 @@ def _fwd_one(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=Tr
 
 
 def _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
-             dB_out=None, dC_out=None):
+             dB_out=None, dC_out=None, dA_times_A=False, defer=False):
     """selective_scan_cuda.bwd: returns ``[du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]``
     (selective_scan.cpp:338-492).  ``out_`` is accepted for signature parity and not read: y is
     recomputed from the states the kernel rebuilds anyway.
 
     ``dB_out`` / ``dC_out`` (extension): pre-allocated float32 (batch, groups, dstate, L) views with unit
-    L stride to receive dB / dC (e.g. rows of the projection-gradient matrix), saving a copy."""
+    L stride to receive dB / dC (e.g. rows of the projection-gradient matrix), saving a copy.
+    ``dA_times_A`` (extension): dA is returned multiplied by A -- d A_log for A = -exp(A_log).
+    ``defer`` (extension): inside a deferred.Scope the final sums of dA / dD / ddelta_bias may run at ``Scope.launch()``
+    -- only for a caller whose three results go straight into parameter gradients."""
     batch, dim, seqlen, dstate, g = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     _lib.require_gpu(dout, x_, dz_)
     _check(dout.dtype == u.dtype and tuple(dout.shape) == (batch, dim, seqlen) and dout.stride(-1) == 1,
@@ -173,8 +176,16 @@ def _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_
     p.C_bs, p.C_gs, p.C_ns = C.stride(0), C.stride(1), C.stride(2)
     p.dB_bs, p.dB_gs, p.dB_ns = dB.stride(0), dB.stride(1), dB.stride(2)
     p.dC_bs, p.dC_gs, p.dC_ns = dC.stride(0), dC.stride(1), dC.stride(2)
+    _check(not dA_times_A or (A.is_contiguous() and A.dtype == torch.float32), "selective_scan_bwd: dA_times_A needs a "
+           "contiguous float32 A")
+    p.dA_times_A = int(bool(dA_times_A))
     with torch.cuda.device(u.device):
-        _lib.check(L.mmu_selective_scan_bwd(p, _lib.stream_of(u)))
+        if defer:
+            _lib.check(L.mmu_selective_scan_bwd(p, _lib.stream_of(u)))
+            deferred.keep(ws)
+        else:
+            with deferred.paused():
+                _lib.check(L.mmu_selective_scan_bwd(p, _lib.stream_of(u)))
     result = [du, ddelta, dA, dB if dB.dtype == B.dtype else dB.to(B.dtype),
               dC if dC.dtype == C.dtype else dC.to(C.dtype), dD, ddelta_bias]
     if has_z:
@@ -350,11 +361,14 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=True, o
 
 
 def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
-        dB_out=None, dC_out=None):
+        dB_out=None, dC_out=None, dA_times_A=False, defer=False):
     """selective_scan_cuda.bwd (selective_scan.cpp:338-492); see ``_bwd_one``."""
     if A.dim() == 2 and u.dim() == 3 and group_split(A.shape[1], u):
         _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
-        return _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_softplus, recompute_out_z,
-                           dB_out, dC_out)
+        res = _bwd_groups(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, dz_, delta_softplus, recompute_out_z,
+                          dB_out, dC_out)
+        if dA_times_A:
+            res[2] = res[2] * A
+        return res
     return _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
-                    dB_out, dC_out)
+                    dB_out, dC_out, dA_times_A, defer)

@@ -242,6 +242,11 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     conv1d_bias = conv1d_bias.contiguous() if conv1d_bias is not None else None
     ctx.is_variable_B = B is None
     ctx.is_variable_C = C is None
+    # A = -exp(A_log) from mamba_simple's batched form: the scan returns d A_log = dA * A itself (one multiply launch per
+    # model less, and the sum may then wait for deferred.Scope.launch() with the other parameter gradients -- which it
+    # may only if D and delta_bias are parameters too, i.e. nothing reads their gradients during the backward pass)
+    ctx.A_neg_exp = bool(getattr(A, "_mmu_neg_exp", False)) and A.dtype == torch.float32 and A.is_contiguous()
+    ctx.scan_params_are_leaves = all(t is None or (t.is_leaf and t.dtype == torch.float32) for t in (D, delta_bias))
     ctx.B_proj_bias_is_None = B_proj_bias is None
     ctx.C_proj_bias_is_None = C_proj_bias is None
     _lib.require_gpu(x)
@@ -323,8 +328,11 @@ def _inner_backward(ctx, dout):
     dB_out = _rows_as_bnl(dx_dblT[r:r + d_state], batch, L) if (ctx.is_variable_B and direct) else None
     dC_out = _rows_as_bnl(dx_dblT[r + d_state:], batch, L) if (ctx.is_variable_C and direct) else None
     res = selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz,
-                                 ctx.delta_softplus, ctx.with_out_proj, dB_out=dB_out, dC_out=dC_out)
+                                 ctx.delta_softplus, ctx.with_out_proj, dB_out=dB_out, dC_out=dC_out,
+                                 dA_times_A=ctx.A_neg_exp, defer=ctx.A_neg_exp and ctx.scan_params_are_leaves)
     dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz = res[:8]
+    if ctx.A_neg_exp:
+        deferred.mark_prescaled(dA)
     dout_proj_weight = dout_proj_bias = None
     if ctx.with_out_proj:
         out_z = res[8]

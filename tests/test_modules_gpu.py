@@ -1,6 +1,8 @@
 """GPU parity of the nn.Module surface (HIP kernels underneath) against fixtures produced by the
 REFERENCE's own modules: Mamba (uni/bi/tri-directional), MMConv, MM_Net (eval logits <= 1e-3 = the
 north-star forward bound; Dice+BCE fwd+bwd in eval and train mode), Unet."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1626,6 +1628,46 @@ def test_multi_tensor_adamw_equals_torch_fused_adamw():
         assert float(sa["step"]) == float(sb["step"]) == 4.0
         close(sb["exp_avg"], sa["exp_avg"], 1e-5, 2e-7, f"exp_avg {i}")
         close(sb["exp_avg_sq"], sa["exp_avg_sq"], 1e-5, 1e-8, f"exp_avg_sq {i}")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 4096, True), (8, 6, 16384, True), (8, 16, 65536, True), (3, 6, 1000, False),
+                                  (2, 5, 40000, False)])
+def test_deferred_scan_parameter_gradient_sums_are_bit_identical(case):
+    """The scan's dA / dD / d delta_bias (K5: sums over the (batch, tile) partials; both partial layouts, one and several
+    slices of 512 rows) recorded inside a deferred.Scope and run by its one launch equal the immediate kernels bit for
+    bit, with and without the factor A (dA_times_A: d A_log for A = -exp(A_log), selective_scan_interface)."""
+    from mm_unet_amd import deferred, selective_scan_hip as ss
+    B, D, L, w8 = case
+    N = 16
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=gen)     # noqa: E731
+    u, delta, z, dout = rnd(B, D, L), 0.1 * rnd(B, D, L), rnd(B, D, L), rnd(B, D, L)
+    A = -torch.exp(0.3 * rnd(D, N))
+    Bm, Cm = rnd(B, 1, N, L), rnd(B, 1, N, L)
+    Dp, bias = rnd(D), 0.1 * rnd(D)
+    os.environ["MMU_SCAN_BWD_W8"] = "1" if w8 else "0"
+    try:
+        out, x, _ = ss.fwd(u, delta, A, Bm, Cm, Dp, z, bias, True)
+
+        def run(scaled, defer):
+            return ss.bwd(u, delta, A, Bm, Cm, Dp, z, bias, dout, x, None, None, True, False, dA_times_A=scaled, defer=defer)
+
+        for scaled in (False, True):
+            ref = run(scaled, False)
+            scope = deferred.Scope(DEV)
+            with scope:
+                got = run(scaled, True)
+                inside = run(scaled, False)          # (not deferred although a scope is open)
+                scope.launch()
+            assert scope.n_jobs == 1
+            torch.cuda.synchronize()
+            for i in (2, 5, 6):                     # dA, dD, d delta_bias
+                assert torch.equal(ref[i], got[i]) and torch.equal(ref[i], inside[i]), (scaled, i)
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+            if scaled:
+                close(ref[2], run(False, False)[2] * A, 1e-6, 1e-7, "dA * A")
+    finally:
+        os.environ.pop("MMU_SCAN_BWD_W8", None)
 
 
 def test_deferred_weight_gradient_sums_are_bit_identical():
