@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import _lib, conv_s2
+from . import _lib, conv_s2, deferred
 
 # The hi/lo bf16 split drops the lo*lo term: ~2^-16 relative per product against 2^-24 on the library's float32 path
 # (tests pin 5e-5 / 1e-4 on randn data).  ENABLED = False (or MMUNET_CONV3X3_MFMA=0 in the environment) routes every
@@ -57,6 +57,7 @@ def _wgrad(x, g, cout):
     p.input, p.weight, p.out, p.workspace = x.data_ptr(), g.data_ptr(), dw.data_ptr(), ws.data_ptr()
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().mmu_conv3x3_wgrad_mfma(p, _lib.stream_of(x)))
+    deferred.keep(ws)    # (inside a deferred.Scope the sum over the workgroups' partials runs later)
     return dw
 
 

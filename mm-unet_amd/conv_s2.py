@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, deferred
 
 ENABLED = os.environ.get("MMUNET_CONV_S2_MFMA", "1") != "0"   # False: the modules' own calls (A/B runs, tests)
 
@@ -46,6 +46,7 @@ def _wgrad(high, low, k):
     p.input, p.weight, p.out, p.workspace = high.data_ptr(), low.data_ptr(), dw.data_ptr(), ws.data_ptr()
     with torch.cuda.device(high.device):
         _lib.check(L.mmu_conv_s2_wgrad_mfma(p, _lib.stream_of(high)))
+    deferred.keep(ws)    # (inside a deferred.Scope the sum over the workgroups' partials runs later)
     return dw
 
 
@@ -59,6 +60,7 @@ def _bias_grad(g):
     out = torch.empty(C, device=g.device, dtype=torch.float32)
     with torch.cuda.device(g.device):
         _lib.check(_lib.lib().mmu_channel_sum(g.data_ptr(), B, C, H * W, ws.data_ptr(), out.data_ptr(), _lib.stream_of(g)))
+    deferred.keep(ws)    # (inside a deferred.Scope the sum over the batch runs later)
     return out
 
 

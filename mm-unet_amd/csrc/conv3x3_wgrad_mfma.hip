@@ -265,6 +265,11 @@ extern "C" int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *st
     conv3x3_wgrad_mfma_kernel<<<grid, NT, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("conv3x3_wgrad_mfma");
     const long n = (long)p->out_channels * p->in_channels * 9;
+    {   // inside a deferred scope: with the other weight-gradient sums of the pass (deferred_reduce.hip, kind 6)
+        const long job[8] = {6, (long)a.ws, (long)p->out, (long)p->in_channels | ((long)p->out_channels << 32), 0, a.n_cic,
+                             a.wg_per_cc, (long)CO | ((long)CI << 32)};
+        if (mmu_defer_job(job)) return 0;
+    }
     conv3x3_wgrad_sum_kernel<<<(unsigned)((n + 15) / 16), 256, 0, st>>>(a.ws, p->out, p->in_channels, p->out_channels,
                                                                          a.n_cic, a.wg_per_cc);
     MMU_HIP_LAUNCH_CHECK("conv3x3_wgrad_mfma(sum)");

@@ -164,6 +164,8 @@ extern "C" int mmu_conv7x7_2to1_bwd(const mmu_conv7x7_params *p, void *stream) {
         const int nblk = conv7_wblocks(n);
         conv7_bwd_weight_kernel<<<nblk, 256, 0, st>>>(p->input, p->dout, p->workspace, p->batch, p->height, p->width);
         MMU_HIP_LAUNCH_CHECK("conv7x7_2to1_bwd(weight)");
+        const long job[8] = {7, (long)p->workspace, (long)p->dweight, 0, NW7, nblk, (NW7 + 3) & ~3, 0};
+        if (mmu_defer_job(job)) return 0;   // (deferred_reduce.hip: with the other weight-gradient sums of the pass)
         conv7_wsum_kernel<<<(NW7 + 3) / 4, 256, 0, st>>>(p->workspace, p->dweight, nblk);
         MMU_HIP_LAUNCH_CHECK("conv7x7_2to1_bwd(weight sum)");
     }

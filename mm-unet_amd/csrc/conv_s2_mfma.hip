@@ -627,6 +627,11 @@ extern "C" int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream)
     conv_s2_wgrad_kernel<<<grid, WNT, WLDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("conv_s2_wgrad_mfma");
     const long n = (long)p->out_channels * p->in_channels * p->kernel * p->kernel;
+    {   // inside a deferred scope: with the other weight-gradient sums of the pass (deferred_reduce.hip, kind 6)
+        const long job[8] = {6, (long)a.ws, (long)p->out, (long)p->in_channels | ((long)p->out_channels << 32), p->kernel,
+                             a.n_cic, a.wg_per_cc, (long)WCO | ((long)WCI << 32)};
+        if (mmu_defer_job(job)) return 0;
+    }
     conv_s2_wgrad_sum_kernel<<<(unsigned)((n + 15) / 16), 256, 0, st>>>(a.ws, p->out, p->in_channels, p->out_channels,
                                                                          p->kernel, a.n_cic, a.wg_per_cc);
     MMU_HIP_LAUNCH_CHECK("conv_s2_wgrad_mfma(sum)");

@@ -132,6 +132,59 @@ __device__ void job_rows(const long *row, int blk, float (*sums)[64]) {
     }
 }
 
+// kind 6: weight gradient of the matrix-core convolutions from its per-workgroup tile partials (conv3x3_wgrad_sum_kernel of
+// conv3x3_wgrad_mfma.hip, conv_s2_wgrad_sum_kernel of conv_s2_mfma.hip; same order: 16 lanes per output stride over the
+// partials, row-local DPP sum).  {6, ws, dW, Cin | Cout << 32, K (0: the 3 x 3 stride-1 layout), n_cic, wg_per_cc,
+// TCO | TCI << 32}; 64 outputs per workgroup.
+__device__ void job_conv_tiles(const long *row, int blk) {
+    const float *ws = reinterpret_cast<const float *>(row[1]);
+    float *dW = reinterpret_cast<float *>(row[2]);
+    const int Cin = (int)(row[3] & 0xffffffff), Cout = (int)(row[3] >> 32), K = (int)row[4];
+    const int n_cic = (int)row[5], wg_per_cc = (int)row[6];
+    const int TCO = (int)(row[7] & 0xffffffff), TCI = (int)(row[7] >> 32);
+    const int sub = threadIdx.x & 15;
+    const int KK = K ? K * K : 9, S = K ? 4 : 9;
+    const long n = (long)Cout * Cin * KK;
+    long i = (long)blk * 64 + (threadIdx.x >> 4);
+    const bool live = i < n;
+    i = live ? i : n - 1;
+    const long r = i / KK;
+    const int t = (int)(i - r * KK);
+    const int c = (int)(r % Cin), co = (int)(r / Cin);
+    int v = c, sidx = t;
+    if (K) {   // stride 2: kh = 2a + 1 - py  <=>  py = (kh + 1) & 1, a = (kh - 1 + py) / 2 (conv_s2_mfma.hip)
+        const int kw = t % K, kh = t / K;
+        const int py = (kh + 1) & 1, a = (kh - 1 + py) >> 1, pxx = (kw + 1) & 1, b = (kw - 1 + pxx) >> 1;
+        v = (py * 2 + pxx) * Cin + c;
+        sidx = a * 2 + b;
+    }
+    const int cc = (co / TCO) * n_cic + v / TCI;
+    const long tile = (long)TCO * TCI * S;
+    const float *src = ws + ((long)cc * wg_per_cc) * tile + ((co % TCO) * TCI + v % TCI) * S + sidx;
+    float a = 0.f;
+    for (int k = sub; k < wg_per_cc; k += 16) a += src[(long)k * tile];
+    a += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, a);
+    a += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, a);
+    a += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, a);
+    a += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, a);
+    if (live && sub == 15) dW[i] = a;
+}
+
+// kind 7: a wave per output over strided partial rows (conv7_wsum_kernel of conv7x7_small.hip).
+// {7, part, dst, -, n_out, nparts, stride, -}; 16 outputs per workgroup
+__device__ void job_wave_rows(const long *row, int blk) {
+    const float *part = reinterpret_cast<const float *>(row[1]);
+    float *dst = reinterpret_cast<float *>(row[2]);
+    const int n_out = (int)row[4], nparts = (int)row[5], stride = (int)row[6];
+    const int lane = threadIdx.x & 63;
+    const int i = blk * 16 + (threadIdx.x >> 6);
+    if (i >= n_out) return;
+    float s = 0.f;
+    for (int k = lane; k < nparts; k += 64) s += part[(long)k * stride + i];
+    s = wave_sum(s);
+    if (lane == 0) dst[i] = s;
+}
+
 // kinds 4 / 5: the selective scan's dA / dD / d delta_bias from its per-(batch, tile) partials -- reduce_partials_w8 (+
 // reduce_slices_w8) of selective_scan_bwd_w8.hip and reduce_partials (+ reduce_slices) of selective_scan.hip, same order:
 // per slice of 512 rows eight strided row sums met in order, then the slices in order.  One workgroup per channel d; its
@@ -213,6 +266,10 @@ __global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__res
         job_conv1d(row, blk);
     else if (kind == 4 || kind == 5)
         job_scan(row, blk, &sums[0][0], tot, kind == 4);
+    else if (kind == 6)
+        job_conv_tiles(row, blk);
+    else if (kind == 7)
+        job_wave_rows(row, blk);
     else
         job_rows(row, blk, sums);
 }

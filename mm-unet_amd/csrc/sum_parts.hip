@@ -80,6 +80,10 @@ extern "C" int mmu_channel_sum(const float *g, int batch, int channels, int64_t 
     hipStream_t st = (hipStream_t)stream;
     channel_sum_rows_kernel<<<(unsigned)(batch * channels), 1024, 0, st>>>(g, workspace, hw);
     MMU_HIP_LAUNCH_CHECK("channel_sum(rows)");
+    if (batch <= 16) {   // (the deferred row sum adds up to 16 parts in the same order; more would change the rounding)
+        const long job[8] = {3, (long)workspace, (long)out, 0, channels, batch, channels, channels};
+        if (mmu_defer_job(job)) return 0;   // (deferred_reduce.hip: with the other parameter-gradient sums of the pass)
+    }
     channel_sum_batch_kernel<<<(channels + 255) / 256, 256, 0, st>>>(workspace, out, batch, channels);
     MMU_HIP_LAUNCH_CHECK("channel_sum");
     return 0;

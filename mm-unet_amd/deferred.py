@@ -78,7 +78,7 @@ class Scope:
         self._keep, self._rows, self._work = [], None, None
         self._captured = False
 
-    def reserve(self, max_work=65536):
+    def reserve(self, max_work=262144):
         self.table = torch.zeros((self.MAX_JOBS, 8), dtype=torch.int64, device=self.device)
         self.work = torch.zeros((max_work, 2), dtype=torch.int32, device=self.device)
 
@@ -118,6 +118,10 @@ class Scope:
                 nb = (r[5] + 15) // 16
             elif r[0] in (4, 5):
                 nb = r[6] & 0xffffffff          # a workgroup per channel
+            elif r[0] == 6:
+                nb = ((r[3] & 0xffffffff) * (r[3] >> 32) * (r[4] * r[4] if r[4] else 9) + 63) // 64
+            elif r[0] == 7:
+                nb = (r[4] + 15) // 16
             else:
                 nb = (r[7] + 63) // 64
             work += [[j, b] for b in range(nb)]

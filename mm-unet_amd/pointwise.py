@@ -6,7 +6,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, deferred
 
 ENABLED = True   # False: callers use F.conv2d (tests compare the two)
 
@@ -118,6 +118,7 @@ class Conv7x7SmallFn(torch.autograd.Function):
         p.dinput, p.dweight, p.workspace = _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(ws)
         with torch.cuda.device(x.device):
             _lib.check(L.mmu_conv7x7_2to1_bwd(p, _lib.stream_of(x)))
+        deferred.keep(ws)    # (inside a deferred.Scope the sum over the blocks' partials runs later)
         return dx, dw
 
 

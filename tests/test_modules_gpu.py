@@ -1670,6 +1670,42 @@ def test_deferred_scan_parameter_gradient_sums_are_bit_identical(case):
         os.environ.pop("MMU_SCAN_BWD_W8", None)
 
 
+def test_deferred_conv_weight_gradient_sums_are_bit_identical():
+    """deferred.Scope, the matrix-core convolutions: weight gradients of the 3 x 3 convolution, of the stride-2 convolution
+    and its transpose (tile partials, kind 6), their bias gradients (batch partials, kind 3) and the 7 x 7 two-channel
+    convolution's weight gradient (kind 7) equal the immediate sums bit for bit."""
+    from mm_unet_amd import conv3x3_mfma, conv_s2, deferred, pointwise
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=gen)     # noqa: E731
+    x3, w3, b3, g3 = rnd(2, 64, 24, 32), 0.1 * rnd(64, 64, 3, 3), rnd(64), rnd(2, 64, 24, 32)
+    xs, ws_, bs, gs = rnd(2, 64, 32, 32), 0.1 * rnd(128, 64, 3, 3), rnd(128), rnd(2, 128, 16, 16)
+    xt, wt, bt, gt = rnd(2, 64, 16, 16), 0.1 * rnd(64, 64, 4, 4), rnd(64), rnd(2, 64, 32, 32)
+    x7, w7, g7 = rnd(2, 2, 40, 48), 0.1 * rnd(1, 2, 7, 7), rnd(2, 1, 40, 48)
+    c7 = torch.nn.Conv2d(2, 1, 7, padding=3, bias=False).to(DEV)
+    assert pointwise.conv7_supported(c7, x7)
+
+    def work():
+        out = []
+        for fn, x, w, b, g in ((conv3x3_mfma.conv3x3_mfma, x3, w3, b3, g3), (conv_s2.conv_s2, xs, ws_, bs, gs),
+                               (conv_s2.conv_transpose_s2, xt, wt, bt, gt)):
+            w, b = w.clone().requires_grad_(), b.clone().requires_grad_()
+            fn(x, w, b).backward(g)
+            out += [w.grad, b.grad]
+        w = w7.clone().requires_grad_()
+        pointwise.Conv7x7SmallFn.apply(x7, w).backward(g7)
+        return out + [w.grad]
+
+    ref = [t.clone() for t in work()]
+    scope = deferred.Scope(DEV)
+    with scope:
+        got = work()
+        scope.launch()
+    assert scope.n_jobs == 7
+    torch.cuda.synchronize()
+    for i, (r, t) in enumerate(zip(ref, got)):
+        assert torch.equal(r, t), i
+
+
 def test_deferred_weight_gradient_sums_are_bit_identical():
     """deferred.Scope: the final ordered sums of gemm_nt (projection / DSC weight gradients), conv3x3_small's weight
     gradient and causal_conv1d_bwd recorded during a backward pass and run by ONE launch -- same partials, same
