@@ -21,31 +21,51 @@ bool g_active = false;
 std::vector<long> g_rows;   // 8 per job
 
 constexpr int ROW = 8;
+#define MMU_DEFER_REP 8   /* mirrored by deferred.py (REP) */
+
+// The kinds with 64 results per block of 1,024 threads (0, 1, 3, 6) take REP consecutive blocks per workgroup and load
+// for all of them before reducing any: at one block per workgroup the launch was 86,000 workgroups each waiting for one
+// or two dependent loads (440 us for 0.1 ms of traffic).  The order of the additions per result is unchanged.
+constexpr int REP = MMU_DEFER_REP;
 
 // kind 0: gemm_nt_splitk slab sums.  {0, part, c, -, n, slabs, rows << 32 | cols, transpose}
-__device__ void job_gemm_nt(const long *row, int blk, float (*sums)[64]) {
+__device__ void job_gemm_nt(const long *row, int blk, float (*sums)[16][64]) {
     const float *part = reinterpret_cast<const float *>(row[1]);
     float *c = reinterpret_cast<float *>(row[2]);
     const long n = row[4];
     const int slabs = (int)row[5], rows = (int)(row[6] >> 32), cols = (int)(row[6] & 0xffffffff);
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const long i = (long)blk * 64 + o;
-    float s = 0.f;
-    if (i < n) {
-        int k = g;
-        for (; k + 48 < slabs; k += 64) {
-            const float v0 = part[(long)k * n + i], v1 = part[(long)(k + 16) * n + i];
-            const float v2 = part[(long)(k + 32) * n + i], v3 = part[(long)(k + 48) * n + i];
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; k < slabs; k += 16) s += part[(long)k * n + i];
-    }
-    sums[g][o] = s;
-    __syncthreads();
-    if (g == 0 && i < n) {
-        float t = sums[0][o];
+    const long base = (long)blk * (64 * REP) + o;
+    float s[REP];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) t += sums[k][o];
+    for (int r = 0; r < REP; ++r) s[r] = 0.f;
+    int k = g;
+    for (; k + 48 < slabs; k += 64) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            const long i = base + r * 64;
+            if (i < n) {
+                const float v0 = part[(long)k * n + i], v1 = part[(long)(k + 16) * n + i];
+                const float v2 = part[(long)(k + 32) * n + i], v3 = part[(long)(k + 48) * n + i];
+                s[r] += v0; s[r] += v1; s[r] += v2; s[r] += v3;
+            }
+        }
+    }
+    for (; k < slabs; k += 16) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            const long i = base + r * 64;
+            if (i < n) s[r] += part[(long)k * n + i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) sums[r][g][o] = s[r];
+    __syncthreads();
+    const long i = base + g * 64;
+    if (g < REP && i < n) {
+        float t = sums[g][0][o];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += sums[g][q][o];
         if (row[7]) {
             const long r = i / cols, q = i - r * cols;
             c[q * rows + r] = t;
@@ -55,7 +75,7 @@ __device__ void job_gemm_nt(const long *row, int blk, float (*sums)[64]) {
     }
 }
 
-// kind 1: conv3x3_small weight / bias gradient.  {1, part, dW, dbias, Cin, nblk, CO, -}; 64 results per workgroup
+// kind 1: conv3x3_small weight / bias gradient.  {1, part, dW, dbias, Cin, nblk, CO, -}; 64 results per block
 __device__ void job_conv3x3s(const long *row, int blk) {
     const float *part = reinterpret_cast<const float *>(row[1]);
     float *dW = reinterpret_cast<float *>(row[2]);
@@ -63,22 +83,35 @@ __device__ void job_conv3x3s(const long *row, int blk) {
     const int Cin = (int)row[4], nblk = (int)row[5], CO = (int)row[6];
     const int NV = CO * 10, NV4 = (NV + 3) & ~3;
     const int sub = threadIdx.x & 15;
-    int idx = blk * 64 + (threadIdx.x >> 4);
-    const bool live = idx < Cin * NV4;
-    idx = live ? idx : Cin * NV4 - 1;
-    float s = 0.f;
-    for (int k = sub; k < nblk; k += 16) s += part[(long)k * Cin * NV4 + idx];
-    s += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, s);
-    s += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, s);
-    s += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, s);
-    s += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, s);   // lane 15 of each row of 16 holds the total
-    const int ci = idx / NV4, e = idx - ci * NV4;
-    if (!live || sub != 15 || e >= NV) return;
-    if (e < CO * 9) {
-        const int co = e / 9, t = e - co * 9;
-        dW[((long)co * Cin + ci) * 9 + t] = s;
-    } else if (ci == 0 && dbias != nullptr) {
-        dbias[e - CO * 9] = s;
+    int idx[REP];
+    bool live[REP];
+    float s[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        idx[r] = (blk * REP + r) * 64 + (threadIdx.x >> 4);
+        live[r] = idx[r] < Cin * NV4;
+        idx[r] = live[r] ? idx[r] : Cin * NV4 - 1;
+        s[r] = 0.f;
+    }
+    for (int k = sub; k < nblk; k += 16) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) s[r] += part[(long)k * Cin * NV4 + idx[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        float v = s[r];
+        v += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, v);
+        v += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, v);
+        v += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, v);
+        v += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, v);   // lane 15 of each row of 16 holds the total
+        const int ci = idx[r] / NV4, e = idx[r] - ci * NV4;
+        if (!live[r] || sub != 15 || e >= NV) continue;
+        if (e < CO * 9) {
+            const int co = e / 9, t = e - co * 9;
+            dW[((long)co * Cin + ci) * 9 + t] = v;
+        } else if (ci == 0 && dbias != nullptr) {
+            dbias[e - CO * 9] = v;
+        }
     }
 }
 
@@ -109,22 +142,29 @@ __device__ void job_conv1d(const long *row, int blk) {
 }
 
 // kind 3: rows of a partial buffer.  {3, part, dst, dst2, n1, nparts, stride, ntot}: dst[i < n1], dst2[i - n1] for the rest
-__device__ void job_rows(const long *row, int blk, float (*sums)[64]) {
+__device__ void job_rows(const long *row, int blk, float (*sums)[16][64]) {
     const float *part = reinterpret_cast<const float *>(row[1]);
     float *dst = reinterpret_cast<float *>(row[2]);
     float *dst2 = reinterpret_cast<float *>(row[3]);
     const int n1 = (int)row[4], nparts = (int)row[5], stride = (int)row[6], ntot = (int)row[7];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = blk * 64 + o;
-    float s = 0.f;
-    if (i < ntot)
-        for (int k = g; k < nparts; k += 16) s += part[(long)k * stride + i];
-    sums[g][o] = s;
-    __syncthreads();
-    if (g == 0 && i < ntot) {
-        float t = sums[0][o];
+    const int base = blk * (64 * REP) + o;
+    float s[REP];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) t += sums[k][o];
+    for (int r = 0; r < REP; ++r) s[r] = 0.f;
+    for (int k = g; k < nparts; k += 16) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r)
+            if (base + r * 64 < ntot) s[r] += part[(long)k * stride + base + r * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) sums[r][g][o] = s[r];
+    __syncthreads();
+    const int i = base + g * 64;
+    if (g < REP && i < ntot) {
+        float t = sums[g][0][o];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += sums[g][q][o];
         if (i < n1)
             dst[i] = t;
         else if (dst2 != nullptr)
@@ -144,30 +184,45 @@ __device__ void job_conv_tiles(const long *row, int blk) {
     const int TCO = (int)(row[7] & 0xffffffff), TCI = (int)(row[7] >> 32);
     const int sub = threadIdx.x & 15;
     const int KK = K ? K * K : 9, S = K ? 4 : 9;
-    const long n = (long)Cout * Cin * KK;
-    long i = (long)blk * 64 + (threadIdx.x >> 4);
-    const bool live = i < n;
-    i = live ? i : n - 1;
-    const long r = i / KK;
-    const int t = (int)(i - r * KK);
-    const int c = (int)(r % Cin), co = (int)(r / Cin);
-    int v = c, sidx = t;
-    if (K) {   // stride 2: kh = 2a + 1 - py  <=>  py = (kh + 1) & 1, a = (kh - 1 + py) / 2 (conv_s2_mfma.hip)
-        const int kw = t % K, kh = t / K;
-        const int py = (kh + 1) & 1, a = (kh - 1 + py) >> 1, pxx = (kw + 1) & 1, b = (kw - 1 + pxx) >> 1;
-        v = (py * 2 + pxx) * Cin + c;
-        sidx = a * 2 + b;
+    const unsigned n = (unsigned)Cout * Cin * KK;        // (host: below 2^31; 32-bit divisions throughout -- the 64-bit ones
+    const long tile = (long)TCO * TCI * S;               //  of the kernels this replaces were most of their 28 us)
+    const float *src[REP];
+    int out[REP];
+    float acc[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        unsigned i = ((unsigned)blk * REP + r) * 64 + (threadIdx.x >> 4);
+        out[r] = i < n ? (int)i : -1;
+        i = i < n ? i : n - 1;
+        const unsigned q = i / (unsigned)KK;
+        const int t = (int)(i - q * KK);
+        const unsigned co = q / (unsigned)Cin;
+        const int c = (int)(q - co * Cin);
+        int v = c, sidx = t;
+        if (K) {   // stride 2: kh = 2a + 1 - py  <=>  py = (kh + 1) & 1, a = (kh - 1 + py) / 2 (conv_s2_mfma.hip)
+            const int kh = t / K, kw = t - kh * K;
+            const int py = (kh + 1) & 1, a = (kh - 1 + py) >> 1, pxx = (kw + 1) & 1, b = (kw - 1 + pxx) >> 1;
+            v = (py * 2 + pxx) * Cin + c;
+            sidx = a * 2 + b;
+        }
+        const unsigned cot = co / (unsigned)TCO, vt = (unsigned)v / (unsigned)TCI;
+        const int cc = (int)(cot * n_cic + vt);
+        src[r] = ws + ((long)cc * wg_per_cc) * tile + ((int)(co - cot * TCO) * TCI + (int)(v - vt * TCI)) * S + sidx;
+        acc[r] = 0.f;
     }
-    const int cc = (co / TCO) * n_cic + v / TCI;
-    const long tile = (long)TCO * TCI * S;
-    const float *src = ws + ((long)cc * wg_per_cc) * tile + ((co % TCO) * TCI + v % TCI) * S + sidx;
-    float a = 0.f;
-    for (int k = sub; k < wg_per_cc; k += 16) a += src[(long)k * tile];
-    a += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, a);
-    a += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, a);
-    a += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, a);
-    a += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, a);
-    if (live && sub == 15) dW[i] = a;
+    for (int k = sub; k < wg_per_cc; k += 16) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) acc[r] += src[r][(long)k * tile];
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        float a = acc[r];
+        a += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, a);
+        a += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, a);
+        a += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, a);
+        a += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, a);
+        if (out[r] >= 0 && sub == 15) dW[out[r]] = a;
+    }
 }
 
 // kind 7: a wave per output over strided partial rows (conv7_wsum_kernel of conv7x7_small.hip).
@@ -253,7 +308,7 @@ __device__ void job_scan(const long *row, int d, float *red /* 1024 */, float *t
 }
 
 __global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__restrict__ table, const int *__restrict__ work) {
-    __shared__ float sums[16][64];
+    __shared__ float sums[REP][16][64];
     __shared__ float tot[32];
     const int job = work[2 * blockIdx.x], blk = work[2 * blockIdx.x + 1];
     const long *row = table + (long)job * ROW;
@@ -264,14 +319,14 @@ __global__ __launch_bounds__(1024) void deferred_reduce_kernel(const long *__res
         job_conv3x3s(row, blk);
     else if (kind == 2)
         job_conv1d(row, blk);
+    else if (kind == 3)
+        job_rows(row, blk, sums);
     else if (kind == 4 || kind == 5)
-        job_scan(row, blk, &sums[0][0], tot, kind == 4);
+        job_scan(row, blk, &sums[0][0][0], tot, kind == 4);
     else if (kind == 6)
         job_conv_tiles(row, blk);
     else if (kind == 7)
         job_wave_rows(row, blk);
-    else
-        job_rows(row, blk, sums);
 }
 
 }  // namespace

@@ -70,6 +70,7 @@ class paused:
 
 class Scope:
     MAX_JOBS = 1024
+    REP = 8
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -124,6 +125,8 @@ class Scope:
                 nb = (r[4] + 15) // 16
             else:
                 nb = (r[7] + 63) // 64
+            if r[0] in (0, 1, 3, 6):            # REP blocks of 64 results per workgroup (MMU_DEFER_REP)
+                nb = (nb + self.REP - 1) // self.REP
             work += [[j, b] for b in range(nb)]
         if len(work) > self.work.shape[0]:
             raise RuntimeError(f"deferred.Scope: {len(work)} workgroups, work list holds {self.work.shape[0]}")
