@@ -219,7 +219,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 4   # = MMU_ABI_VERSION of include/mmunet_amd.h
+ABI_VERSION = 5   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():
