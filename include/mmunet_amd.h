@@ -612,6 +612,13 @@ int mmu_sum_parts(const mmu_sum_parts_params *p, void *stream);
  * workspace: batch * channels floats.  Ordered sums (reproducible). */
 int mmu_channel_sum(const float *g, int batch, int channels, int64_t hw, float *workspace, float *out, void *stream);
 
+/* Input gradient of `nn.Conv2d(I, O, kernel_size=1, stride=2, bias=False)` (the shortcut of the down-sampling residual
+ * blocks, src/UM_Net/MMUNet.py:448) from the gradient `src` [planes, ceil(height/2), ceil(width/2)] of its gathered
+ * input: dst [planes, height, width] = src at the even pixels, 0 elsewhere, + addend (optional, [planes, height, width]).
+ * addend == dst: in place, only the even pixels are touched. */
+int mmu_scatter_stride2(const float *src, float *dst, const float *addend, int64_t planes, int height, int width,
+                        void *stream);
+
 /* ---- nn.Conv2d(C, 1, kernel_size=1): one output channel (RCG's gate, the side outputs) --------------------------- */
 /* src/UM_Net/MMUNet.py:346,386: out[b, p] = bias + sum_c weight[c] * input[b, c, p] over hw pixels; float32, contiguous
  * NCHW, channels in {16, 64}, hw % 4 == 0.  bwd: dinput[b, c, p] = dout[b, p] weight[c] (optional), dweight [C] and

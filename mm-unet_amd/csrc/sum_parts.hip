@@ -71,7 +71,52 @@ __global__ __launch_bounds__(256) void channel_sum_batch_kernel(const float *__r
     out[c] = t;
 }
 
+// Input gradient of a stride-2 1 x 1 convolution from the gradient of its gathered input: dst[p][2y][2x] = src[p][y][x], 0
+// elsewhere (+ addend).  In place on a gradient another consumer of the input left (addend == dst) only the even pixels are
+// touched: a quarter of the tensor instead of a zero fill, a strided copy and an add over all of it.
+__global__ __launch_bounds__(256) void scatter_s2_inplace_kernel(const float *__restrict__ src, float *dst, int h, int w, int H,
+                                                                 int W, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % w);
+    const long r = i / w;
+    const int y = (int)(r % h);
+    const long p = r / h;
+    dst[(p * H + 2 * y) * W + 2 * x] += src[i];
+}
+
+__global__ __launch_bounds__(256) void scatter_s2_full_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                              const float *__restrict__ addend, int h, int w, int H, int W,
+                                                              long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one output element
+    if (i >= n) return;
+    const int X = (int)(i % W);
+    const long r = i / W;
+    const int Y = (int)(r % H);
+    const long p = r / H;
+    float v = ((X | Y) & 1) ? 0.f : src[(p * h + (Y >> 1)) * w + (X >> 1)];
+    if (addend) v += addend[i];
+    dst[i] = v;
+}
+
 }  // namespace
+
+extern "C" int mmu_scatter_stride2(const float *src, float *dst, const float *addend, int64_t planes, int height, int width,
+                                   void *stream) {
+    MMU_CHECK(src && dst && planes > 0 && height > 0 && width > 0, "scatter_stride2: src, dst and positive sizes required");
+    const int h = (height + 1) / 2, w = (width + 1) / 2;
+    hipStream_t st = (hipStream_t)stream;
+    if (addend == dst) {
+        const long n = planes * h * w;
+        scatter_s2_inplace_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, dst, h, w, height, width, n);
+    } else {
+        const long n = planes * height * width;
+        MMU_CHECK(n < (1L << 39), "scatter_stride2: tensor too large");
+        scatter_s2_full_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(src, dst, addend, h, w, height, width, n);
+    }
+    MMU_HIP_LAUNCH_CHECK("scatter_stride2");
+    return 0;
+}
 
 extern "C" int mmu_channel_sum(const float *g, int batch, int channels, int64_t hw, float *workspace, float *out, void *stream) {
     MMU_CHECK(g && workspace && out && batch > 0 && channels > 0 && hw > 0, "channel_sum: g, workspace, out and positive sizes required");

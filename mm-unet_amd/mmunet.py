@@ -213,11 +213,13 @@ class MMConv(nn.Module):
         return self.dsc_conv_y(morph_sample(input, y_rows, slot=slot)), None
 
 
-def run_fused(seq, x, residual=None):
+def run_fused(seq, x, residual=None, in_slot=None):
     """``seq(x)`` (``relu(seq(x) + residual)`` when a residual is given: the tail of a ResidualBlock) for an
     nn.Sequential, with every ``MMConv -> BatchNorm2d [-> ReLU]`` run as the MMConv up
     to its final GroupNorm followed by ONE fused GroupNorm + BatchNorm + ReLU (norm_fused): 2 passes over the
-    activation instead of 8 forward, 2 instead of 13 backward.  Module structure / state_dict are untouched."""
+    activation instead of 8 forward, 2 instead of 13 backward.  Module structure / state_dict are untouched.
+    ``in_slot``: a conv3x3_small.SharedGrad of all consumers of ``x``, for a sequence that opens with the stride-2 1 x 1
+    shortcut convolution."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -256,7 +258,7 @@ def run_fused(seq, x, residual=None):
             else:
                 x = conv3x3_mfma.conv3x3_mfma(x, m.weight, m.bias)
         elif conv1x1_stride2_supported(m, x):     # shortcut of a down-sampling residual block
-            x = conv1x1_stride2(x, m.weight)
+            x = conv1x1_stride2(x, m.weight, in_slot if i == 0 else None)
         elif conv_s2.module_supported(m, x):      # 3 x 3 / stride 2 opening of a down-sampling residual block
             x = conv_s2.module_call(m, x)
         else:
@@ -411,7 +413,13 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         # relu(block1(x) + shortcut): the add and the ReLU ride along in block1's last fused normalisation
-        return run_fused(self.block1, x, residual=run_fused(self.block2, x) if self.downsample else x)
+        if not self.downsample:
+            return run_fused(self.block1, x, residual=x)
+        # x feeds the 3 x 3 stride-2 convolution and the 1 x 1 stride-2 shortcut: the shortcut's backward adds its even
+        # pixels to the gradient the other one left (conv3x3_small.SharedGrad) instead of autograd adding two tensors
+        slot = conv3x3_small.SharedGrad() if (torch.is_grad_enabled() and x.requires_grad) else None
+        shortcut = run_fused(self.block2, x, in_slot=slot)
+        return run_fused(self.block1, conv3x3_small.shared_input(x, slot), residual=shortcut)
 
 
 class MM_Net(nn.Module):
@@ -459,7 +467,8 @@ class MM_Net(nn.Module):
             blocks = [m for m in self.modules() if isinstance(m, MMConv) and m.morph == 0]
             rcgs = [m.mamba for m in self.modules() if isinstance(m, RCG)]   # their projections take the same GEMM
             self._dsc_prep = [mfma_gemm.prepared_weights(
-                lambda: [m.dsc_conv_x.weight for m in blocks] + [w for m in rcgs for w in (m.in_proj.weight, m.out_proj.weight)])]
+                lambda: [m.dsc_conv_x.weight for m in blocks] + [w for m in rcgs for w in (m.in_proj.weight, m.out_proj.weight)]
+                + [m.block2[0].weight for m in self.modules() if isinstance(m, ResidualBlock) and m.downsample])]
         # A = -exp(A_log) of all 50 Mamba blocks in two launches; the 56 BatchNorm batch counters in one; the bf16 hi/lo
         # images of the 47 DSC weights (both orientations) in one
         with self._a_batch[0], norm_fused.batched_counters(), self._dsc_prep[0]:

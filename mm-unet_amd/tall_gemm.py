@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import mfma_gemm
+from . import _lib, mfma_gemm
 
 _SLAB = 2048
 _NT_MIN = int(os.environ.get("MMUNET_GEMM_NT_MIN_TOKENS", str(4 * _SLAB)))   # fewer tokens: one library GEMM
@@ -270,7 +270,7 @@ class _Conv1x1Stride2Fn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, slot=None):
         B, I, H, W = x.shape
         O = weight.shape[0]
         xs = x[:, :, ::2, ::2].contiguous()
@@ -279,12 +279,18 @@ class _Conv1x1Stride2Fn(torch.autograd.Function):
         W2 = weight.view(O, I)
         out = torch.empty((B, O, T), device=x.device, dtype=torch.float32)
         xs3 = xs.view(B, I, T)
+        ctx.prep_t = None
         if mfma_gemm.supported(O, I, B * T, W2, xs3, out) and T % 4 == 0:
             mfma_gemm.gemm_tokens(W2, xs3, out, O, I, T, B, T, I * T, T, O * T)
+            ctx.prep_t = mfma_gemm.prepared_for(W2, I, O, True)     # (the W^T image, for the backward pass)
         else:
             torch.matmul(W2, xs3, out=out)
         ctx.save_for_backward(W2, xs3)
         ctx.in_hw = (H, W)
+        # slot: a conv3x3_small.SharedGrad of all consumers of x -- their input gradients leave as one
+        ctx.slot = slot if (slot is not None and ctx.needs_input_grad[0]) else None
+        if ctx.slot is not None:
+            ctx.slot.join()
         return out.view(B, O, Ho, Wo)
 
     @staticmethod
@@ -297,20 +303,40 @@ class _Conv1x1Stride2Fn(torch.autograd.Function):
         G3 = G.float().contiguous().view(B, O, T)
         dx = dW = None
         if ctx.needs_input_grad[0]:
-            dxs = torch.matmul(W2.t(), G3)                                     # (B, I, T)
-            dx = torch.zeros((B, I, H, W), device=G.device, dtype=torch.float32)
-            dx[:, :, ::2, ::2] = dxs.view(B, I, (H + 1) // 2, (W + 1) // 2)
+            # d xs = W^T G per batch item (strided-batch matrix-core GEMM: torch.matmul folds the batch into the token
+            # axis behind two transposing copies), then the even pixels of d x -- in place on the gradient another
+            # consumer of x left, or a zero-filled tensor
+            dxs = torch.empty((B, I, T), device=G.device, dtype=torch.float32)
+            # (the matrix-core kernel also below its usual break-even of 192 tiles: the library's strided-batch kernel
+            #  for 64 x 128 against 8 x 4,096 tokens takes 121 us, 64 workgroups of this one ~10)
+            tiles = (I // 64) * ((B * T + 511) // 512)
+            if (mfma_gemm.ENABLED and I % 64 == 0 and O % 16 == 0 and T % 4 == 0 and tiles >= 48 and W2.is_contiguous()
+                    and not torch.is_autocast_enabled() and G3.data_ptr() % 16 == 0 and W2.data_ptr() % 16 == 0):
+                mfma_gemm.gemm_tokens(W2, G3, dxs, I, O, T, B, T, O * T, T, I * T, transposed_weight=True,
+                                      prepared=ctx.prep_t)
+            else:
+                torch.matmul(W2.t(), G3, out=dxs)
+            parked = ctx.slot.take() if ctx.slot is not None else None
+            if parked is not None and (tuple(parked.shape) != (B, I, H, W) or parked.dtype != torch.float32
+                                       or not parked.is_contiguous()):
+                raise RuntimeError("conv1x1_stride2: parked input gradient does not match the input")
+            dx = parked if parked is not None else torch.empty((B, I, H, W), device=G.device, dtype=torch.float32)
+            with torch.cuda.device(G.device):
+                _lib.check(_lib.lib().mmu_scatter_stride2(dxs.data_ptr(), dx.data_ptr(), _lib.ptr(parked), B * I, H, W,
+                                                          _lib.stream_of(G)))
+            if ctx.slot is not None:
+                dx = ctx.slot.give(dx)
         if ctx.needs_input_grad[1]:
             if T % 32 == 0 and B * T >= _NT_MIN and mfma_gemm.nt_supported(G3, xs3, T):
                 dW = mfma_gemm.gemm_nt(G3, xs3, O, I, B, T, T, O * T, T, I * T)
             else:
                 dW = torch.einsum("bot,bit->oi", G3, xs3)
             dW = dW.view(O, I, 1, 1)
-        return dx, dW
+        return dx, dW, None
 
 
-def conv1x1_stride2(x, weight):
-    return _Conv1x1Stride2Fn.apply(x, weight)
+def conv1x1_stride2(x, weight, slot=None):
+    return _Conv1x1Stride2Fn.apply(x, weight, slot)
 
 
 STRIDE2_ENABLED = True   # False: the shortcut convolutions stay nn.Conv2d calls (fused_paths.plain_aten)

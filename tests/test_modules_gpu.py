@@ -1360,10 +1360,12 @@ def test_shared_input_gradient_hand_over_equals_autograd_sum(shape):
     autograd to add them.  Same total as the plain route, whichever order autograd runs the consumers in."""
     from mm_unet_amd import conv3x3_small, maxpool, pointwise
     from mm_unet_amd.resize import bilinear_resize
+    from mm_unet_amd.tall_gemm import conv1x1_stride2
     B, C, H, W = shape
     gen = torch.Generator(device=DEV).manual_seed(31)
     x = torch.randn(*shape, device=DEV, generator=gen)
     w = 0.2 * torch.randn(1, C, 3, 3, device=DEV, generator=gen)
+    w2 = 0.2 * torch.randn(64, C, 1, 1, device=DEV, generator=gen)
     gate = torch.rand(B, C, 1, 1, device=DEV, generator=gen)
 
     def run(shared, order):
@@ -1378,6 +1380,7 @@ def test_shared_input_gradient_hand_over_equals_autograd_sum(shape):
             "join": lambda: conv3x3_small.shared_input(xi, slot) * 0.5,
             "stats": lambda: sum(pointwise.pixel_mean_max(xi, slot)),
             "gate": lambda: pointwise.gated_mul(xi, gate, slot),
+            "s2": lambda: conv1x1_stride2(xi, w2, slot),
         }
         gg = torch.Generator(device=DEV).manual_seed(5)
         total = 0
@@ -1390,10 +1393,10 @@ def test_shared_input_gradient_hand_over_equals_autograd_sum(shape):
             assert slot.pending == 0 and slot.grad is None
         return xi.grad
 
-    names = ["r2", "r4", "up", "conv", "pool", "join", "stats", "gate"]
+    names = ["r2", "r4", "up", "conv", "pool", "join", "stats", "gate", "s2"]
     ref = run(False, names)
     scale = float(ref.abs().max())
-    for order in (names, names[::-1], ["pool", "join"], ["conv", "r2", "r4", "up"]):
+    for order in (names, names[::-1], ["pool", "join"], ["conv", "r2", "r4", "up"], ["s2", "join"], ["join", "s2"]):
         want = ref if len(order) == len(names) else run(False, order)
         got = run(True, order)
         close(got, want, 1e-5, 1e-5 * scale, f"shared gradient, order {order}")
