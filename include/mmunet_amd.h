@@ -612,6 +612,25 @@ int mmu_sum_parts(const mmu_sum_parts_params *p, void *stream);
  * workspace: batch * channels floats.  Ordered sums (reproducible). */
 int mmu_channel_sum(const float *g, int batch, int channels, int64_t hw, float *workspace, float *out, void *stream);
 
+/* ---- the training loss: Dice + BCE on sigmoid(logits) (top-level loss.py:5-28) ------------------------------------ */
+/* loss = 1 - (2 sum(p t) + smooth) / (sum(p + t) + smooth) + mean BCE(p, t), p = sigmoid(logits), the sums over the whole
+ * batch, BCE's logs clamped at -100 as nn.BCELoss does.  fwd: two launches (per-workgroup partial sums, their ordered
+ * sum); bwd: one.  float32, contiguous, n elements; no atomics. */
+typedef struct {
+    int64_t n;
+    float smooth;
+    const float *logits;   /* [n] */
+    const float *targets;  /* [n] */
+    float *workspace;      /* fwd: mmu_dice_bce_workspace_floats(n) floats */
+    float *out;            /* fwd: written -- out[0] = loss, out[1] = sum(p t), out[2] = sum(p + t); bwd: read */
+    const float *dloss;    /* bwd: d loss (one float, on the device) */
+    float *dlogits;        /* bwd: [n] */
+} mmu_dice_bce_params;
+
+size_t mmu_dice_bce_workspace_floats(int64_t n);
+int mmu_dice_bce_fwd(const mmu_dice_bce_params *p, void *stream);
+int mmu_dice_bce_bwd(const mmu_dice_bce_params *p, void *stream);
+
 /* Input gradient of `nn.Conv2d(I, O, kernel_size=1, stride=2, bias=False)` (the shortcut of the down-sampling residual
  * blocks, src/UM_Net/MMUNet.py:448) from the gradient `src` [planes, ceil(height/2), ceil(width/2)] of its gathered
  * input: dst [planes, height, width] = src at the even pixels, 0 elsewhere, + addend (optional, [planes, height, width]).

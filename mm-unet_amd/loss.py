@@ -1,7 +1,48 @@
 """Dice + BCE loss of the reference's top-level ``loss.py`` (:5-28)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+FUSED = os.environ.get("MMUNET_FUSED_LOSS", "1") != "0"   # False: the ATen ops below (fused_paths.plain_aten, tests compare)
+
+
+class _DiceBceFn(torch.autograd.Function):
+    """The whole loss in two launches forward, one backward (csrc/dice_bce.hip); as ATen ops 22 + 14."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, smooth):
+        from . import _lib
+        _lib.require_gpu(logits, targets)
+        if logits.dtype != torch.float32 or targets.dtype != torch.float32 or logits.shape != targets.shape:
+            raise RuntimeError("dice_bce: float32 logits and targets of one shape required")
+        x, t = logits.contiguous(), targets.contiguous()
+        n = x.numel()
+        L = _lib.lib()
+        ws = torch.empty(L.mmu_dice_bce_workspace_floats(n), device=x.device, dtype=torch.float32)
+        out = torch.empty(3, device=x.device, dtype=torch.float32)       # loss, sum(p t), sum(p + t)
+        p = _lib.DiceBceParams()
+        p.n, p.smooth = n, float(smooth)
+        p.logits, p.targets, p.workspace, p.out = x.data_ptr(), t.data_ptr(), ws.data_ptr(), out.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(L.mmu_dice_bce_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, t, out)
+        ctx.smooth = float(smooth)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x, t, out = ctx.saved_tensors
+        g = g.float().contiguous()
+        dx = torch.empty_like(x)
+        p = _lib.DiceBceParams()
+        p.n, p.smooth = x.numel(), ctx.smooth
+        p.logits, p.targets, p.out, p.dloss, p.dlogits = x.data_ptr(), t.data_ptr(), out.data_ptr(), g.data_ptr(), dx.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_dice_bce_bwd(p, _lib.stream_of(x)))
+        return dx, None, None
 
 
 class DICE_BCE_Loss(nn.Module):
@@ -13,6 +54,9 @@ class DICE_BCE_Loss(nn.Module):
         self.smooth = smooth
 
     def forward(self, logits, targets):
+        if (FUSED and logits.is_cuda and logits.dtype == torch.float32 and targets.dtype == torch.float32
+                and logits.shape == targets.shape and not targets.requires_grad and not torch.is_autocast_enabled()):
+            return _DiceBceFn.apply(logits, targets, self.smooth)
         p = torch.sigmoid(logits)
         intersection = 2 * (p * targets).sum() + self.smooth
         union = (p + targets).sum() + self.smooth

@@ -64,7 +64,8 @@ def test_param_structs_match_header_field_order():
                         ("mmu_conv_s2_params", _lib.ConvS2Params),
                         ("mmu_morph_mix_params", _lib.MorphMixParams),
                         ("mmu_adamw_params", _lib.AdamWParams),
-                        ("mmu_cbam_gate_params", _lib.CbamGateParams)):
+                        ("mmu_cbam_gate_params", _lib.CbamGateParams),
+                        ("mmu_dice_bce_params", _lib.DiceBceParams)):
         # (mmu_cbam_stats_params declares two pointers per line: not parsed by this check)
         assert fields(struct) == [f[0] for f in cls._fields_], struct
 

@@ -1326,6 +1326,48 @@ def test_max_pool3s2_vs_module(shape):
     assert torch.equal(torch.nan_to_num(maxpool.pool_module(m, xn), nan=12345.0), torch.nan_to_num(m(xn), nan=12345.0))
 
 
+@pytest.mark.parametrize("shape", [(8, 1, 512, 512), (2, 1, 33, 17), (1, 3, 5, 7)])
+def test_fused_dice_bce_loss_vs_aten_and_fixture(shape):
+    """loss.DICE_BCE_Loss on the GPU (csrc/dice_bce.hip: two launches forward, one backward) against the same formula in
+    ATen ops evaluated in float64 (top-level loss.py:5-28: batch-wide Dice sums, BCELoss's -100 clamp), value and
+    gradient, saturated logits included; bit-reproducible; and against the reference's own fixture."""
+    from mm_unet_amd import loss as loss_mod
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    x = 3 * torch.randn(*shape, device=DEV, generator=gen)
+    x.view(-1)[::11] = 120.0            # p == 1 in float32: log(1 - p) clamps at -100
+    x.view(-1)[5::13] = -120.0          # p == 0
+    t = (torch.rand(*shape, device=DEV, generator=gen) > 0.6).float()
+    fn = loss_mod.DICE_BCE_Loss()
+    outs = []
+    for _ in range(2):
+        xi = x.clone().requires_grad_()
+        val = fn(xi, t)
+        (2.5 * val).backward()
+        outs.append((val.detach().clone(), xi.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    p = torch.sigmoid(x.cpu()).double()         # the float32 probabilities (0 and 1 where the logits saturate), summed in float64
+    t64 = t.double().cpu()
+    dice = 1 - (2 * (p * t64).sum() + 1) / ((p + t64).sum() + 1)
+    bce = -(t64 * torch.log(p).clamp_min(-100) + (1 - t64) * torch.log(1 - p).clamp_min(-100)).mean()
+    ref = dice + bce
+    close(outs[0][0], ref.float(), 2e-6, 1e-6, "loss")
+    saved, loss_mod.FUSED = loss_mod.FUSED, False
+    try:
+        xa = x.clone().requires_grad_()
+        va = fn(xa, t)
+        (2.5 * va).backward()
+    finally:
+        loss_mod.FUSED = saved
+    close(outs[0][0], va, 2e-6, 1e-6, "loss vs the ATen route")
+    close(outs[0][1], xa.grad, 1e-5, 1e-9, "d logits vs the ATen route")
+    g = golden("loss_dice_bce")
+    lg = torch.from_numpy(g["logits"]).to(DEV).requires_grad_()
+    lv = fn(lg, torch.from_numpy(g["targets"]).to(DEV))
+    lv.backward()
+    close(lv, g["loss"], 1e-6, 1e-6, "fixture loss")
+    close(lg.grad, g["dlogits"], 1e-5, 1e-9, "fixture d logits")
+
+
 @pytest.mark.parametrize("case", [(8, 64, 4), (3, 32, 2), (1, 16, 1), (5, 48, 7)])
 def test_cbam_gate_vs_modules(case):
     """pointwise.cbam_gate == sigmoid(mlp(avg) + mlp(max)) with CBAM's shared bias-free 1 x 1 MLP (MMUNet.py:319-329):
