@@ -549,7 +549,17 @@ typedef struct {
      * instead of being materialised and added by two more passes over the map */
     const float *stats_dout;     /* [batch, 2, hw] */
     const int32_t *stats_argmax; /* [batch, hw] */
+    /* MMU_GATE_SPATIAL, optional: a second factor and an addend of the input's shape -- out = input * input2 * gate +
+     * addend (RCG's `x0 * gate * x2 + f`, MMUNet.py:415) in one pass; bwd: dinput = dout gate input2,
+     * dinput2 = dout gate input, dgate = sum over the channels of dout input input2 (d addend = dout) */
+    const float *input2;
+    const float *addend;         /* fwd */
+    float *dinput2;              /* bwd, optional */
+    float *workspace;            /* bwd, MMU_GATE_SPATIAL with dgate: mmu_gated_mul_bwd_workspace_floats() floats (the
+                                  * channel range is cut into chunks whose sums meet in a fixed order) */
 } mmu_gated_mul_params;
+
+size_t mmu_gated_mul_bwd_workspace_floats(int batch, int channels, int64_t hw, int mode);
 
 int mmu_gated_mul_fwd(const mmu_gated_mul_params *p, void *stream);
 int mmu_gated_mul_bwd(const mmu_gated_mul_params *p, void *stream);

@@ -147,7 +147,7 @@ class DiceBceParams(ctypes.Structure):
 
 class GatedMulParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("channels", _i32), ("mode", _i32), ("hw", _i64)] + \
-               [(n, _vp) for n in ("input", "gate", "out", "dout", "dinput", "dgate", "stats_dout", "stats_argmax")]
+               [(n, _vp) for n in ("input", "gate", "out", "dout", "dinput", "dgate", "stats_dout", "stats_argmax", "input2", "addend", "dinput2", "workspace")]
 
 
 class Conv7x7Params(ctypes.Structure):
@@ -213,7 +213,7 @@ EXPORTS = (
     "mmu_conv3x3_small_wgrad_workspace_floats",
     "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
-    "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_adamw_multi", "mmu_coords_bwd_workspace_floats", "mmu_channel_sum", "mmu_scatter_stride2", "mmu_dice_bce_fwd", "mmu_dice_bce_bwd", "mmu_dice_bce_workspace_floats", "mmu_cbam_gate_fwd", "mmu_cbam_gate_bwd", "mmu_maxpool3s2_fwd", "mmu_maxpool3s2_bwd_codes", "mmu_deferred_begin", "mmu_deferred_pause", "mmu_deferred_end", "mmu_deferred_jobs", "mmu_deferred_launch", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
+    "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_adamw_multi", "mmu_coords_bwd_workspace_floats", "mmu_channel_sum", "mmu_scatter_stride2", "mmu_dice_bce_fwd", "mmu_dice_bce_bwd", "mmu_dice_bce_workspace_floats", "mmu_gated_mul_bwd_workspace_floats", "mmu_cbam_gate_fwd", "mmu_cbam_gate_bwd", "mmu_maxpool3s2_fwd", "mmu_maxpool3s2_bwd_codes", "mmu_deferred_begin", "mmu_deferred_pause", "mmu_deferred_end", "mmu_deferred_jobs", "mmu_deferred_launch", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_mamba_small_supported", "mmu_mamba_small_parts", "mmu_mamba_small_bwd_workspace_floats",
@@ -282,6 +282,8 @@ def lib():
     L.mmu_conv3x3_small_wgrad_workspace_floats.argtypes = [ctypes.c_int] * 5
     L.mmu_channel_sum.restype = ctypes.c_int
     L.mmu_channel_sum.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]
+    L.mmu_gated_mul_bwd_workspace_floats.restype = ctypes.c_size_t
+    L.mmu_gated_mul_bwd_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int]
     L.mmu_dice_bce_workspace_floats.restype = ctypes.c_size_t
     L.mmu_dice_bce_workspace_floats.argtypes = [ctypes.c_int64]
     L.mmu_scatter_stride2.restype = ctypes.c_int

@@ -67,40 +67,81 @@ __global__ __launch_bounds__(1024) void gm_channel_bwd_kernel(const float *__res
     if (threadIdx.x == 0 && dgate) dgate[row] = s;
 }
 
-// gate[b][p]; thread = 4 pixels of one batch item
+// gate[b][p].  x2 (optional): a second factor of the same shape (RCG's x0 * x2 * gate, MMUNet.py:415); addend (optional):
+// added to the product (RCG's "+ f").  Forward: plain elementwise, one float4 per thread.  (Round 2's form -- a thread
+// walking all channels of its four pixels -- ran 64 dependent iterations on 128 workgroups at 128 x 128: 45 us for what
+// the elementwise kernels it replaced did in 14.)
+__device__ __forceinline__ float4 gm_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
 __global__ __launch_bounds__(256) void gm_spatial_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gate,
-                                                             float *__restrict__ out, int C, long HW4) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= HW4) return;
-    const int b = blockIdx.y;
-    const float4 gv = reinterpret_cast<const float4 *>(gate)[b * HW4 + q];
-    const float4 *xp = reinterpret_cast<const float4 *>(x) + (long)b * C * HW4 + q;
-    float4 *op = reinterpret_cast<float4 *>(out) + (long)b * C * HW4 + q;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) {
-        const float4 v = xp[c * HW4];
-        op[c * HW4] = make_float4(v.x * gv.x, v.y * gv.y, v.z * gv.z, v.w * gv.w);
+                                                             float *__restrict__ out, long CHW4, long HW4, long total4,
+                                                             const float *__restrict__ x2, const float *__restrict__ addend) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const long b = i / CHW4, p = (i - b * CHW4) % HW4;
+    float4 v = reinterpret_cast<const float4 *>(x)[i];
+    if (x2) v = gm_mul(v, reinterpret_cast<const float4 *>(x2)[i]);
+    v = gm_mul(v, reinterpret_cast<const float4 *>(gate)[b * HW4 + p]);
+    if (addend) {
+        const float4 a = reinterpret_cast<const float4 *>(addend)[i];
+        v = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
     }
+    reinterpret_cast<float4 *>(out)[i] = v;
 }
+
+// dx = g gate [x2];  dx2 = g gate x;  dgate = sum over the channels of g x [x2].  Thread = 4 pixels of one batch item and
+// a CHUNK of GM_CCH channels (grid.z): the chunk sums go to part[chunk][b][p] and gm_chunk_sum_kernel adds them in order
+// (one chunk: straight to dgate).
+constexpr int GM_CCH = 8;
 
 __global__ __launch_bounds__(256) void gm_spatial_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gate,
                                                              const float *__restrict__ g, float *__restrict__ dx,
-                                                             float *__restrict__ dgate, int C, long HW4) {
+                                                             float *__restrict__ dgate, int C, long HW4,
+                                                             const float *__restrict__ x2, float *__restrict__ dx2,
+                                                             float *__restrict__ part) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= HW4) return;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, c0 = blockIdx.z * GM_CCH, c1 = min(c0 + GM_CCH, C);
     const float4 gv = reinterpret_cast<const float4 *>(gate)[b * HW4 + q];
-    const float4 *xp = reinterpret_cast<const float4 *>(x) + (long)b * C * HW4 + q;
-    const float4 *gp = reinterpret_cast<const float4 *>(g) + (long)b * C * HW4 + q;
-    float4 *dp = dx ? reinterpret_cast<float4 *>(dx) + (long)b * C * HW4 + q : nullptr;
+    const long base = (long)b * C * HW4 + q;
+    const float4 *xp = reinterpret_cast<const float4 *>(x) + base;
+    const float4 *gp = reinterpret_cast<const float4 *>(g) + base;
+    const float4 *x2p = x2 ? reinterpret_cast<const float4 *>(x2) + base : nullptr;
+    float4 *dp = dx ? reinterpret_cast<float4 *>(dx) + base : nullptr;
+    float4 *d2p = dx2 ? reinterpret_cast<float4 *>(dx2) + base : nullptr;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-    for (int c = 0; c < C; ++c) {
-        const float4 a = xp[c * HW4], d = gp[c * HW4];
+    for (int c = c0; c < c1; ++c) {
+        float4 a = xp[c * HW4];
+        const float4 d = gp[c * HW4];
+        const float4 dg = gm_mul(d, gv);
+        if (x2p) {
+            const float4 w = x2p[c * HW4];
+            if (dp) dp[c * HW4] = gm_mul(dg, w);
+            if (d2p) d2p[c * HW4] = gm_mul(dg, a);
+            a = gm_mul(a, w);
+        } else if (dp) {
+            dp[c * HW4] = dg;
+        }
         s.x = fmaf(a.x, d.x, s.x); s.y = fmaf(a.y, d.y, s.y); s.z = fmaf(a.z, d.z, s.z); s.w = fmaf(a.w, d.w, s.w);
-        if (dp) dp[c * HW4] = make_float4(d.x * gv.x, d.y * gv.y, d.z * gv.z, d.w * gv.w);
     }
-    if (dgate) reinterpret_cast<float4 *>(dgate)[b * HW4 + q] = s;
+    if (gridDim.z == 1) {
+        if (dgate) reinterpret_cast<float4 *>(dgate)[b * HW4 + q] = s;
+    } else if (part) {
+        reinterpret_cast<float4 *>(part)[((long)blockIdx.z * gridDim.y + b) * HW4 + q] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void gm_chunk_sum_kernel(const float *__restrict__ part, float *__restrict__ dgate, int nchunk,
+                                                           long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = reinterpret_cast<const float4 *>(part)[i];
+    for (int k = 1; k < nchunk; ++k) {
+        const float4 v = reinterpret_cast<const float4 *>(part)[(long)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4 *>(dgate)[i] = s;
 }
 
 int check(const mmu_gated_mul_params *p, const char *name) {
@@ -115,18 +156,26 @@ int check(const mmu_gated_mul_params *p, const char *name) {
 
 }  // namespace
 
+extern "C" size_t mmu_gated_mul_bwd_workspace_floats(int batch, int channels, int64_t hw, int mode) {
+    if (mode != MMU_GATE_SPATIAL || batch <= 0 || channels <= GM_CCH || hw <= 0) return 0;
+    return (size_t)((channels + GM_CCH - 1) / GM_CCH) * batch * hw;
+}
+
 extern "C" int mmu_gated_mul_fwd(const mmu_gated_mul_params *p, void *stream) {
     if (int r = check(p, "gated_mul_fwd")) return r;
     MMU_CHECK(p->out && ((uintptr_t)p->out & 15) == 0 && ((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->gate & 15) == 0,
               "gated_mul_fwd: out is required; input, gate, out 16-byte aligned");
+    MMU_CHECK((!p->input2 && !p->addend) || p->mode == MMU_GATE_SPATIAL, "gated_mul_fwd: input2 / addend need the spatial gate");
+    MMU_CHECK(((uintptr_t)p->input2 & 15) == 0 && ((uintptr_t)p->addend & 15) == 0, "gated_mul_fwd: input2, addend 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long HW4 = p->hw / 4;
     if (p->mode == MMU_GATE_CHANNEL) {
         const long total4 = (long)p->batch * p->channels * HW4;
         gm_channel_fwd_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, st>>>(p->input, p->gate, p->out, HW4, total4);
     } else {
-        gm_spatial_fwd_kernel<<<dim3((unsigned)((HW4 + 255) / 256), p->batch), 256, 0, st>>>(p->input, p->gate, p->out,
-                                                                                            p->channels, HW4);
+        const long CHW4 = (long)p->channels * HW4, total4 = (long)p->batch * CHW4;
+        gm_spatial_fwd_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, st>>>(p->input, p->gate, p->out, CHW4, HW4, total4,
+                                                                             p->input2, p->addend);
     }
     MMU_HIP_LAUNCH_CHECK("gated_mul_fwd");
     return 0;
@@ -134,8 +183,10 @@ extern "C" int mmu_gated_mul_fwd(const mmu_gated_mul_params *p, void *stream) {
 
 extern "C" int mmu_gated_mul_bwd(const mmu_gated_mul_params *p, void *stream) {
     if (int r = check(p, "gated_mul_bwd")) return r;
-    MMU_CHECK(p->dout && (p->dinput || p->dgate), "gated_mul_bwd: dout and at least one of dinput / dgate are required");
-    const void *ptrs[] = {p->input, p->gate, p->dout, p->dinput, p->dgate};
+    MMU_CHECK(p->dout && (p->dinput || p->dgate || p->dinput2), "gated_mul_bwd: dout and at least one output are required");
+    MMU_CHECK((!p->input2 && !p->dinput2) || (p->mode == MMU_GATE_SPATIAL && p->input2),
+              "gated_mul_bwd: input2 / dinput2 need the spatial gate (and dinput2 needs input2)");
+    const void *ptrs[] = {p->input, p->gate, p->dout, p->dinput, p->dgate, p->input2, p->dinput2};
     for (const void *q : ptrs) MMU_CHECK(((uintptr_t)q & 15) == 0, "gated_mul_bwd: tensors must be 16-byte aligned");
     MMU_CHECK((p->stats_dout == nullptr) == (p->stats_argmax == nullptr) && (!p->stats_dout || p->mode == MMU_GATE_CHANNEL) &&
                   ((uintptr_t)p->stats_dout & 15) == 0 && ((uintptr_t)p->stats_argmax & 15) == 0,
@@ -148,8 +199,17 @@ extern "C" int mmu_gated_mul_bwd(const mmu_gated_mul_params *p, void *stream) {
                                                                                      p->dgate, HW4, p->stats_dout,
                                                                                      p->stats_argmax, p->channels);
     } else {
-        gm_spatial_bwd_kernel<<<dim3((unsigned)((HW4 + 255) / 256), p->batch), 256, 0, st>>>(p->input, p->gate, p->dout,
-                                                                                            p->dinput, p->dgate, p->channels, HW4);
+        const int nchunk = (p->channels + GM_CCH - 1) / GM_CCH;
+        MMU_CHECK(nchunk == 1 || !p->dgate || (p->workspace && ((uintptr_t)p->workspace & 15) == 0),
+                  "gated_mul_bwd: the spatial gate's dgate needs mmu_gated_mul_bwd_workspace_floats() floats of workspace");
+        gm_spatial_bwd_kernel<<<dim3((unsigned)((HW4 + 255) / 256), p->batch, nchunk), 256, 0, st>>>(
+            p->input, p->gate, p->dout, p->dinput, p->dgate, p->channels, HW4, p->input2, p->dinput2,
+            p->dgate ? p->workspace : nullptr);
+        if (nchunk > 1 && p->dgate) {
+            MMU_HIP_LAUNCH_CHECK("gated_mul_bwd");
+            const long n4 = (long)p->batch * HW4;
+            gm_chunk_sum_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(p->workspace, p->dgate, nchunk, n4);
+        }
     }
     MMU_HIP_LAUNCH_CHECK("gated_mul_bwd");
     return 0;

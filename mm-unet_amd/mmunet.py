@@ -363,7 +363,7 @@ class RCG(nn.Module):
 
     def forward(self, pre, edge, f, edge_slot=None):
         """``edge_slot``: a conv3x3_small.SharedGrad of all consumers of ``edge`` (MM_Net: three RCG blocks + the line head)."""
-        r = (1 - torch.sigmoid(pre)) * f
+        r = pointwise.gated_mul(f, 1 - torch.sigmoid(pre))     # (1 - sigmoid(pre)) * f with a per-pixel gate: one pass each way
         edge1 = bilinear_resize(edge, size=f.size()[2:], slot=edge_slot)
         x2 = run_fused(self.conv1, torch.cat((edge1, r), 1))
         # tri-directional Mamba at 2x resolution (MMUNet.py:398-412)
@@ -374,7 +374,7 @@ class RCG(nn.Module):
         out, _, _, _ = self.mamba.forward_bcl(x0.reshape(B, C, H * W))
         x0 = conv_s2.module_call(self.downsample, out.reshape(B, C, H, W))
         gate = torch.sigmoid(pointwise.conv_module(self.mlp[0], x2))       # mlp = Conv2d(64, 1, 1) -> Sigmoid
-        return pointwise.gated_mul(x0 * x2, gate) + f
+        return pointwise.gated_mul3(x0, x2, gate, f)           # x0 * x2 * gate + f in one pass
 
 
 class DecoderBlock(nn.Module):

@@ -152,6 +152,12 @@ def _gate_mode(x, gate):
     return None
 
 
+def _spatial_workspace(x, mode):
+    """Chunk sums of the spatial gate's gradient (csrc/gated_mul.hip), or None when one chunk covers the channels."""
+    n = _lib.lib().mmu_gated_mul_bwd_workspace_floats(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], mode)
+    return torch.empty(n, device=x.device, dtype=torch.float32) if n else None
+
+
 class ChannelStatsSlot:
     """Hand-over between ``channel_max_mean(y)`` and the ``gated_mul`` that produced ``y`` (CBAM: y1 = x * c_out feeds the
     spatial statistics and the second product): the statistics' backward parks its two small operands here and returns
@@ -208,6 +214,8 @@ class GatedMulFn(torch.autograd.Function):
         p.batch, p.channels, p.mode, p.hw = B, C, ctx.mode, H * W
         p.input, p.gate, p.dout = x.data_ptr(), gate.data_ptr(), g.data_ptr()
         p.dinput, p.dgate = _lib.ptr(dx), _lib.ptr(dgate)
+        ws = _spatial_workspace(x, ctx.mode) if need_g else None
+        p.workspace = _lib.ptr(ws)
         if stats is not None:
             sg, sam = stats
             if sg.shape != (B, 2, H, W) or sam.shape != (B, H, W) or sg.dtype != torch.float32 or sam.dtype != torch.int32:
@@ -219,6 +227,57 @@ class GatedMulFn(torch.autograd.Function):
             parked = ctx.x_slot.take()
             dx = ctx.x_slot.give(dx if parked is None else parked.add_(dx))
         return dx, dgate, None, None, None
+
+
+class GatedMul3Fn(torch.autograd.Function):
+    """``x * x2 * gate + addend`` with a per-pixel gate (B, 1, H, W): RCG's ``x0 * gate * x2 + f`` (MMUNet.py:415) in one pass
+    each way instead of a product, a gated product and an add (three passes) / five kernels backward."""
+
+    @staticmethod
+    def forward(ctx, x, x2, gate, addend):
+        _lib.require_gpu(x, x2, gate, addend)
+        _need_f32_nchw("gated_mul3", x)
+        B, C, H, W = x.shape
+        if any(t.dtype != torch.float32 for t in (x2, gate, addend)) or x2.shape != x.shape or addend.shape != x.shape or \
+                tuple(gate.shape) != (B, 1, H, W):
+            raise RuntimeError("gated_mul3: float32 x, x2, addend of one (B, C, H, W) shape and a (B, 1, H, W) gate required")
+        x, x2, gate, addend = x.contiguous(), x2.contiguous(), gate.contiguous(), addend.contiguous()
+        out = torch.empty_like(x)
+        p = _lib.GatedMulParams()
+        p.batch, p.channels, p.mode, p.hw = B, C, 1, H * W
+        p.input, p.gate, p.out, p.input2, p.addend = x.data_ptr(), gate.data_ptr(), out.data_ptr(), x2.data_ptr(), addend.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mmu_gated_mul_fwd(p, _lib.stream_of(x)))
+        ctx.save_for_backward(x, x2, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, x2, gate = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.float().contiguous()
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dx2 = torch.empty_like(x) if need[1] else None
+        dgate = torch.empty_like(gate) if need[2] else None
+        if need[0] or need[1] or need[2]:
+            p = _lib.GatedMulParams()
+            p.batch, p.channels, p.mode, p.hw = B, C, 1, H * W
+            p.input, p.gate, p.dout, p.input2 = x.data_ptr(), gate.data_ptr(), g.data_ptr(), x2.data_ptr()
+            p.dinput, p.dgate, p.dinput2 = _lib.ptr(dx), _lib.ptr(dgate), _lib.ptr(dx2)
+            ws = _spatial_workspace(x, 1) if need[2] else None
+            p.workspace = _lib.ptr(ws)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().mmu_gated_mul_bwd(p, _lib.stream_of(x)))
+        return dx, dx2, dgate, (g if need[3] else None)
+
+
+def gated_mul3(x, x2, gate, addend):
+    """``x * x2 * gate + addend`` for a per-pixel gate; the one-pass HIP form for float32 NCHW tensors, else ATen."""
+    if (_gate_mode(x, gate) == 1 and x2.shape == x.shape and addend.shape == x.shape and x2.dtype == torch.float32
+            and addend.dtype == torch.float32):
+        return GatedMul3Fn.apply(x, x2, gate, addend)
+    return gated_mul(x * x2, gate) + addend
 
 
 def gated_mul(x, gate, x_slot=None, stats_slot=None):

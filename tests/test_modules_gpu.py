@@ -1504,6 +1504,31 @@ def test_gated_mul_vs_broadcast_multiply(case):
     assert pointwise._gate_mode(x, odd) is None and torch.equal(pointwise.gated_mul(x, odd), x * odd)
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 128, 128), (2, 5, 6, 10), (1, 64, 32, 32)])
+def test_gated_mul3_vs_aten(shape):
+    """pointwise.gated_mul3 == ``x0 * gate * x2 + f`` (RCG, MMUNet.py:415) with a per-pixel gate: output and the four
+    gradients against the ATen expression; bit-reproducible."""
+    from mm_unet_amd import pointwise
+    B, C, H, W = shape
+    gen = torch.Generator(device=DEV).manual_seed(15)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=gen)     # noqa: E731
+    x, x2, f, g = rnd(*shape), rnd(*shape), rnd(*shape), rnd(*shape)
+    gate = torch.rand(B, 1, H, W, device=DEV, generator=gen)
+    ref_in = [t.clone().requires_grad_() for t in (x, x2, gate, f)]
+    ref = ref_in[0] * ref_in[2] * ref_in[1] + ref_in[3]
+    ref.backward(g)
+    res = []
+    for _ in range(2):
+        ins = [t.clone().requires_grad_() for t in (x, x2, gate, f)]
+        out = pointwise.gated_mul3(*ins)
+        out.backward(g)
+        res.append([out.detach()] + [t.grad for t in ins])
+    close(res[0][0], ref, 1e-6, 1e-6, "out")
+    for name, a, b in zip(("d x", "d x2", "d gate", "d f"), res[0][1:], (t.grad for t in ref_in)):
+        close(a, b, 1e-5, 2e-6 * C ** 0.5, name)
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+
+
 @pytest.mark.parametrize("shape", [(8, 64, 256, 256), (2, 5, 6, 10), (3, 16, 12, 12), (1, 64, 16, 16)])
 def test_cbam_stats_vs_aten(shape):
     """csrc/cbam_stats.hip: (avg_pool, max_pool) over the pixels and cat(max, mean) over the channels of CBAM
