@@ -9,6 +9,7 @@
 // kernel: thread = 4 consecutive output x of one (plane, oy), 16-byte stores.  Backward is a GATHER (each
 // input pixel sums the outputs whose footprint covers it; the source ranges follow from monotonic sy, sx),
 // so it needs neither atomics nor a zeroed buffer and is bit-reproducible (ATen: float atomics).
+#include <type_traits>
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
 
@@ -33,34 +34,83 @@ __device__ __forceinline__ void tap(int o, float r, int n, int &i0, int &i1, flo
     w = s - (float)i0;
 }
 
+// block (bx, 256 / bx), bx = 8 ... 64 lanes along x by the output width: a thread = 4 consecutive output x of one row
+// (plane, oy); at bx = 64 a WAVE owns the row -- its y tap and row pointers are wave-uniform -- and the row index is one
+// 32-bit division where the flat form paid four 64-bit ones per thread.
 template <typename io_t>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs p) {
-    const int xq = (p.OW + 3) / 4;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)p.planes * p.OH * xq;
-    if (idx >= total) return;
-    const int q = (int)(idx % xq);
-    const long r = idx / xq;
-    const int oy = (int)(r % p.OH);
-    const long plane = r / p.OH;
+    const unsigned row = blockIdx.x * blockDim.y + threadIdx.y;        // (plane, oy); host: planes * OH < 2^32
+    if (row >= (unsigned)p.planes * (unsigned)p.OH) return;
+    const unsigned plane = row / (unsigned)p.OH;
+    const int oy = (int)(row - plane * (unsigned)p.OH);
+    const int q = blockIdx.y * blockDim.x + threadIdx.x;
+    if (q * 4 >= p.OW) return;
     int y0, y1;
     float wy;
     tap(oy, p.ry, p.H, y0, y1, wy);
     const io_t *in = static_cast<const io_t *>(p.in);
-    const io_t *r0 = in + (plane * p.H + y0) * p.W, *r1 = in + (plane * p.H + y1) * p.W;
+    const io_t *r0 = in + ((long)plane * p.H + y0) * p.W, *r1 = in + ((long)plane * p.H + y1) * p.W;
     float v[4];
+    int x0[4], x1[4];
+    float wx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ox = q * 4 + j;
-        int x0, x1;
-        float wx;
-        tap(ox < p.OW ? ox : p.OW - 1, p.rx, p.W, x0, x1, wx);
-        const float a0 = to_f32(r0[x0]), b0 = to_f32(r1[x0]);
-        const float a = fmaf(wx, to_f32(r0[x1]) - a0, a0);
-        const float b = fmaf(wx, to_f32(r1[x1]) - b0, b0);
-        v[j] = fmaf(wy, b - a, a);
+        tap(ox < p.OW ? ox : p.OW - 1, p.rx, p.W, x0[j], x1[j], wx[j]);
     }
-    io_t *dst = static_cast<io_t *>(p.out) + (plane * p.OH + oy) * p.OW + q * 4;
+    // the four outputs read a short run of consecutive input columns (4 when up-sampling, 8 when halving): one or two
+    // 16-byte (unaligned) loads per row instead of eight dword gathers strided across the wave
+    const int span = x1[3] - x0[0];
+    if (std::is_same<io_t, float>::value && p.W >= 8 && span <= 7) {
+        const int wide = span > 3;                       // wave-uniform in practice (the ratio decides)
+        const int base = min(x0[0], p.W - (wide ? 8 : 4));
+        const float *f0 = reinterpret_cast<const float *>(r0) + base, *f1 = reinterpret_cast<const float *>(r1) + base;
+        float t0[8], t1[8];
+        __builtin_memcpy(t0, f0, 16);
+        __builtin_memcpy(t1, f1, 16);
+        if (wide) {
+            __builtin_memcpy(t0 + 4, f0 + 4, 16);
+            __builtin_memcpy(t1 + 4, f1 + 4, 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i0 = x0[j] - base, i1 = x1[j] - base;
+                float a0 = t0[0], a1 = t0[0], b0 = t1[0], b1 = t1[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    a0 = i0 == k ? t0[k] : a0;
+                    a1 = i1 == k ? t0[k] : a1;
+                    b0 = i0 == k ? t1[k] : b0;
+                    b1 = i1 == k ? t1[k] : b1;
+                }
+                const float a = fmaf(wx[j], a1 - a0, a0), b = fmaf(wx[j], b1 - b0, b0);
+                v[j] = fmaf(wy, b - a, a);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i0 = x0[j] - base, i1 = x1[j] - base;
+                float a0 = t0[0], a1 = t0[0], b0 = t1[0], b1 = t1[0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    a0 = i0 == k ? t0[k] : a0;
+                    a1 = i1 == k ? t0[k] : a1;
+                    b0 = i0 == k ? t1[k] : b0;
+                    b1 = i1 == k ? t1[k] : b1;
+                }
+                const float a = fmaf(wx[j], a1 - a0, a0), b = fmaf(wx[j], b1 - b0, b0);
+                v[j] = fmaf(wy, b - a, a);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a0 = to_f32(r0[x0[j]]), b0 = to_f32(r1[x0[j]]);
+            const float a = fmaf(wx[j], to_f32(r0[x1[j]]) - a0, a0);
+            const float b = fmaf(wx[j], to_f32(r1[x1[j]]) - b0, b0);
+            v[j] = fmaf(wy, b - a, a);
+        }
+    }
+    io_t *dst = static_cast<io_t *>(p.out) + (long)row * p.OW + q * 4;
     if ((p.OW & 3) == 0) {
         store_k<io_t, 4, true>(dst, 4, true, v);
     } else {
@@ -310,11 +360,17 @@ extern "C" int mmu_bilinear_resize_fwd(const mmu_resize_params *p, void *stream)
     if (int r = fill(p, a, "bilinear_resize_fwd")) return r;
     MMU_CHECK(p->input && p->out, "bilinear_resize_fwd: input and out are required");
     a.in = p->input; a.out = p->out;
-    const long total = (long)a.planes * a.OH * ((a.OW + 3) / 4);
+    const long rows = (long)a.planes * a.OH;
+    MMU_CHECK(rows < (1L << 32), "bilinear_resize_fwd: too many output rows");
+    const int xq = (a.OW + 3) / 4;
+    MMU_CHECK((xq + 63) / 64 <= 65535, "bilinear_resize_fwd: output too wide");
+    int bx = 8;
+    while (bx < 64 && bx < xq) bx *= 2;
+    const dim3 block(bx, 256 / bx), grid((unsigned)((rows + block.y - 1) / block.y), (unsigned)((xq + bx - 1) / bx));
     if (p->dtype == MMU_DTYPE_BF16)
-        resize_fwd_kernel<bf16_t><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+        resize_fwd_kernel<bf16_t><<<grid, block, 0, (hipStream_t)stream>>>(a);
     else
-        resize_fwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+        resize_fwd_kernel<float><<<grid, block, 0, (hipStream_t)stream>>>(a);
     MMU_HIP_LAUNCH_CHECK("bilinear_resize_fwd");
     return 0;
 }
