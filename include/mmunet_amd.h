@@ -665,6 +665,8 @@ typedef struct {
     float *dweight;        /* bwd, optional */
     float *dbias;          /* bwd, optional */
     float *workspace;      /* bwd */
+    const float *scale;    /* optional: [batch, channels] factors on the input (the side outputs' Dropout2d in front of the
+                            * convolution, MMUNet.py:345-350: mask / (1 - p)) -- out = sum_c w[c] scale[b][c] x[b][c] */
 } mmu_conv1x1_one_params;
 
 size_t mmu_conv1x1_one_workspace_floats(int batch, int channels, long hw);

@@ -166,7 +166,7 @@ class SumPartsParams(ctypes.Structure):
 
 class Conv1x1OneParams(ctypes.Structure):
     _fields_ = [("batch", _i32), ("channels", _i32), ("hw", _i64)] + \
-               [(n, _vp) for n in ("input", "weight", "bias", "out", "dout", "dinput", "dweight", "dbias", "workspace")]
+               [(n, _vp) for n in ("input", "weight", "bias", "out", "dout", "dinput", "dweight", "dbias", "workspace", "scale")]
 
 
 class MambaPreParams(ctypes.Structure):

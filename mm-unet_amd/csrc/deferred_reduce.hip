@@ -225,19 +225,26 @@ __device__ void job_conv_tiles(const long *row, int blk) {
     }
 }
 
-// kind 7: a wave per output over strided partial rows (conv7_wsum_kernel of conv7x7_small.hip).
-// {7, part, dst, -, n_out, nparts, stride, -}; 16 outputs per workgroup
+// kind 7: a wave per output over strided partial rows (conv7_wsum_kernel of conv7x7_small.hip;
+// pw1_sum_kernel of pointwise_one.hip: results from n1 on go to dst2).
+// {7, part, dst, dst2 or 0, n_out, nparts, stride, n1 (0: all to dst)}; 16 outputs per workgroup
 __device__ void job_wave_rows(const long *row, int blk) {
     const float *part = reinterpret_cast<const float *>(row[1]);
     float *dst = reinterpret_cast<float *>(row[2]);
-    const int n_out = (int)row[4], nparts = (int)row[5], stride = (int)row[6];
+    float *dst2 = reinterpret_cast<float *>(row[3]);
+    const int n_out = (int)row[4], nparts = (int)row[5], stride = (int)row[6], n1 = (int)row[7];
     const int lane = threadIdx.x & 63;
     const int i = blk * 16 + (threadIdx.x >> 6);
     if (i >= n_out) return;
     float s = 0.f;
     for (int k = lane; k < nparts; k += 64) s += part[(long)k * stride + i];
     s = wave_sum(s);
-    if (lane == 0) dst[i] = s;
+    if (lane == 0) {
+        if (n1 == 0 || i < n1)
+            dst[i] = s;
+        else
+            dst2[i - n1] = s;
+    }
 }
 
 // kinds 4 / 5: the selective scan's dA / dD / d delta_bias from its per-(batch, tile) partials -- reduce_partials_w8 (+

@@ -13,31 +13,35 @@
 
 namespace {
 
-template <int C>
+template <int C, bool SCALED>
 __global__ __launch_bounds__(256) void pw1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ bias, float *__restrict__ out, int B,
-                                                      long HW) {
+                                                      long HW, const float *__restrict__ scale) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;      // group of 4 pixels of batch item blockIdx.y
     if (q * 4 >= HW) return;
     const int b = blockIdx.y;
+    const float *sc = SCALED ? scale + (long)b * C : nullptr;  // (b, c) factors on the input: Dropout2d's mask / (1 - p)
     const float *xp = x + (long)b * C * HW + q * 4;
     const float bv = bias ? bias[0] : 0.f;
     float a0 = bv, a1 = bv, a2 = bv, a3 = bv;
 #pragma unroll 8
     for (int c = 0; c < C; ++c) {
         const float4 v = *reinterpret_cast<const float4 *>(xp + (long)c * HW);
-        const float wv = w[c];
+        float wv = w[c];
+        if constexpr (SCALED) wv *= sc[c];
         a0 = fmaf(wv, v.x, a0); a1 = fmaf(wv, v.y, a1); a2 = fmaf(wv, v.z, a2); a3 = fmaf(wv, v.w, a3);
     }
     *reinterpret_cast<float4 *>(out + (long)b * HW + q * 4) = make_float4(a0, a1, a2, a3);
 }
 
-template <int C>
+template <int C, bool SCALED>
 __global__ __launch_bounds__(256) void pw1_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ g, float *__restrict__ dx,
-                                                      float *__restrict__ part, int B, long HW) {
+                                                      float *__restrict__ part, int B, long HW,
+                                                      const float *__restrict__ scale) {
     constexpr int NV = C + 1, NV4 = (NV + 3) & ~3;
     __shared__ float red[4 * NV4];
+    const float *sc = SCALED ? scale + (long)blockIdx.y * C : nullptr;
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     const bool live = q * 4 < HW;
@@ -52,8 +56,10 @@ __global__ __launch_bounds__(256) void pw1_bwd_kernel(const float *__restrict__ 
     for (int c = 0; c < C; ++c) {
         const float4 xv = *reinterpret_cast<const float4 *>(xp + (long)c * HW);
         v[c] = fmaf(g4.x, xv.x, fmaf(g4.y, xv.y, fmaf(g4.z, xv.z, g4.w * xv.w)));
+        if constexpr (SCALED) v[c] *= sc[c];
         if (dp && live) {
-            const float wv = w[c];
+            float wv = w[c];
+            if constexpr (SCALED) wv *= sc[c];
             *reinterpret_cast<float4 *>(dp + (long)c * HW) = make_float4(g4.x * wv, g4.y * wv, g4.z * wv, g4.w * wv);
         }
     }
@@ -115,10 +121,13 @@ extern "C" int mmu_conv1x1_one_fwd(const mmu_conv1x1_one_params *p, void *stream
     MMU_CHECK(p->out && ((uintptr_t)p->out & 15) == 0, "conv1x1_one_fwd: out (16-byte aligned) is required");
     dim3 grid(pw1_blocks(p->hw), p->batch);
     hipStream_t st = (hipStream_t)stream;
-    if (p->channels == 16)
-        pw1_fwd_kernel<16><<<grid, 256, 0, st>>>(p->input, p->weight, p->bias, p->out, p->batch, p->hw);
-    else
-        pw1_fwd_kernel<64><<<grid, 256, 0, st>>>(p->input, p->weight, p->bias, p->out, p->batch, p->hw);
+    if (p->channels == 16) {
+        if (p->scale) pw1_fwd_kernel<16, true><<<grid, 256, 0, st>>>(p->input, p->weight, p->bias, p->out, p->batch, p->hw, p->scale);
+        else pw1_fwd_kernel<16, false><<<grid, 256, 0, st>>>(p->input, p->weight, p->bias, p->out, p->batch, p->hw, nullptr);
+    } else {
+        if (p->scale) pw1_fwd_kernel<64, true><<<grid, 256, 0, st>>>(p->input, p->weight, p->bias, p->out, p->batch, p->hw, p->scale);
+        else pw1_fwd_kernel<64, false><<<grid, 256, 0, st>>>(p->input, p->weight, p->bias, p->out, p->batch, p->hw, nullptr);
+    }
     MMU_HIP_LAUNCH_CHECK("conv1x1_one_fwd");
     return 0;
 }
@@ -130,14 +139,23 @@ extern "C" int mmu_conv1x1_one_bwd(const mmu_conv1x1_one_params *p, void *stream
     dim3 grid(pw1_blocks(p->hw), p->batch);
     const int nblk = (int)(grid.x * grid.y);
     hipStream_t st = (hipStream_t)stream;
-    if (p->channels == 16) {
-        pw1_bwd_kernel<16><<<grid, 256, 0, st>>>(p->input, p->weight, p->dout, p->dinput, p->workspace, p->batch, p->hw);
-        MMU_HIP_LAUNCH_CHECK("conv1x1_one_bwd");
-        if (p->dweight || p->dbias) pw1_sum_kernel<16><<<(17 + 3) / 4, 256, 0, st>>>(p->workspace, p->dweight, p->dbias, nblk);
+    const int C = p->channels, NV4 = (C + 1 + 3) & ~3;
+#define PW1_BWD(C_, S_) pw1_bwd_kernel<C_, S_><<<grid, 256, 0, st>>>(p->input, p->weight, p->dout, p->dinput, p->workspace, p->batch, p->hw, p->scale)
+    if (C == 16) {
+        if (p->scale) PW1_BWD(16, true); else PW1_BWD(16, false);
     } else {
-        pw1_bwd_kernel<64><<<grid, 256, 0, st>>>(p->input, p->weight, p->dout, p->dinput, p->workspace, p->batch, p->hw);
-        MMU_HIP_LAUNCH_CHECK("conv1x1_one_bwd");
-        if (p->dweight || p->dbias) pw1_sum_kernel<64><<<(65 + 3) / 4, 256, 0, st>>>(p->workspace, p->dweight, p->dbias, nblk);
+        if (p->scale) PW1_BWD(64, true); else PW1_BWD(64, false);
+    }
+#undef PW1_BWD
+    MMU_HIP_LAUNCH_CHECK("conv1x1_one_bwd");
+    if (p->dweight || p->dbias) {
+        // inside a deferred scope: with the other parameter-gradient sums of the pass (deferred_reduce.hip, kind 7)
+        if (p->dweight && p->dbias) {
+            const long job[8] = {7, (long)p->workspace, (long)p->dweight, (long)p->dbias, C + 1, nblk, NV4, C};
+            if (mmu_defer_job(job)) return 0;
+        }
+        if (C == 16) pw1_sum_kernel<16><<<(17 + 3) / 4, 256, 0, st>>>(p->workspace, p->dweight, p->dbias, nblk);
+        else pw1_sum_kernel<64><<<(65 + 3) / 4, 256, 0, st>>>(p->workspace, p->dweight, p->dbias, nblk);
     }
     MMU_HIP_LAUNCH_CHECK("conv1x1_one_bwd(sum)");
     return 0;

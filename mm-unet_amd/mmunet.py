@@ -346,7 +346,7 @@ class SideoutBlock(nn.Module):
         self.conv2 = nn.Conv2d(in_channels // 4, out_channels, kernel_size=1)
 
     def forward(self, x):
-        return pointwise.conv_module(self.conv2, self.dropout(run_fused(self.conv1, x)))
+        return pointwise.conv_module(self.conv2, run_fused(self.conv1, x), dropout=self.dropout)
 
 
 class RCG(nn.Module):

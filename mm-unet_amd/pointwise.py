@@ -26,8 +26,10 @@ def module_supported(m, x):
 
 class Conv1x1OneFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        _lib.require_gpu(x, weight)
+    def forward(ctx, x, weight, bias, scale=None):
+        _lib.require_gpu(x, weight, scale)
+        if scale is not None and (scale.dtype != torch.float32 or scale.numel() != x.shape[0] * x.shape[1]):
+            raise RuntimeError("conv1x1_one: scale must hold batch * channels float32 factors")
         if not supported(x, weight) or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != 1)):
             raise RuntimeError("conv1x1_one: float32 NCHW input with 16 or 64 channels and H*W % 4 == 0, a [1, C, 1, 1] "
                                "float32 weight and a float32 bias of one element required")
@@ -38,21 +40,23 @@ class Conv1x1OneFn(torch.autograd.Function):
         p = _lib.Conv1x1OneParams()
         p.batch, p.channels, p.hw = B, C, H * W
         p.input, p.weight, p.bias, p.out = x.data_ptr(), weight.data_ptr(), _lib.ptr(bias), out.data_ptr()
+        scale = scale.contiguous() if scale is not None else None
+        p.scale = _lib.ptr(scale)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_conv1x1_one_fwd(p, _lib.stream_of(x)))
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, scale)
         ctx.has_bias = bias is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight, scale = ctx.saved_tensors
         B, C, H, W = x.shape
         g = g.float().contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if not (need_x or need_w or need_b):
-            return None, None, None
+            return None, None, None, None
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty_like(weight) if need_w else None
         db = torch.empty(1, device=x.device, dtype=torch.float32) if need_b else None
@@ -62,18 +66,29 @@ class Conv1x1OneFn(torch.autograd.Function):
         p.batch, p.channels, p.hw = B, C, H * W
         p.input, p.weight, p.dout = x.data_ptr(), weight.data_ptr(), g.data_ptr()
         p.dinput, p.dweight, p.dbias, p.workspace = _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr()
+        p.scale = _lib.ptr(scale)
         with torch.cuda.device(x.device):
             _lib.check(L.mmu_conv1x1_one_bwd(p, _lib.stream_of(x)))
-        return dx, dw, db
+        deferred.keep(ws)    # (inside a deferred.Scope the sum over the workgroups' partials runs later)
+        return dx, dw, db, None
 
 
-def conv1x1_one(x, weight, bias=None):
-    return Conv1x1OneFn.apply(x, weight, bias)
+def conv1x1_one(x, weight, bias=None, scale=None):
+    return Conv1x1OneFn.apply(x, weight, bias, scale)
 
 
-def conv_module(m, x):
-    """``m(x)`` for an ``nn.Conv2d``: the HIP kernels when :func:`module_supported`, the module itself otherwise."""
-    return conv1x1_one(x, m.weight, m.bias) if module_supported(m, x) else m(x)
+def conv_module(m, x, dropout=None):
+    """``m(x)`` for an ``nn.Conv2d``: the HIP kernels when :func:`module_supported`, the module itself otherwise.
+    ``dropout``: an ``nn.Dropout2d`` to apply to ``x`` first (SideoutBlock, MMUNet.py:345-350) -- its (batch, channel) mask
+    is drawn exactly as the module draws it and folded into the convolution's weights per batch item instead of
+    multiplied into the activation (two passes over it each way)."""
+    active = dropout is not None and dropout.training and dropout.p > 0
+    if not module_supported(m, x):
+        return m(dropout(x) if dropout is not None else x)
+    scale = None
+    if active:   # F.dropout2d: noise = x.new_empty(B, C, 1, 1).bernoulli_(1 - p).div_(1 - p); x * noise
+        scale = x.new_empty((x.shape[0], x.shape[1], 1, 1)).bernoulli_(1 - dropout.p).div_(1 - dropout.p)
+    return conv1x1_one(x, m.weight, m.bias, scale)
 
 
 # ---- nn.Conv2d(2, 1, 7, padding=3, bias=False): CBAM's spatial-attention convolution (MMUNet.py:323,335) --------------

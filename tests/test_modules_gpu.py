@@ -1192,6 +1192,44 @@ def test_conv1x1_one_vs_conv2d(case):
         pointwise.conv1x1_one(x[:, :3].contiguous(), w[:, :3].contiguous(), None)
 
 
+@pytest.mark.parametrize("case", [(8, 16, 128, 128), (2, 64, 12, 10), (3, 16, 6, 6)])
+def test_side_output_dropout_folded_into_the_1x1_convolution(case):
+    """SideoutBlock's ``conv2(dropout(x))`` (MMUNet.py:345-350) with Dropout2d's (batch, channel) mask folded into the
+    convolution's weights per batch item: the same mask as the module draws (same generator state -> same result),
+    output and input / weight / bias gradients against the two modules; eval mode and p = 0 are the plain convolution;
+    the deferred weight / bias sums equal the immediate ones bit for bit."""
+    from mm_unet_amd import deferred, pointwise
+    B, C, H, W = case
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(B, C, H, W, device=DEV, generator=gen)
+    g = torch.randn(B, 1, H, W, device=DEV, generator=gen)
+    conv = torch.nn.Conv2d(C, 1, 1).to(DEV)
+    drop = torch.nn.Dropout2d(0.3).train()
+    assert pointwise.module_supported(conv, x)
+
+    def run(fused, scope=None):
+        torch.manual_seed(123)
+        xi = x.clone().requires_grad_()
+        conv.zero_grad(set_to_none=True)
+        out = pointwise.conv_module(conv, xi, dropout=drop) if fused else conv(drop(xi))
+        out.backward(g)
+        if scope is not None:
+            scope.launch()
+        return out.detach(), xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone()
+
+    ref, got = run(False), run(True)
+    assert float((got[1] == 0).all(dim=(2, 3)).float().mean()) > 0     # some (b, c) planes were dropped
+    for name, a, b, tol in zip(("out", "d x", "d w", "d b"), got, ref, (1e-5, 1e-6, 1e-4, 1e-4)):
+        close(a, b, 1e-4, tol * (H * W * B) ** 0.5, name)
+    scope = deferred.Scope(DEV)
+    with scope:
+        later = run(True, scope)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, later))
+    drop.eval()
+    close(pointwise.conv_module(conv, x, dropout=drop), conv(x), 1e-5, 1e-5, "eval")
+
+
 @pytest.mark.parametrize("case", [(8, 64, 128, 64, 64), (2, 16, 24, 10, 14), (1, 128, 256, 7, 9), (8, 256, 512, 32, 32)])
 def test_conv1x1_stride2_vs_conv2d(case):
     """tall_gemm.conv1x1_stride2 == nn.Conv2d(I, O, 1, stride=2, bias=False) (MMUNet.py:448, the down-sampling shortcut):
