@@ -201,6 +201,8 @@ typedef struct {
     int32_t y_parts;     /* fwd: 0 / 1 = y is the row map; n > 1 = y holds n maps [n][batch, taps, height, width] whose
                           * sum is the row map (mmu_mamba_small_fwd's state-range partials), summed in fixed order */
     float *y_sum;        /* fwd, y_parts > 1: receives the summed map [batch, taps, height, width] (pass it as y to bwd) */
+    const void *dinput_addend; /* bwd, optional: [batch, channels, height, width], in_dtype -- added to dinput (another
+                                * consumer's gradient of the input: a residual connection; may be dinput itself) */
 } mmu_morph_params;
 
 int mmu_morph_sample_fwd(const mmu_morph_params *p, void *stream);

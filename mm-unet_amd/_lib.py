@@ -69,7 +69,7 @@ class Conv1dUpdateParams(ctypes.Structure):
 class MorphParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "channels", "height", "width", "taps", "out_layout")]
                 + [(n, _vp) for n in ("input", "y", "out", "dout", "dinput", "dy")]
-                + [("in_dtype", _i32), ("y_parts", _i32), ("y_sum", _vp)])
+                + [("in_dtype", _i32), ("y_parts", _i32), ("y_sum", _vp), ("dinput_addend", _vp)])
 
 
 class ResizeParams(ctypes.Structure):

@@ -30,10 +30,36 @@ class GradSlot:
     backward adds its own contribution to it in the same kernel and returns the sum -- autograd has one gradient to
     route instead of two to add (41 activation-sized adds per training step).  ``armed`` is set by the convolution's
     forward when its backward will produce an input gradient."""
-    __slots__ = ("armed", "grad")
+    __slots__ = ("armed", "grad", "extra", "extra_ok")
 
     def __init__(self):
-        self.armed, self.grad = False, None
+        # extra / extra_ok: a third consumer's gradient (park_extra), accepted while the sampler's backward is still to come
+        self.armed, self.grad, self.extra, self.extra_ok = False, None, None, False
+
+
+class _ParkExtraFn(torch.autograd.Function):
+    """Identity on a THIRD consumer's view of the tensor a GradSlot's pair reads (ResidualBlock: the block input also
+    feeds the residual add): its gradient is parked in ``slot.extra`` and the sampler's backward -- the first of the pair
+    to run -- adds it in its gather kernel.  Applied right before the op that consumes the view, so that autograd runs this
+    node before the pair's (later-created nodes first); if the pair has already run, the gradient goes the normal way."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        ctx.like = (x.dtype, tuple(x.shape))
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        slot = ctx.slot
+        if slot.extra_ok and slot.extra is None and g.is_contiguous() and (g.dtype, tuple(g.shape)) == ctx.like:
+            slot.extra = g
+            return None, None
+        return g, None
+
+
+def park_extra(x, slot):
+    return _ParkExtraFn.apply(x, slot) if (slot is not None and x.requires_grad and torch.is_grad_enabled()) else x
 
 
 class SharedGrad:

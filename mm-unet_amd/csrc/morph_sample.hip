@@ -41,6 +41,7 @@ struct MorphArgs {
     const float *dout;      // same layout as out
     void *din;              // [B, C, H, W], in_t
     float *dy;              // [B, K, H, W]  zero-initialised when cs > 1
+    const void *din_addend; // gather: added to d input ([B, C, H, W], in_t; another consumer's gradient of the input), or null
 };
 
 // += on an element of d input (the rare far-outlier contributions): float atomics, or for bf16 a CAS loop on the
@@ -182,6 +183,13 @@ __global__ __launch_bounds__(256) void morph_gather_din_kernel(MorphArgs p) {
     float acc[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) acc[c] = 0.f;
+    if (p.din_addend) {   // a residual connection's gradient: the sums start from it (its loads are in flight during the
+                          // coordinate work below; added at the end they were 13 us of exposed latency per call)
+        const in_t *ad = static_cast<const in_t *>(p.din_addend) + ((long)b * p.C + c0) * HW + pos;
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+            if (c < nc) acc[c] = to_f32(ad[(long)c * HW]);
+    }
     const int hlo = yy - p.reach > 0 ? yy - p.reach : 0;
     const int hhi = yy + p.reach < p.H - 1 ? yy + p.reach : p.H - 1;
     const long ostride = p.so_c;
@@ -292,6 +300,7 @@ extern "C" int mmu_morph_sample_bwd(const mmu_morph_params *p, void *stream) {
     MorphArgs a = {};
     a.B = p->batch; a.C = p->channels; a.H = p->height; a.W = p->width; a.K = p->taps;
     a.in = p->input; a.y = p->y; a.dout = p->dout; a.din = p->dinput; a.dy = p->dy;
+    a.din_addend = p->dinput_addend;
     set_out_strides(a, p->out_layout);
     const int positions = a.K * a.H * a.W;
     a.cs = channel_slices(a.B, a.C, positions);

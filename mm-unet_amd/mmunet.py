@@ -167,12 +167,14 @@ class MMConv(nn.Module):
         gradient in place; the mix-first sampler (and dsc_conv_y) a batch-major one."""
         return self.morph == 0 and not morph_mix.wanted(input, self.dsc_conv_x, self.kernel_size)
 
-    def forward_pre_gn(self, input):
+    def forward_pre_gn(self, input, slot=None):
         """Everything of forward() before the final GroupNorm (run_fused joins that GroupNorm with the
         BatchNorm2d / ReLU that follow the block in its nn.Sequential).  Returns (conv output WITHOUT its
         bias, bias or None): the fused normalisation folds the bias into its statistics."""
-        # the offset convolution and the sampler both read `input`: their input gradients leave as one (GradSlot)
-        slot = conv3x3_small.GradSlot() if input.requires_grad and torch.is_grad_enabled() else None
+        # the offset convolution and the sampler both read `input`: their input gradients leave as one (GradSlot; a caller
+        # whose `input` has a third consumer -- ResidualBlock's shortcut -- passes the slot it parks that gradient in)
+        if slot is None:
+            slot = conv3x3_small.GradSlot() if input.requires_grad and torch.is_grad_enabled() else None
         raw = self._offset_conv(input, slot)
         if norm_fused.supported(raw, self.gn_offset):
             # GroupNorm -> tanh in 2 passes; float32 also under autocast (coordinates: the reference's group_norm and
@@ -213,25 +215,28 @@ class MMConv(nn.Module):
         return self.dsc_conv_y(morph_sample(input, y_rows, slot=slot)), None
 
 
-def run_fused(seq, x, residual=None, in_slot=None):
+def run_fused(seq, x, residual=None, in_slot=None, first_slot=None):
     """``seq(x)`` (``relu(seq(x) + residual)`` when a residual is given: the tail of a ResidualBlock) for an
     nn.Sequential, with every ``MMConv -> BatchNorm2d [-> ReLU]`` run as the MMConv up
     to its final GroupNorm followed by ONE fused GroupNorm + BatchNorm + ReLU (norm_fused): 2 passes over the
     activation instead of 8 forward, 2 instead of 13 backward.  Module structure / state_dict are untouched.
     ``in_slot``: a conv3x3_small.SharedGrad of all consumers of ``x``, for a sequence that opens with the stride-2 1 x 1
-    shortcut convolution."""
+    shortcut convolution.  ``first_slot``: the conv3x3_small.GradSlot of an opening MMConv when ``residual`` is the same
+    tensor as ``x`` (ResidualBlock): the residual's gradient is parked there and added by the sampler's backward kernel
+    instead of an autograd add."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, MMConv) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
-            pre, bias = m.forward_pre_gn(x)
+            pre, bias = m.forward_pre_gn(x, first_slot if i == 0 else None)
             bn = mods[i + 1]
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
             if norm_fused.supported(pre, m.gn, bn):
                 last = residual is not None and not relu and i + 2 == len(mods)   # ... -> BN, then + residual, ReLU
                 x = norm_fused.gn_bn_act(pre, m.gn, bn, "relu" if (relu or last) else None, pre_bias=bias,
-                                         grad_channel_major=m.grad_channel_major(x), residual=residual if last else None)
+                                         grad_channel_major=m.grad_channel_major(x),
+                                         residual=conv3x3_small.park_extra(residual, first_slot) if last else None)
                 if last:
                     return x
                 i += 3 if relu else 2
@@ -414,7 +419,10 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         # relu(block1(x) + shortcut): the add and the ReLU ride along in block1's last fused normalisation
         if not self.downsample:
-            return run_fused(self.block1, x, residual=x)
+            # x feeds block1's first MMConv (offset convolution + sampler: one GradSlot) and the residual add: the
+            # residual's gradient rides along in that slot instead of being added by autograd
+            slot = conv3x3_small.GradSlot() if (torch.is_grad_enabled() and x.requires_grad) else None
+            return run_fused(self.block1, x, residual=x, first_slot=slot)
         # x feeds the 3 x 3 stride-2 convolution and the 1 x 1 stride-2 shortcut: the shortcut's backward adds its even
         # pixels to the gradient the other one left (conv3x3_small.SharedGrad) instead of autograd adding two tensors
         slot = conv3x3_small.SharedGrad() if (torch.is_grad_enabled() and x.requires_grad) else None

@@ -57,6 +57,8 @@ class MorphSampleFn(torch.autograd.Function):
         ctx.parts = parts
         ctx.in_dtype, ctx.y_dtype, ctx.tokens_last = input.dtype, y.dtype, bool(tokens_last)
         ctx.slot = slot
+        if slot is not None:   # this call's backward can add a third consumer's gradient of the input (park_extra)
+            slot.extra_ok = bool(ctx.needs_input_grad[0]) and x.dtype == input.dtype
         return out
 
     @staticmethod
@@ -73,10 +75,18 @@ class MorphSampleFn(torch.autograd.Function):
         p.input, p.y, p.dout = x.data_ptr(), yy.data_ptr(), g.data_ptr()
         p.dinput, p.dy = dinput.data_ptr(), dy.data_ptr()
         p.in_dtype = _lib.dtype_code(x)
+        slot = ctx.slot
+        extra = None
+        if slot is not None:
+            slot.extra_ok = False      # (from here on a late park_extra gradient goes the normal way)
+        if slot is not None and slot.extra is not None:    # a residual connection's gradient of x (conv3x3_small.park_extra)
+            extra, slot.extra = slot.extra, None
+            if extra.shape != x.shape or extra.dtype != x.dtype or not extra.is_contiguous():
+                raise RuntimeError("morph_sample: parked residual gradient does not match the input")
+            p.dinput_addend = extra.data_ptr()
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_morph_sample_bwd(p, _lib.stream_of(x)))
         dinput = dinput.to(ctx.in_dtype)
-        slot = ctx.slot
         # conv3x3_small.GradSlot: the offset convolution's backward (which needs this call's d(row) and therefore
         # runs after it) adds its own input gradient to this one and returns the sum
         if slot is not None and slot.armed and ctx.needs_input_grad[1] and slot.grad is None and x.dtype == ctx.in_dtype:
