@@ -175,53 +175,51 @@ __device__ void job_rows(const long *row, int blk, float (*sums)[16][64]) {
 // kind 6: weight gradient of the matrix-core convolutions from its per-workgroup tile partials (conv3x3_wgrad_sum_kernel of
 // conv3x3_wgrad_mfma.hip, conv_s2_wgrad_sum_kernel of conv_s2_mfma.hip; same order: 16 lanes per output stride over the
 // partials, row-local DPP sum).  {6, ws, dW, Cin | Cout << 32, K (0: the 3 x 3 stride-1 layout), n_cic, wg_per_cc,
-// TCO | TCI << 32}; 64 outputs per workgroup.
+// TCO | TCI << 32}; 1,024 tile elements per workgroup.
+// Walked in the PARTIALS' order (a thread = one element of a tile, consecutive threads consecutive elements: coalesced; the
+// output-ordered form read one float per 64 KB-strided line: 147 us for 150 MB), with the additions in the order of the
+// kernels it replaces: sixteen class sums k = c, c + 16, ... and their row-shift tree.
 __device__ void job_conv_tiles(const long *row, int blk) {
     const float *ws = reinterpret_cast<const float *>(row[1]);
     float *dW = reinterpret_cast<float *>(row[2]);
     const int Cin = (int)(row[3] & 0xffffffff), Cout = (int)(row[3] >> 32), K = (int)row[4];
     const int n_cic = (int)row[5], wg_per_cc = (int)row[6];
     const int TCO = (int)(row[7] & 0xffffffff), TCI = (int)(row[7] >> 32);
-    const int sub = threadIdx.x & 15;
-    const int KK = K ? K * K : 9, S = K ? 4 : 9;
-    const unsigned n = (unsigned)Cout * Cin * KK;        // (host: below 2^31; 32-bit divisions throughout -- the 64-bit ones
-    const long tile = (long)TCO * TCI * S;               //  of the kernels this replaces were most of their 28 us)
-    const float *src[REP];
-    int out[REP];
-    float acc[REP];
+    const int S = K ? 4 : 9;
+    const unsigned tile = (unsigned)TCO * TCI * S;
+    const unsigned total = (unsigned)n_cic * (Cout / TCO) * tile;
+    const unsigned g = (unsigned)blk * 1024 + threadIdx.x;
+    if (g >= total) return;
+    const unsigned cc = g / tile, e = g - cc * tile;
+    const float *src = ws + (long)cc * wg_per_cc * tile + e;
+    float a[16];
 #pragma unroll
-    for (int r = 0; r < REP; ++r) {
-        unsigned i = ((unsigned)blk * REP + r) * 64 + (threadIdx.x >> 4);
-        out[r] = i < n ? (int)i : -1;
-        i = i < n ? i : n - 1;
-        const unsigned q = i / (unsigned)KK;
-        const int t = (int)(i - q * KK);
-        const unsigned co = q / (unsigned)Cin;
-        const int c = (int)(q - co * Cin);
-        int v = c, sidx = t;
-        if (K) {   // stride 2: kh = 2a + 1 - py  <=>  py = (kh + 1) & 1, a = (kh - 1 + py) / 2 (conv_s2_mfma.hip)
-            const int kh = t / K, kw = t - kh * K;
-            const int py = (kh + 1) & 1, a = (kh - 1 + py) >> 1, pxx = (kw + 1) & 1, b = (kw - 1 + pxx) >> 1;
-            v = (py * 2 + pxx) * Cin + c;
-            sidx = a * 2 + b;
-        }
-        const unsigned cot = co / (unsigned)TCO, vt = (unsigned)v / (unsigned)TCI;
-        const int cc = (int)(cot * n_cic + vt);
-        src[r] = ws + ((long)cc * wg_per_cc) * tile + ((int)(co - cot * TCO) * TCI + (int)(v - vt * TCI)) * S + sidx;
-        acc[r] = 0.f;
-    }
-    for (int k = sub; k < wg_per_cc; k += 16) {
+    for (int c = 0; c < 16; ++c) a[c] = 0.f;
+    int k = 0;
+    for (; k + 16 <= wg_per_cc; k += 16) {
 #pragma unroll
-        for (int r = 0; r < REP; ++r) acc[r] += src[r][(long)k * tile];
+        for (int c = 0; c < 16; ++c) a[c] += src[(long)(k + c) * tile];
     }
 #pragma unroll
-    for (int r = 0; r < REP; ++r) {
-        float a = acc[r];
-        a += dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(0.f, a);
-        a += dpp_mov<MMU_DPP_ROW_SHR(2), 0xf>(0.f, a);
-        a += dpp_mov<MMU_DPP_ROW_SHR(4), 0xf>(0.f, a);
-        a += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, a);
-        if (out[r] >= 0 && sub == 15) dW[out[r]] = a;
+    for (int c = 0; c < 16; ++c)
+        if (k + c < wg_per_cc) a[c] += src[(long)(k + c) * tile];
+    // lane 15 of the row-shift sum of sixteen lanes holding a[0..15] (s += shr1, shr2, shr4, shr8)
+    const float x1 = a[1] + a[0], x3 = a[3] + a[2], x5 = a[5] + a[4], x7 = a[7] + a[6];
+    const float x9 = a[9] + a[8], x11 = a[11] + a[10], x13 = a[13] + a[12], x15 = a[15] + a[14];
+    const float y3 = x3 + x1, y7 = x7 + x5, y11 = x11 + x9, y15 = x15 + x13;
+    const float z7 = y7 + y3, z15 = y15 + y11;
+    const float sum = z15 + z7;
+    // where the element goes
+    const unsigned cot = cc / (unsigned)n_cic, vt = cc - cot * n_cic;
+    const unsigned col = e / (unsigned)(TCI * S), rem = e - col * (TCI * S);
+    const unsigned vl = rem / (unsigned)S, sidx = rem - vl * S;
+    const unsigned co = cot * TCO + col, v = vt * TCI + vl;
+    if (K == 0) {
+        dW[((long)co * Cin + v) * 9 + sidx] = sum;
+    } else {   // kh = 2a + 1 - py, kw = 2b + 1 - px with (py, px) = the phase of virtual channel v (conv_s2_mfma.hip)
+        const unsigned ph = v / (unsigned)Cin, c = v - ph * Cin;
+        const int kh = 2 * (int)(sidx >> 1) + 1 - (int)(ph >> 1), kw = 2 * (int)(sidx & 1) + 1 - (int)(ph & 1);
+        if (kh < K && kw < K) dW[(((long)co * Cin + c) * K + kh) * K + kw] = sum;
     }
 }
 

@@ -119,13 +119,14 @@ class Scope:
                 nb = (r[5] + 15) // 16
             elif r[0] in (4, 5):
                 nb = r[6] & 0xffffffff          # a workgroup per channel
-            elif r[0] == 6:
-                nb = ((r[3] & 0xffffffff) * (r[3] >> 32) * (r[4] * r[4] if r[4] else 9) + 63) // 64
+            elif r[0] == 6:     # one thread per element of the partial tiles: n_cic * (Cout / TCO) * TCO * TCI * S
+                tco, tci = r[7] & 0xffffffff, r[7] >> 32
+                nb = (r[5] * ((r[3] >> 32) // tco) * tco * tci * (4 if r[4] else 9) + 1023) // 1024
             elif r[0] == 7:
                 nb = (r[4] + 15) // 16
             else:
                 nb = (r[7] + 63) // 64
-            if r[0] in (0, 1, 3, 6):            # REP blocks of 64 results per workgroup (MMU_DEFER_REP)
+            if r[0] in (0, 1, 3):               # REP blocks of 64 results per workgroup (MMU_DEFER_REP)
                 nb = (nb + self.REP - 1) // self.REP
             work += [[j, b] for b in range(nb)]
         if len(work) > self.work.shape[0]:
