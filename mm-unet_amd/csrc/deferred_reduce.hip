@@ -35,6 +35,66 @@ __device__ void job_gemm_nt(const long *row, int blk, float (*sums)[16][64]) {
     const long n = row[4];
     const int slabs = (int)row[5], rows = (int)(row[6] >> 32), cols = (int)(row[6] & 0xffffffff);
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if ((n & 3) == 0 && REP == 8) {
+        // four consecutive results per lane (16-byte loads: a quarter of the load instructions), two such groups per thread;
+        // every result still adds its slabs k = g, g + 16, ... in the same order
+        float4 (*sums4)[16][64] = reinterpret_cast<float4 (*)[16][64]>(&sums[0][0][0]);   // [2][16][64] float4 = the same 32 KB
+        const long b4 = (long)blk * (64 * REP) + o * 4;
+        float4 s4[2];
+        s4[0] = s4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = g;
+        for (; k + 48 < slabs; k += 64) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const long i = b4 + r * 256;
+                if (i < n) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(part + (long)k * n + i);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(part + (long)(k + 16) * n + i);
+                    const float4 v2 = *reinterpret_cast<const float4 *>(part + (long)(k + 32) * n + i);
+                    const float4 v3 = *reinterpret_cast<const float4 *>(part + (long)(k + 48) * n + i);
+                    s4[r].x += v0.x; s4[r].x += v1.x; s4[r].x += v2.x; s4[r].x += v3.x;
+                    s4[r].y += v0.y; s4[r].y += v1.y; s4[r].y += v2.y; s4[r].y += v3.y;
+                    s4[r].z += v0.z; s4[r].z += v1.z; s4[r].z += v2.z; s4[r].z += v3.z;
+                    s4[r].w += v0.w; s4[r].w += v1.w; s4[r].w += v2.w; s4[r].w += v3.w;
+                }
+            }
+        }
+        for (; k < slabs; k += 16) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const long i = b4 + r * 256;
+                if (i < n) {
+                    const float4 v = *reinterpret_cast<const float4 *>(part + (long)k * n + i);
+                    s4[r].x += v.x; s4[r].y += v.y; s4[r].z += v.z; s4[r].w += v.w;
+                }
+            }
+        }
+        sums4[0][g][o] = s4[0];
+        sums4[1][g][o] = s4[1];
+        __syncthreads();
+        if (g < 2) {
+            const long i = b4 + g * 256;
+            if (i < n) {
+                float4 t = sums4[g][0][o];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) {
+                    const float4 v = sums4[g][q][o];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                const float tv[4] = {t.x, t.y, t.z, t.w};
+                if (row[7]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const long ii = i + j, r = ii / cols, q = ii - r * cols;
+                        c[q * rows + r] = tv[j];
+                    }
+                } else {
+                    *reinterpret_cast<float4 *>(c + i) = t;
+                }
+            }
+        }
+        return;
+    }
     const long base = (long)blk * (64 * REP) + o;
     float s[REP];
 #pragma unroll
