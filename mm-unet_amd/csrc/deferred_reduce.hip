@@ -153,7 +153,19 @@ __device__ void job_conv3x3s(const long *row, int blk) {
         idx[r] = live[r] ? idx[r] : Cin * NV4 - 1;
         s[r] = 0.f;
     }
-    for (int k = sub; k < nblk; k += 16) {
+    int k = sub;
+    for (; k + 48 < nblk; k += 64) {     // four partial rows in flight per result, added in the same order
+        float v[4][REP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < REP; ++r) v[u][r] = part[(long)(k + 16 * u) * Cin * NV4 + idx[r]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < REP; ++r) s[r] += v[u][r];
+    }
+    for (; k < nblk; k += 16) {
 #pragma unroll
         for (int r = 0; r < REP; ++r) s[r] += part[(long)k * Cin * NV4 + idx[r]];
     }
@@ -212,7 +224,20 @@ __device__ void job_rows(const long *row, int blk, float (*sums)[16][64]) {
     float s[REP];
 #pragma unroll
     for (int r = 0; r < REP; ++r) s[r] = 0.f;
-    for (int k = g; k < nparts; k += 16) {
+    int k = g;
+    for (; k + 48 < nparts; k += 64) {   // four partial rows in flight per result, added in the same order
+        float v[4][REP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < REP; ++r)
+                v[u][r] = base + r * 64 < ntot ? part[(long)(k + 16 * u) * stride + base + r * 64] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < REP; ++r) s[r] += v[u][r];
+    }
+    for (; k < nparts; k += 16) {
 #pragma unroll
         for (int r = 0; r < REP; ++r)
             if (base + r * 64 < ntot) s[r] += part[(long)k * stride + base + r * 64];
@@ -331,7 +356,15 @@ __device__ void job_scan(const long *row, int d, float *red /* 1024 */, float *t
             float s = 0.f;
             if (sl < n_slices && j < M) {
                 const int r0 = sl * 512, r1 = min(r0 + 512, BT);
-                for (int bt = r0 + r; bt < r1; bt += 8) s += part[((long)bt * dim + d) * M + j];
+                int bt = r0 + r;
+                for (; bt + 56 < r1; bt += 64) {        // eight loads in flight, added in the same order
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = part[((long)(bt + 8 * u) * dim + d) * M + j];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; bt < r1; bt += 8) s += part[((long)bt * dim + d) * M + j];
             }
             red[threadIdx.x] = s;
             __syncthreads();
