@@ -112,9 +112,13 @@ class TrainStep:
             self._scope = deferred.Scope(dev)
             self._scope.reserve()
         self._adamw = None
-        if whole and self.multi_tensor_adamw and adamw_multi.supported(self.optimizer) and \
+        # (several ranks: the gradients are static storage too -- the same two launches run after the all-reduce, outside
+        #  the graph, instead of optimizer.step()'s 41; only with the learning rate as a device tensor, which a scheduler
+        #  updates in place)
+        if self.multi_tensor_adamw and adamw_multi.supported(self.optimizer) and \
                 all(isinstance(s.get("step"), torch.Tensor) and s["step"].is_cuda for s in self.optimizer.state.values()) \
-                and len(self.optimizer.state) > 0:
+                and len(self.optimizer.state) > 0 and \
+                (whole or all(isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda for g in self.optimizer.param_groups)):
             self._adamw = adamw_multi.MultiTensorAdamW(self.optimizer)
             self._adamw.reserve()
         with torch.cuda.graph(self._graph):
@@ -126,6 +130,8 @@ class TrainStep:
                 else:
                     self.optimizer.step()
         if self._adamw is not None:
+            if not whole:
+                self._adamw.plan()             # (the parameters the captured backward has given gradients)
             self._adamw.bind()                 # addresses into the table the captured launches read
         if self._scope is not None:
             self._scope.bind()                 # (the same for the deferred reductions' job table)
@@ -164,7 +170,10 @@ class TrainStep:
         self._graph.replay()
         if not self._whole:
             self.reducer.finish()
-            self.optimizer.step()
+            if self._adamw is not None:
+                self._adamw.launch()
+            else:
+                self.optimizer.step()
         return self._loss
 
 
