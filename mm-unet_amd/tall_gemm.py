@@ -7,11 +7,12 @@ per call (measured on MI355X; 44 MMConv blocks x 3 such products per step).  flo
 token-contraction matrix-core kernel (csrc/gemm_nt_splitk.hip: both layouts read in place, ordered slab sums);
 other dtypes split T into slabs as one strided batched GEMM + a small sum.
 """
+import contextlib
 import os
 
 import torch
 
-from . import _lib, mfma_gemm
+from . import _lib, deferred, mfma_gemm
 
 _SLAB = 2048
 _NT_MIN = int(os.environ.get("MMUNET_GEMM_NT_MIN_TOKENS", str(4 * _SLAB)))   # fewer tokens: one library GEMM
@@ -165,6 +166,11 @@ class _ProjBclFn(torch.autograd.Function):
     def forward(ctx, W, X, to_cb):
         B, I, L = X.shape
         O = W.shape[0]
+        # May the weight gradient's final sum wait for a deferred.Scope's launch?  Only if nothing reads it during the
+        # backward pass: W is a parameter, or a view of one (view backward ops move no data).  A COPY of a parameter
+        # (morph_mix's permuted, padded weight) has its gradient sliced / permuted / cloned by autograd on the spot.
+        base = W._base if W._is_view() else None
+        ctx.defer_dw = bool(W.is_leaf or (base is not None and base.is_leaf and W.is_contiguous()))
         if to_cb:
             out = torch.empty((O, B, L), device=X.device, dtype=X.dtype).permute(1, 0, 2)   # [O][B][L]
         else:
@@ -206,10 +212,12 @@ class _ProjBclFn(torch.autograd.Function):
             if (G.stride(2) == 1 and X.stride(2) == 1 and mfma_gemm.nt_supported(G, X, L) and B * L >= _NT_MIN
                     and all(t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 for t in (G, X))):
                 # both layouts addressed in place: no transposing copy of the batch-major operand
-                dW = mfma_gemm.gemm_nt(G, X, W.shape[0], I, B, L, G.stride(1), G.stride(0), X.stride(1),
-                                       X.stride(0)).to(W.dtype)
+                with (contextlib.nullcontext() if ctx.defer_dw else deferred.paused()):
+                    dW = mfma_gemm.gemm_nt(G, X, W.shape[0], I, B, L, G.stride(1), G.stride(0), X.stride(1),
+                                           X.stride(0)).to(W.dtype)
             else:
-                dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(X)).to(W.dtype)
+                with (contextlib.nullcontext() if ctx.defer_dw else deferred.paused()):
+                    dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(X)).to(W.dtype)
         return dW, dX, None
 
 

@@ -1018,8 +1018,11 @@ def test_train_step_vs_oracle_side_step():
         assert torch.equal(after[k].detach().cpu(), sd0[k]), k
 
 
-def test_train_step_graph_replay_matches_eager():
-    """HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) against the eager step.  The learning rate is 0,
+@pytest.mark.parametrize("size", [64, 256])
+def test_train_step_graph_replay_matches_eager(size):
+    """(size 256: maps up to 128 x 128 -- the matrix-core GEMMs with their deferred split sums, the mix-first blocks, the
+    512-token scan tiles and the streaming forward are all taken, as at the benchmark's 512 x 512.)
+    HIP-graph replay of the whole step (fwd + loss + bwd + AdamW) against the eager step.  The learning rate is 0,
     so the weights never move and every step's gradient is a function of the step's batch alone; what is compared
     is AdamW's state after 2 eager warm-up steps + 2 replays -- the exponential averages of the gradients and of
     their squares, i.e. every gradient the replayed backward produced.  A stale input buffer or a gradient that is
@@ -1030,8 +1033,8 @@ def test_train_step_graph_replay_matches_eager():
     from mm_unet_amd.loss import DICE_BCE_Loss
     from mm_unet_amd.train_step import TrainStep, make_optimizer
     gen = torch.Generator().manual_seed(3)
-    xs = [torch.randn(2, 3, 64, 64, generator=gen).to(DEV) for _ in range(4)]
-    ts = [(torch.rand(2, 1, 64, 64, generator=gen) > 0.88).float().to(DEV) for _ in range(4)]
+    xs = [torch.randn(2, 3, size, size, generator=gen).to(DEV) for _ in range(4)]
+    ts = [(torch.rand(2, 1, size, size, generator=gen) > 0.88).float().to(DEV) for _ in range(4)]
     losses, state, w0 = {}, {}, None
     for mode in ("eager", "graph"):
         m = _mmnet().eval()           # (running statistics: the batch-statistics path amplifies the atomics' noise)
@@ -1063,9 +1066,11 @@ def test_train_step_graph_replay_matches_eager():
     for k, (ea, _) in state["eager"].items():
         ga = state["graph"][k][0]
         nk = float(ea.double().norm())
+        rel = float((ea - ga).double().norm()) / max(nk, 1e-30)
         if nk > 1e-2 * total:   # tensors that carry a visible share of the gradient
-            rel = float((ea - ga).double().norm()) / nk
             assert rel < 0.2, f"{k}: exp_avg differs by {rel:.1%} between eager and graph replay"
+        elif nk > 1e-3 * total:  # smaller ones: a gradient of the WRONG step (every step has its own batch) is ~100 % off
+            assert rel < 0.5, f"{k}: exp_avg differs by {rel:.1%} between eager and graph replay"
     assert (num / den) ** 0.5 < 0.02, f"gradient averages differ by {(num / den) ** 0.5:.2%} overall"
     assert (num2 / den2) ** 0.5 < 0.05, f"squared-gradient averages differ by {(num2 / den2) ** 0.5:.2%} overall"
 
@@ -1776,6 +1781,43 @@ def test_deferred_scan_parameter_gradient_sums_are_bit_identical(case):
                 close(ref[2], run(False, False)[2] * A, 1e-6, 1e-7, "dA * A")
     finally:
         os.environ.pop("MMU_SCAN_BWD_W8", None)
+
+
+def test_mix_first_weight_gradient_is_not_read_before_the_deferred_sum():
+    """Regression: morph_mix.dsc_mix_first multiplies with a permuted, padded COPY of the convolution weight, so autograd
+    post-processes that copy's gradient (slice, permute, a cloning AccumulateGrad) during the backward pass -- it must not
+    be one of the sums a deferred.Scope runs afterwards, or the clone reads the buffer before it is written (inside the
+    captured training step: the previous step's values).  Two backward passes with different cotangents inside scopes,
+    each against its own immediate result."""
+    from mm_unet_amd import deferred, morph_mix
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    B, C, O, H, W, K = 2, 64, 16, 128, 128, 3
+    x = torch.randn(B, C, H, W, device=DEV, generator=gen)
+    y = torch.rand(B, K, H, W, device=DEV, generator=gen) * (H - 1)
+    conv = torch.nn.Conv2d(C, O, (K, 1), stride=(K, 1)).to(DEV)
+    assert morph_mix.wanted(x, conv, K)
+
+    def run(g, scoped):
+        conv.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        scope = deferred.Scope(DEV) if scoped else contextlib.nullcontext()
+        with scope:
+            out = morph_mix.dsc_mix_first(xi, y, conv)
+            out.backward(g)
+            if scoped:
+                scope.launch()
+        torch.cuda.synchronize()
+        return conv.weight.grad.clone(), xi.grad.clone()
+
+    import contextlib
+    for seed in (1, 2):
+        g = torch.randn(B, O, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        ref_w, ref_x = run(g, False)
+        got_w, got_x = run(g, True)
+        assert float(ref_w.abs().max()) > 0
+        # (run to run the sampler's float atomics move the last bits; a gradient read too early is O(1) off)
+        close(got_w, ref_w, 1e-4, 1e-5 * float(ref_w.abs().max()), f"cotangent {seed}: weight gradient read before the deferred sum")
+        close(got_x, ref_x, 1e-4, 1e-5 * float(ref_x.abs().max()), "d x")
 
 
 def test_deferred_conv_weight_gradient_sums_are_bit_identical():
