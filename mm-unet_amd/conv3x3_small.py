@@ -7,6 +7,8 @@ NCHW; the input (and its gradient) float32 or bfloat16 -- bf16 activations under
 arithmetic, the weights and the 6-channel output are float32 (more exact than autocast's bf16 convolution, and
 the output feeds a GroupNorm that autocast runs in float32 anyway); anything else is the caller's ``F.conv2d``.
 """
+import os
+
 import torch
 
 from . import _lib, deferred
@@ -21,6 +23,19 @@ ENABLED = True   # False: callers keep their nn.Conv2d call (fused_paths.plain_a
 def supported(x, weight):
     return (ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32 and x.dim() == 4
             and weight.shape[2:] == (3, 3) and weight.shape[0] in SUPPORTED_CO)
+
+
+# False (MMUNET_GRAD_HANDOVER=0): no gradient hand-over slots are created -- every consumer returns its input gradient to
+# autograd, which adds them (the same kernels otherwise: tools/dbg/handover_vs_autograd.py compares the two at full size)
+HANDOVER = os.environ.get("MMUNET_GRAD_HANDOVER", "1") != "0"
+
+
+def grad_slot():
+    return GradSlot() if HANDOVER else None
+
+
+def shared_grad():
+    return SharedGrad() if HANDOVER else None
 
 
 class GradSlot:

@@ -145,7 +145,7 @@ class MMConv(nn.Module):
                 # small maps (16 x 16, 32 x 32): the whole chain below as ONE kernel each way
                 return mamba_small_fused.mamba_rows(offset, m, self.altho, self.extend_scope, A=neg_exp(m.A_log),
                                                     combine=combine)
-            oslot = morph_coords.OffsetGradSlot()   # the two consumers of the offsets hand their d(offset) over
+            oslot = morph_coords.OffsetGradSlot() if conv3x3_small.HANDOVER else None   # the two consumers of the offsets hand their d(offset) over
             xz = morph_coords.zigzag_inproj(offset, m.in_proj.weight, oslot)
             out_z = mamba_inner_fn_no_out_proj(xz, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight,
                                                m.dt_proj.weight, neg_exp(m.A_log), None, None,
@@ -174,7 +174,7 @@ class MMConv(nn.Module):
         # the offset convolution and the sampler both read `input`: their input gradients leave as one (GradSlot; a caller
         # whose `input` has a third consumer -- ResidualBlock's shortcut -- passes the slot it parks that gradient in)
         if slot is None:
-            slot = conv3x3_small.GradSlot() if input.requires_grad and torch.is_grad_enabled() else None
+            slot = conv3x3_small.grad_slot() if input.requires_grad and torch.is_grad_enabled() else None
         raw = self._offset_conv(input, slot)
         if norm_fused.supported(raw, self.gn_offset):
             # GroupNorm -> tanh in 2 passes; float32 also under autocast (coordinates: the reference's group_norm and
@@ -319,8 +319,8 @@ class CBAM(nn.Module):
         # hand-overs of the backward pass (no activation-sized gradient adds): x feeds the pooled statistics and the
         # first product; y1 the spatial statistics and the second product
         share = fused and pointwise.GATED_MUL and torch.is_grad_enabled() and x.requires_grad
-        xs = conv3x3_small.SharedGrad() if share else None
-        ss = pointwise.ChannelStatsSlot() if share else None
+        xs = conv3x3_small.shared_grad() if share else None
+        ss = pointwise.ChannelStatsSlot() if (share and conv3x3_small.HANDOVER) else None
         if fused:    # mean and max (+ arg-max) in one pass each way (csrc/cbam_stats.hip)
             x_avg, x_max = pointwise.pixel_mean_max(x, xs)
         else:
@@ -421,11 +421,11 @@ class ResidualBlock(nn.Module):
         if not self.downsample:
             # x feeds block1's first MMConv (offset convolution + sampler: one GradSlot) and the residual add: the
             # residual's gradient rides along in that slot instead of being added by autograd
-            slot = conv3x3_small.GradSlot() if (torch.is_grad_enabled() and x.requires_grad) else None
+            slot = conv3x3_small.grad_slot() if (torch.is_grad_enabled() and x.requires_grad) else None
             return run_fused(self.block1, x, residual=x, first_slot=slot)
         # x feeds the 3 x 3 stride-2 convolution and the 1 x 1 stride-2 shortcut: the shortcut's backward adds its even
         # pixels to the gradient the other one left (conv3x3_small.SharedGrad) instead of autograd adding two tensors
-        slot = conv3x3_small.SharedGrad() if (torch.is_grad_enabled() and x.requires_grad) else None
+        slot = conv3x3_small.shared_grad() if (torch.is_grad_enabled() and x.requires_grad) else None
         shortcut = run_fused(self.block2, x, in_slot=slot)
         return run_fused(self.block1, conv3x3_small.shared_input(x, slot), residual=shortcut)
 
@@ -489,7 +489,7 @@ class MM_Net(nn.Module):
         # e1 feeds the max-pool and CBAM, the edge map c1 three RCG blocks and the line head: their input gradients are
         # handed from consumer to consumer (conv3x3_small.SharedGrad) instead of added by autograd
         share = torch.is_grad_enabled() and e1.requires_grad
-        s1 = conv3x3_small.SharedGrad() if share else None
+        s1 = conv3x3_small.shared_grad() if share else None
         e2 = self.encoder2(maxpool_op.pool_module(self.maxpool, e1, s1))
         e3 = self.encoder3(e2)
         e4 = self.encoder4(e3)
@@ -498,7 +498,7 @@ class MM_Net(nn.Module):
         d5 = self.decoder5(e5)
         out5 = self.side5(d5)
         c1 = run_fused(self.cbam, conv3x3_small.shared_input(e1, s1))   # contour branch on the stride-2 stem features
-        sc = conv3x3_small.SharedGrad() if share else None
+        sc = conv3x3_small.shared_grad() if share else None
         p_c = _small_conv3x3(self.line_predict, c1, sc)
         r4 = self.rcg4(out5, c1, e4, sc)
         d4 = self.decoder4(torch.cat((d5, r4), dim=1))
