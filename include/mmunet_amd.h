@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 5
+#define MMU_ABI_VERSION 6
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -121,6 +121,10 @@ typedef struct {
     int64_t dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
     int32_t dA_times_A;      /* non-zero: dA receives dA * A, the gradient of a parameter a with A = -exp(a) (Mamba's A_log,
                               * mamba_simple.py:209); needs a contiguous A.  0: dA as the reference returns it */
+    const void *out;         /* optional (ABI 6): the forward's `out` = y before gating, [batch, dim, L] strides (out_bs, out_ds, 1),
+                              * what the reference's backward reads (selective_scan.cpp:338 `out_`, selective_scan_bwd_kernel.cuh:
+                              * dz and the recomputed out_z come from it).  NULL: y is recomputed from the states. */
+    int64_t out_bs, out_ds;
 } mmu_scan_bwd_params;
 
 int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream);

@@ -37,7 +37,7 @@ class ScanBwdParams(ctypes.Structure):
                                "du_bs", "du_ds", "ddelta_bs", "ddelta_ds", "dz_bs", "dz_ds", "out_z_bs",
                                "out_z_ds", "A_ds", "A_ns", "B_bs", "B_gs", "B_ns", "C_bs", "C_gs", "C_ns",
                                "dB_bs", "dB_gs", "dB_ns", "dC_bs", "dC_gs", "dC_ns")]
-        + [("dA_times_A", _i32)]
+        + [("dA_times_A", _i32), ("out", _vp), ("out_bs", _i64), ("out_ds", _i64)]
     )
 
 
@@ -224,7 +224,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 5   # = MMU_ABI_VERSION of include/mmunet_amd.h
+ABI_VERSION = 6   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():

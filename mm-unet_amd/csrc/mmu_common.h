@@ -242,6 +242,7 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
 }
 
 #define MMU_DPP_ROW_SHR(n) (0x110 + (n))
+#define MMU_DPP_ROW_SHL(n) (0x100 + (n))
 #define MMU_DPP_WAVE_SHR1 0x138
 #define MMU_DPP_ROW_BCAST15 0x142
 #define MMU_DPP_ROW_BCAST31 0x143
@@ -305,6 +306,27 @@ __device__ __forceinline__ void wave_scan_affine_x2(float &P0, float &S0, float 
                  : "+v"(P0), "+v"(S0), "+v"(P1), "+v"(S1));
 }
 
+// The same inside each 16-lane DPP row only (four steps): prefix (row_shr) and suffix (row_shl) forms.  A row is one
+// 128-token chunk at 8 tokens per lane; the chunk carries come from memory (selective_scan_bwd_w8.hip).
+__device__ __forceinline__ void row_scan_affine_x2(float &P0, float &S0, float &P1, float &S1) {
+    asm volatile("s_nop 1\n\t"
+                 MMU_SCAN2_STEP("row_shr:1", "0xf")
+                 MMU_SCAN2_STEP("row_shr:2", "0xf")
+                 MMU_SCAN2_STEP("row_shr:4", "0xf")
+                 MMU_SCAN2_STEP("row_shr:8", "0xf")
+                 "s_nop 1"
+                 : "+v"(P0), "+v"(S0), "+v"(P1), "+v"(S1));
+}
+__device__ __forceinline__ void row_rscan_affine_x2(float &P0, float &S0, float &P1, float &S1) {
+    asm volatile("s_nop 1\n\t"
+                 MMU_SCAN2_STEP("row_shl:1", "0xf")
+                 MMU_SCAN2_STEP("row_shl:2", "0xf")
+                 MMU_SCAN2_STEP("row_shl:4", "0xf")
+                 MMU_SCAN2_STEP("row_shl:8", "0xf")
+                 "s_nop 1"
+                 : "+v"(P0), "+v"(S0), "+v"(P1), "+v"(S1));
+}
+
 #define MMU_SCAN1_STEP(ctrl, mask)                                                         \
     "v_fmac_f32_dpp %1, %1, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"               \
     "v_mul_f32_dpp %0, %0, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                \
@@ -351,7 +373,6 @@ __device__ __forceinline__ float row_scan_add_up(float v) {  // lane l gets sum 
     v += dpp_mov<MMU_DPP_ROW_SHR(8), 0xf>(0.f, v);
     return v;
 }
-#define MMU_DPP_ROW_SHL(n) (0x100 + (n))
 __device__ __forceinline__ float row_scan_add_down(float v) {  // lane l gets sum over lanes >= l of its row
     v += dpp_mov<MMU_DPP_ROW_SHL(1), 0xf>(0.f, v);
     v += dpp_mov<MMU_DPP_ROW_SHL(2), 0xf>(0.f, v);

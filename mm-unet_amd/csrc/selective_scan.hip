@@ -1829,6 +1829,9 @@ extern "C" int mmu_selective_scan_bwd(const mmu_scan_bwd_params *p, void *stream
     a.u = p->u; a.delta = p->delta; a.z = p->z; a.B = p->B; a.C = p->C; a.A = p->A; a.D = p->D;
     a.delta_bias = p->delta_bias; a.dout = p->dout; a.x = const_cast<float *>(p->x);
     a.du = p->du; a.ddelta = p->ddelta; a.dz = p->dz; a.out_z = p->out_z; a.dB = p->dB; a.dC = p->dC;
+    // the forward's y (before gating), if it was kept: read by the w8 apply kernel instead of recomputing it (only with z:
+    // without z nothing in the backward needs y)
+    a.out = p->z ? const_cast<void *>(p->out) : nullptr; a.out_bs = p->out_bs; a.out_ds = p->out_ds;
     a.u_bs = p->u_bs; a.u_ds = p->u_ds; a.delta_bs = p->delta_bs; a.delta_ds = p->delta_ds;
     a.z_bs = p->z_bs; a.z_ds = p->z_ds; a.dout_bs = p->dout_bs; a.dout_ds = p->dout_ds;
     a.du_bs = p->du_bs; a.du_ds = p->du_ds; a.ddelta_bs = p->ddelta_bs; a.ddelta_ds = p->ddelta_ds;

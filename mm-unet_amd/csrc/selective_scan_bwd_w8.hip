@@ -21,7 +21,7 @@
 // One LDS-only barrier per channel; exchange buffers double-buffered by channel parity.
 //
 // grid (L / 512, batch, ngroups), block 512, one workgroup per CU (118 KiB LDS).
-// LDS (floats): xch[2][8][1632] | prep[2][3][544] | slots[8][2][8]
+// LDS (floats): xch[2][8][1632] | prep[2][3][544] | slots[8][2][24]
 //   prep rows: token T sits at ((T >> 2) & 1) * 288 + (T >> 3) * 4 + (T & 3): a lane's two float4 groups are
 //   contiguous across lanes (b128 reads), the per-token dword writes fall in 64 distinct banks.
 //   xch row of a wave: (q, dd) pairs of token T at ((T >> 1) & 3) * 272 + (T >> 3) * 4 + (T & 1) * 2 (b128 writes of
@@ -48,15 +48,18 @@ __device__ unsigned long long g_w8_stamps[2 * 8 * 8 * 8];  // [block sel][wave][
 
 namespace {
 
-constexpr int W8_TT = 512, W8_AS = 544, W8_SUB = 288, W8_XS = 1632, W8_SUB2 = 272;
+constexpr int W8_TT = 512, W8_AS = 544, W8_SUB = 272, W8_XS = 1632, W8_SUB2 = 272;
 
 template <typename io_t>
 __device__ __forceinline__ float ld1(const io_t *p) { return to_f32(*p); }
 template <typename io_t>
 __device__ __forceinline__ void st1(io_t *p, float v) { *p = from_f32<io_t>(v); }
 
-template <typename io_t, bool HAS_Z, bool HAS_OZ>
+// Y_IN: the forward's y (before gating) is read from p.out instead of being recomputed: no C h products, no y row in
+// the exchange (a third of its LDS traffic), no eight-wave sum per token.
+template <typename io_t, bool HAS_Z, bool HAS_OZ, bool Y_IN>
 __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) {
+    static_assert(HAS_Z || !Y_IN, "y is only needed with z");
     constexpr int N = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = blockIdx.x, b = blockIdx.y;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
     const int t0 = tile * W8_TT, c0 = tile * 4, n_tiles = gridDim.x;
     float *xch = smem;                                   // [2][8][XS]
     float *prep = smem + 2 * 8 * W8_XS;                  // [2][3][AS]
-    float *slots = prep + 2 * 3 * W8_AS + w * 16;        // [8][2][8]: A2 pair | h0 pair | g0 pair | bias | D
+    float *slots = prep + 2 * 3 * W8_AS + w * 48;        // [8][2][24]: A2 pair | bias | D | h0 pair x 4 rows | g0 pair x 4 rows
     const int dpg = p.dim / p.ngroups, cps = (dpg + p.d_splits - 1) / p.d_splits;   // host: no range is empty
     const int dbeg = g * dpg + sp * cps, dend = min(dbeg + cps, (g + 1) * dpg);
     const unsigned T = w * 64 + lane;                    // the token this lane prepares and finishes
@@ -100,46 +103,58 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
     const io_t *f_u = (const io_t *)p.u + (long)b * p.u_bs + (long)dbeg * p.u_ds + t0 + T;
     const io_t *f_go = (const io_t *)p.dout + (long)b * p.dout_bs + (long)dbeg * p.dout_ds + t0 + T;
     const io_t *f_z = HAS_Z ? (const io_t *)p.z + (long)b * p.z_bs + (long)dbeg * p.z_ds + t0 + T : nullptr;
+    const io_t *f_y = Y_IN ? (const io_t *)p.out + (long)b * p.out_bs + (long)dbeg * p.out_ds + t0 + T : nullptr;
     io_t *o_du = (io_t *)p.du + (long)b * p.du_bs + (long)dbeg * p.du_ds + t0 + T;
     io_t *o_dd = (io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)dbeg * p.ddelta_ds + t0 + T;
     io_t *o_dz = HAS_Z ? (io_t *)p.dz + (long)b * p.dz_bs + (long)dbeg * p.dz_ds + t0 + T : nullptr;
     io_t *o_oz = HAS_OZ ? (io_t *)p.out_z + (long)b * p.out_z_bs + (long)dbeg * p.out_z_ds + t0 + T : nullptr;
+    // one opaque 64-bit register pair per stream: left visible, the bf16 build splits each into a uniform base (kept in
+    // VGPRs: the scalar file is full) plus a lane offset -- 12 more VGPRs, 20 spilled, 18 v_mov_b64 per two channels
+    asm volatile("" : "+v"(f_dl), "+v"(f_u), "+v"(f_go), "+v"(f_z), "+v"(f_y));
+    asm volatile("" : "+v"(o_du), "+v"(o_dd), "+v"(o_dz), "+v"(o_oz));
     float *part8 = p.part + (((long)b * n_tiles + tile) * p.dim + dbeg) * 32 + w * 4 + ((lane - 12) & 3);
-    const bool hasH = c0 > 0, hasG = c0 + 4 < p.n_chunks;
-
-    // the 8 scalars of a channel (A pair, forward / adjoint carry-in pair, bias, D): one gathered load, lane j < 8
-    // owns one of them as base + channel * stride; the other lanes re-read lane 0's word
-    const int jj = lane < 8 ? lane : 0;
+    // the 20 scalars of a channel: A pair, bias, D, and the carries of the wave's state pair at the four 128-token
+    // chunks of the tile -- h entering chunk c0 + r from the left (the forward's chunk states x), the adjoint entering
+    // it from the right (the carried reverse aggregates gx): every 16-lane DPP row is one chunk, so both cross-lane
+    // scans stay inside a row (4 steps, no lane reversal).  One gathered load: lane j < 20 owns one scalar as
+    // base + channel * stride; the other lanes re-read lane 0's word.
+    const int jj = lane < 20 ? lane : 0;
     const float *gbase = p.A + (long)(n0 + (jj & 1)) * p.A_ns;
     unsigned gstride = (unsigned)p.A_ds;
     float gscale = MMU_LOG2E;
-    if (jj >= 2 && jj < 4) {
-        gbase = p.x + ((long)b * p.dim * p.n_chunks + (hasH ? c0 - 1 : 0)) * 2 * N + 2 * (n0 + (jj & 1)) + 1;
-        gstride = (unsigned)p.n_chunks * 2 * N;
-        gscale = hasH ? 1.f : 0.f;
-    } else if (jj >= 4 && jj < 6) {
-        gbase = p.gx + ((long)b * p.dim * p.n_chunks + (hasG ? c0 + 4 : 0)) * 2 * N + 2 * (n0 + (jj & 1)) + 1;
-        gstride = (unsigned)p.n_chunks * 2 * N;
-        gscale = hasG ? 1.f : 0.f;
-    } else if (jj == 6) {
+    if (jj == 2) {
         gbase = p.delta_bias ? p.delta_bias : p.A;
         gstride = p.delta_bias ? 1u : 0u;
         gscale = p.delta_bias ? 1.f : 0.f;
-    } else if (jj == 7) {
+    } else if (jj == 3) {
         gbase = p.D ? p.D : p.A;
         gstride = p.D ? 1u : 0u;
         gscale = p.D ? 1.f : 0.f;
+    } else if (jj >= 4 && jj < 12) {
+        const int cc = c0 + ((jj - 4) >> 1) - 1;
+        gbase = p.x + ((long)b * p.dim * p.n_chunks + (cc >= 0 ? cc : 0)) * 2 * N + 2 * (n0 + (jj & 1)) + 1;
+        gstride = (unsigned)p.n_chunks * 2 * N;
+        gscale = cc >= 0 ? 1.f : 0.f;
+    } else if (jj >= 12) {
+        const int cc = c0 + ((jj - 12) >> 1) + 1;
+        gbase = p.gx + ((long)b * p.dim * p.n_chunks + (cc < p.n_chunks ? cc : 0)) * 2 * N + 2 * (n0 + (jj & 1)) + 1;
+        gstride = (unsigned)p.n_chunks * 2 * N;
+        gscale = cc < p.n_chunks ? 1.f : 0.f;
     }
+    const int row = lane >> 4;
+    const bool rl0 = (lane & 15) == 0, rl15 = (lane & 15) == 15;
 
     // ---- per-token pipeline: raw loads (two channels ahead) -> prepared values (one channel ahead) ----------
     const float *gp = gbase + (unsigned long)dbeg * gstride;
-    struct Raw { float dl, u, go, z, gv; };   // one channel's loads in flight; two sets, alternating by channel parity
+    struct Raw { float dl, u, go, z, y, gv; };   // one channel's loads in flight; two sets, alternating by channel parity
     auto fetch = [&](Raw &r) {
         r.dl = ld1(f_dl);
         r.u = ld1(f_u);
         r.go = ld1(f_go);
         r.z = 0.f;
         if constexpr (HAS_Z) r.z = ld1(f_z);
+        r.y = 0.f;
+        if constexpr (Y_IN) r.y = ld1(f_y);
         r.gv = *gp;
     };
     auto advance_fetch = [&]() {   // to the next channel (uniform pointers: scalar adds)
@@ -147,20 +162,22 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
         f_u += p.u_ds;
         f_go += p.dout_ds;
         if constexpr (HAS_Z) f_z += p.z_ds;
+        if constexpr (Y_IN) f_y += p.out_ds;
         gp += gstride;
     };
     // what the finishing step of a channel needs of its token
-    struct Tok { float dl, u, dy, dsp, F, G, D; };
+    struct Tok { float dl, u, dy, dsp, F, G, D, y; };
     auto prepare = [&](int par, const Raw &r, Tok &k) {   // a channel's loads -> prep[par], slots[par], k
         const float r_dl = r.dl, r_u = r.u, r_go = r.go, r_z = r.z;
         const float gvs = r.gv * gscale;
-        if (lane < 8) slots[par * 8 + lane] = gvs;
-        const float bias = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gvs), 6));
-        k.D = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gvs), 7));
+        if (lane < 20) slots[par * 24 + lane] = gvs;
+        const float bias = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gvs), 2));
+        k.D = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gvs), 3));
         const float vraw = r_dl + bias;
         k.dl = p.softplus ? softplus_thr(vraw) : vraw;
         k.dsp = (p.softplus && vraw <= 20.f) ? sigmoidf_(vraw) : 1.f;   // bwd_kernel.cuh:439-453
         k.u = r_u;
+        k.y = r.y;
         if constexpr (HAS_Z) {
             const float zs = sigmoidf_(r_z);
             k.G = r_z * zs;                                  // out_z = y * G ; dy = dout * G
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
 #pragma unroll
         for (int wv = 0; wv < 8; ++wv) {
             f.qd[wv] = *reinterpret_cast<const v2f *>(xc + wv * W8_XS + posT2);
-            if constexpr (HAS_Z) f.y[wv] = xc[wv * W8_XS + 4 * W8_SUB2 + posT];
+            if constexpr (HAS_Z && !Y_IN) f.y[wv] = xc[wv * W8_XS + 4 * W8_SUB2 + posT];
         }
     };
     auto finish_done = [&](const Fin &f, const Tok &k, v2f dA) {
@@ -225,8 +242,13 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
         st1(o_du, du);
         st1(o_dd, ddel);
         if constexpr (HAS_Z) {
-            const float Y = ((f.y[0] + f.y[1]) + (f.y[2] + f.y[3])) + ((f.y[4] + f.y[5]) + (f.y[6] + f.y[7]));
-            const float yt = fmaf(k.D, k.u, Y);
+            float yt;
+            if constexpr (Y_IN) {
+                yt = k.y;   // the forward's out already holds D u
+            } else {
+                const float Y = ((f.y[0] + f.y[1]) + (f.y[2] + f.y[3])) + ((f.y[4] + f.y[5]) + (f.y[6] + f.y[7]));
+                yt = fmaf(k.D, k.u, Y);
+            }
             st1(o_dz, yt * k.F);
             if constexpr (HAS_OZ) st1(o_oz, yt * k.G);
         }
@@ -247,6 +269,16 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
     auto channel = [&](auto PAR, auto FIN, Tok &prv_nxt, Raw &raw) {
         constexpr int par = decltype(PAR)::value;
         constexpr bool fin = decltype(FIN)::value;
+        // (Measured and dropped in round 4: issuing the finishing reads behind this channel's reads and consuming them
+        // behind its 16 exps -- 1,066 vs 1,066 us, 6 more VGPRs.)
+#ifndef MMU_W8_PRIO
+#define MMU_W8_PRIO 1
+#endif
+        // VALU issue goes to the OLDER of the two waves of a SIMD (waves 0-3): it runs its channel at nearly the
+        // single-wave rate (3,000 cycles) and then waits 1,400 at the barrier while the younger one, starved until then,
+        // finishes alone at 0.7 of the shared rate (stamps, round 4).  The younger half leads through the first half
+        // of the channel (finish + recompute + scans) and hands the lead back for the walk: both arrive together.
+        if (MMU_W8_PRIO && w >= 4) __builtin_amdgcn_s_setprio(1);
         if constexpr (fin) {
             Fin fbuf;
             finish_issue(std::integral_constant<int, par ^ 1>{}, fbuf);
@@ -254,9 +286,9 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
         }
         W8_STAMP(0);
         // ---- this channel's scalars and prepared per-token values ------------------------------------
-        const float4 sA = *reinterpret_cast<const float4 *>(slots + par * 8);
-        const float4 sB = *reinterpret_cast<const float4 *>(slots + par * 8 + 4);
-        const v2f a2 = v2f{sA.x, sA.y}, h0 = v2f{sA.z, sA.w}, g0 = v2f{sB.x, sB.y};
+        const v2f a2 = *reinterpret_cast<const v2f *>(slots + par * 24);
+        const v2f h0 = *reinterpret_cast<const v2f *>(slots + par * 24 + 4 + 2 * row);    // this row's chunk: state entering it
+        const v2f g0 = *reinterpret_cast<const v2f *>(slots + par * 24 + 12 + 2 * row);   // adjoint entering it from the right
         v2f dl2[4], dlu2[4], dy2[4];
         {
             const float *pr = prep + par * (3 * W8_AS) + posL;
@@ -270,6 +302,10 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
                 dy2[2 * j] = v2f{f2.x, f2.y}; dy2[2 * j + 1] = v2f{f2.z, f2.w};
             }
         }
+#ifdef MMU_W8_STAMPS
+        asm volatile("" : "+v"(dl2[0]), "+v"(dy2[3]), "+v"(dlu2[3]));
+#endif
+        W8_STAMP(7);
         // ---- forward recompute and the two cross-lane scans -------------------------------------------
         v2f a[8], hh[8];
         float dlsum;
@@ -300,24 +336,28 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
             for (int i = 6; i >= 0; --i)
                 R = a[i] * ((i & 1) ? fma_bcast<1>(dy2[i >> 1], Cv[i], R) : fma_bcast<0>(dy2[i >> 1], Cv[i], R));
             const v2f S_in = fma2(P, h0, S), R_in = fma2(P, g0, R);
-            S = lane == 0 ? S_in : S;
-            R = lane == 63 ? R_in : R;
+            S = rl0 ? S_in : S;
+            R = rl15 ? R_in : R;
             float P0 = P.x, S0 = S.x, P1 = P.y, S1 = S.y;
-            float Q0 = wave_reverse(P.x), R0 = wave_reverse(R.x), Q1 = wave_reverse(P.y), R1 = wave_reverse(R.y);
-            wave_scan_affine_x2(P0, S0, P1, S1);
-            wave_scan_affine_x2(Q0, R0, Q1, R1);
-            h_in = v2f{wave_shift_up1(S0, h0.x), wave_shift_up1(S1, h0.y)};
+            float Q0 = P.x, R0 = R.x, Q1 = P.y, R1 = R.y;
+            row_scan_affine_x2(P0, S0, P1, S1);     // inclusive prefix inside the chunk's 16 lanes
+            row_rscan_affine_x2(Q0, R0, Q1, R1);    // inclusive suffix
+            // state entering this lane's tokens = the previous lane's prefix (the chunk carry on the row's first lane);
+            // adjoint entering from the right = the next lane's suffix (the chunk carry on the row's last lane)
+            h_in = v2f{dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(h0.x, S0), dpp_mov<MMU_DPP_ROW_SHR(1), 0xf>(h0.y, S1)};
             v2f h = h_in;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 h = fma2(a[i], h, bb[i]);
                 hh[i] = h;
             }
-            // adjoint entering this lane from the right = reversed-order inclusive R of lane + 1
-            gam.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((62 - lane) << 2, __builtin_bit_cast(int, R0)));
-            gam.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((62 - lane) << 2, __builtin_bit_cast(int, R1)));
-            gam = lane == 63 ? g0 : gam;
+            gam = v2f{dpp_mov<MMU_DPP_ROW_SHL(1), 0xf>(g0.x, R0), dpp_mov<MMU_DPP_ROW_SHL(1), 0xf>(g0.y, R1)};
         }
+#ifdef MMU_W8_STAMPS
+        asm volatile("" : "+v"(gam), "+v"(hh[7]));
+#endif
+        W8_STAMP(6);
+        if (MMU_W8_PRIO && w >= 4) __builtin_amdgcn_s_setprio(0);
         // ---- adjoint walk, right to left: gradients of this state pair -------------------------------------
         //   g_t = dy_t C_t + gamma_{t+1};  gamma_t = a_t g_t;  with q_t = sum_n g B:
         //   du = delta q + D dy;  ddelta' = u q + sum_n A (gamma_t h_{t-1});  dA = sum_t delta (gamma_t h_{t-1});
@@ -325,6 +365,7 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
         const v2f An = a2 * MMU_LN2;
         v2f dAp = v2f{0.f, 0.f};
         float qv[8], ddv[8], yv[8];
+        float *xc = xch + par * (8 * W8_XS) + w * W8_XS + posL;
 #pragma unroll
         for (int i = 7; i >= 0; --i) {
             const int k = i >> 1;
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
                 const v2f tq = gt * Bv[i], td = An * gah;
                 qv[i] = tq.x + tq.y;
                 ddv[i] = td.x + td.y;
-                if constexpr (HAS_Z) {
+                if constexpr (HAS_Z && !Y_IN) {
                     const v2f ty = Cv[i] * hh[i];
                     yv[i] = ty.x + ty.y;
                 }
@@ -343,20 +384,18 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
             dAp = (i & 1) ? fma_bcast<1>(dl2[k], gah, dAp) : fma_bcast<0>(dl2[k], gah, dAp);
             accB[i] = (i & 1) ? fma_bcast<1>(dlu2[k], gt, accB[i]) : fma_bcast<0>(dlu2[k], gt, accB[i]);
             accC[i] = (i & 1) ? fma_bcast<1>(dy2[k], hh[i], accC[i]) : fma_bcast<0>(dy2[k], hh[i], accC[i]);
+            // the exchange rows leave as soon as their tokens are done: six 128-bit LDS stores per lane take the eight
+            // waves ~600 cycles of the store path, which the rest of the walk now covers (they used to follow the loop,
+            // with every wave waiting for its last one in front of the barrier)
+            if (!(i & 1))   // tokens i, i + 1: (q, dd, q, dd)
+                *reinterpret_cast<float4 *>(xc + (i >> 1) * W8_SUB2) = make_float4(qv[i], ddv[i], qv[i + 1], ddv[i + 1]);
+            if constexpr (HAS_Z && !Y_IN) {
+                if (!(i & 3))
+                    *reinterpret_cast<float4 *>(xc + 4 * W8_SUB2 + (i >> 2) * W8_SUB) = make_float4(yv[i], yv[i + 1], yv[i + 2], yv[i + 3]);
+            }
+            if (!(i & 1)) __builtin_amdgcn_sched_barrier(0);
         }
         W8_STAMP(1);
-        {
-            float *xc = xch + par * (8 * W8_XS) + w * W8_XS + posL;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)   // tokens 2j, 2j+1: (q, dd, q, dd)
-                *reinterpret_cast<float4 *>(xc + j * W8_SUB2) = make_float4(qv[2 * j], ddv[2 * j], qv[2 * j + 1], ddv[2 * j + 1]);
-            if constexpr (HAS_Z) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    *reinterpret_cast<float4 *>(xc + 4 * W8_SUB2 + j * W8_SUB) =
-                        make_float4(yv[4 * j], yv[4 * j + 1], yv[4 * j + 2], yv[4 * j + 3]);
-            }
-        }
         dA_prv = dAp;
         // ---- the next channel's tokens (loads issued two channels ago), then the loads of the one after it ----
         W8_STAMP(2);
@@ -463,7 +502,7 @@ __global__ __launch_bounds__(64) void reduce_slices_w8_kernel(const float *__res
     w8_emit(t32, d, dA, dD, dbias, Asc);
 }
 
-unsigned long long g_lds_done[2][3];
+unsigned long long g_lds_done[2][6];
 
 }  // namespace
 
@@ -482,21 +521,24 @@ int mmu_scan_bwd_apply_w8(const ScanArgs &a, int dtype, hipStream_t st) {
     if (a.dstate != 16 || a.seqlen % W8_TT != 0) return 0;
     const long wgs = (long)(a.seqlen / W8_TT) * a.batch * a.ngroups * a.d_splits;
     if (!(e && e[0] == '1') && wgs < mmu_cu_count()) return 0;   // too few tiles to give every CU one: p4's are half the size
-    const size_t lds = sizeof(float) * (2 * 8 * W8_XS + 2 * 3 * W8_AS + 8 * 16);
+    const size_t lds = sizeof(float) * (2 * 8 * W8_XS + 2 * 3 * W8_AS + 8 * 48);
     dim3 grid(a.seqlen / W8_TT, a.batch, a.ngroups * a.d_splits);
     const bool f32 = dtype == MMU_DTYPE_F32;
     hipError_t err = hipSuccess;
     MMU_BOOL(a.z != nullptr, HAS_Z, {
         MMU_BOOL(a.z != nullptr && a.out_z != nullptr, HAS_OZ, {
-            if constexpr (HAS_Z || !HAS_OZ) {
-                if (f32) {
-                    err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<float, HAS_Z, HAS_OZ>, (int)lds, g_lds_done[0][HAS_Z + HAS_OZ]);
-                    if (err == hipSuccess) chunk_apply_bwd_w8_kernel<float, HAS_Z, HAS_OZ><<<grid, 512, lds, st>>>(a);
-                } else {
-                    err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z, HAS_OZ>, (int)lds, g_lds_done[1][HAS_Z + HAS_OZ]);
-                    if (err == hipSuccess) chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z, HAS_OZ><<<grid, 512, lds, st>>>(a);
+            MMU_BOOL(a.z != nullptr && a.out != nullptr, Y_IN, {
+                if constexpr ((HAS_Z || !HAS_OZ) && (HAS_Z || !Y_IN)) {
+                    constexpr int vi = HAS_Z + HAS_OZ + 3 * Y_IN;
+                    if (f32) {
+                        err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<float, HAS_Z, HAS_OZ, Y_IN>, (int)lds, g_lds_done[0][vi]);
+                        if (err == hipSuccess) chunk_apply_bwd_w8_kernel<float, HAS_Z, HAS_OZ, Y_IN><<<grid, 512, lds, st>>>(a);
+                    } else {
+                        err = mmu_set_lds_once(chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z, HAS_OZ, Y_IN>, (int)lds, g_lds_done[1][vi]);
+                        if (err == hipSuccess) chunk_apply_bwd_w8_kernel<bf16_t, HAS_Z, HAS_OZ, Y_IN><<<grid, 512, lds, st>>>(a);
+                    }
                 }
-            }
+            });
         });
     });
     // contract: 1 = taken, 0 = not taken, < 0 = error (mmu_fail() itself returns 1 = "an error", which would read as

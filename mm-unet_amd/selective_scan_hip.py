@@ -106,7 +106,7 @@ def _fwd_one(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, want_out=Tr
 def _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
              dB_out=None, dC_out=None, dA_times_A=False, defer=False):
     """selective_scan_cuda.bwd: returns ``[du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]``
-    (selective_scan.cpp:338-492).  ``out_`` is accepted for signature parity and not read: y is
+    (selective_scan.cpp:338-492).  ``out_`` (the forward's y before gating) is read when given; without it y is
     recomputed from the states the kernel rebuilds anyway.
 
     ``dB_out`` / ``dC_out`` (extension): pre-allocated float32 (batch, groups, dstate, L) views with unit
@@ -179,6 +179,11 @@ def _bwd_one(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_
     _check(not dA_times_A or (A.is_contiguous() and A.dtype == torch.float32), "selective_scan_bwd: dA_times_A needs a "
            "contiguous float32 A")
     p.dA_times_A = int(bool(dA_times_A))
+    if out_ is not None and has_z:
+        # the forward's y before gating (selective_scan.cpp:338 `out_`): read instead of recomputed where the kernel can
+        _check(out_.shape == u.shape and out_.dtype == u.dtype and out_.stride(-1) == 1 and out_.device == u.device,
+               "selective_scan_bwd: out must have u's shape, dtype and device and unit stride along L")
+        p.out, p.out_bs, p.out_ds = out_.data_ptr(), out_.stride(0), out_.stride(1)
     with torch.cuda.device(u.device):
         if defer:
             _lib.check(L.mmu_selective_scan_bwd(p, _lib.stream_of(u)))

@@ -119,6 +119,8 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 # three-launch path (tests compare the two)
 KEEP_LARGE_ACTIVATIONS = os.environ.get("MMUNET_KEEP_ACTIVATIONS", "1") != "0"
 KEEP_MAX_BYTES = 1 << 30     # per tensor
+# the scan's un-gated output kept for the backward kernel (what the reference saves); "0": recomputed there
+KEEP_SCAN_OUT = os.environ.get("MMUNET_KEEP_SCAN_OUT", "1") != "0"
 PRE_SMALL_FUSED = True
 POST_SMALL_FUSED = True   # ... and the backward mirror (d x_dbl row 0, both weight gradients, d conv += W_x^T d x_dbl)
 
@@ -264,9 +266,13 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                                        C_proj_bias)
     if D is not None:
         D = D.contiguous()
-    # the un-gated `out` is not kept: this backward recomputes y from the states it rebuilds
-    _, scan_intermediates, out_z = selective_scan_hip.fwd(conv1d_out, delta, A, B, C, D, z, delta_bias,
-                                                          delta_softplus, want_out=False, opaque_x=True)
+    # The un-gated `out` (y + D u) is kept for the backward where the 512-token backward kernel will read it (d_state 16,
+    # L a multiple of 512: selective_scan.cpp:338 `out_`, as the reference does) -- that kernel then neither recomputes
+    # C h per state nor sums it over its eight waves.  Elsewhere the backward recomputes y from the states it rebuilds.
+    keep_out = (KEEP_SCAN_OUT and d_state == 16 and conv1d_out.shape[-1] % 512 == 0
+                and conv1d_out.numel() * conv1d_out.element_size() <= KEEP_MAX_BYTES)
+    scan_out, scan_intermediates, out_z = selective_scan_hip.fwd(conv1d_out, delta, A, B, C, D, z, delta_bias,
+                                                                 delta_softplus, want_out=keep_out, opaque_x=True)
     ctx.delta_softplus = delta_softplus
     ctx.checkpoint_lvl = checkpoint_lvl
     ctx.with_out_proj = with_out_proj
@@ -284,7 +290,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dblT, x_proj_weight, delta_proj_weight,
                           out_proj_weight if with_out_proj else None, conv1d_out, delta, A,
                           None if ctx.is_variable_B else B, None if ctx.is_variable_C else C, D, delta_bias,
-                          scan_intermediates)
+                          scan_intermediates, scan_out if keep_out else None)
     if not with_out_proj:
         return out_z
     # (B, L, E) = out_z^T W_out^T, computed tokens-last then viewed
@@ -297,7 +303,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
 
 def _inner_backward(ctx, dout):
     (xz, conv1d_weight, conv1d_bias, x_dblT, x_proj_weight, delta_proj_weight, out_proj_weight, conv1d_out, delta,
-     A, B, C, D, delta_bias, scan_intermediates) = ctx.saved_tensors
+     A, B, C, D, delta_bias, scan_intermediates, scan_out) = ctx.saved_tensors
     batch, _, L = xz.shape
     r = delta_proj_weight.shape[1]
     d_state = A.shape[-1]
@@ -327,7 +333,7 @@ def _inner_backward(ctx, dout):
     direct = dx_dblT.dtype == torch.float32
     dB_out = _rows_as_bnl(dx_dblT[r:r + d_state], batch, L) if (ctx.is_variable_B and direct) else None
     dC_out = _rows_as_bnl(dx_dblT[r + d_state:], batch, L) if (ctx.is_variable_C and direct) else None
-    res = selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, None, dz,
+    res = selective_scan_hip.bwd(conv1d_out, delta, A, B, C, D, z, delta_bias, dout_y, scan_intermediates, scan_out, dz,
                                  ctx.delta_softplus, ctx.with_out_proj, dB_out=dB_out, dC_out=dC_out,
                                  dA_times_A=ctx.A_neg_exp, defer=ctx.A_neg_exp and ctx.scan_params_are_leaves)
     dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz = res[:8]

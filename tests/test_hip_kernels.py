@@ -295,6 +295,15 @@ def test_scan_bwd_w8_vs_oracle_and_p4(case):
             torch.cuda.synchronize()
         finally:
             del os.environ["MMU_SCAN_BWD_W8"]
+    # the same kernel fed with the forward's un-gated `out` (what the reference's backward is handed,
+    # selective_scan.cpp:338): y is then read, not recomputed -- dz and the recomputed out_z must not move
+    if has_z:
+        os.environ["MMU_SCAN_BWD_W8"] = "1"
+        try:
+            got["y"] = ss.bwd(u, delta, A, B, C, D, z, bias, dout, res[1], res[0], None, True, want_oz)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["MMU_SCAN_BWD_W8"]
     dpg = d // g
     og = {}
     for gi in range(g):
@@ -311,6 +320,18 @@ def test_scan_bwd_w8_vs_oracle_and_p4(case):
     rt, at = (RTOL, ATOL) if f32 else (3e-2, 6e-2)
     names = ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z"]
     w8, p4 = got["1"], got["0"]
+    if has_z:
+        wy = got["y"]
+        assert len(wy) == len(w8)
+        close(wy[7], cat["dz"], RTOLW if f32 else 3e-2, ATOLW if f32 else 6e-2, "dz vs oracle (y read)")
+        for i, nm in enumerate(names[:len(w8)]):
+            if w8[i] is None:
+                assert wy[i] is None, nm
+                continue
+            scale = float(w8[i].float().abs().max()) + 1e-6
+            # everything but dz / out_z is bit-identical (y enters nothing else); those two see y rounded to the I/O type
+            tol = 0.0 if nm not in ("dz", "out_z") else (2e-5 if f32 else 2e-2) * scale
+            close(wy[i], w8[i], 0.0, tol, f"{nm}: y read vs y recomputed")
     close(w8[0], cat["du"], rt * 2, at * 2, "du vs oracle")
     close(w8[1], cat["ddelta"], rt * 5, at * 10, "ddelta vs oracle")
     close(w8[2], cat["dA"], RTOLW if f32 else 3e-2, (ATOLW * 5 if f32 else 0.5) * max(1, l // 1024), "dA vs oracle")

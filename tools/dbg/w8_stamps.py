@@ -23,12 +23,19 @@ buf = (ctypes.c_ulonglong * (2 * 8 * 8 * 8))()
 fn = _lib.lib().mmu_debug_w8_stamps
 assert fn(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(2, 8, 8, 8).astype(np.int64)
-names = ["main (+finish of the previous channel)", "xch wr", "prepare", "fetch", "barrier wait"]
 for blk in range(2):
-    print(f"block sel {blk}: ticks (10 ns) per phase, averaged over channels 16..23")
+    print(f"block sel {blk}: cycles (s_memtime) per phase, averaged over channels 16..23")
     for w in range(8):
-        dt = np.diff(t[blk, w, :, :6], axis=1).mean(axis=0)
-        nxt = (t[blk, w, 1:, 0] - t[blk, w, :-1, 5]).mean()  # wave sum + partial store + pointer adds
-        per = (t[blk, w, 1:, 0] - t[blk, w, :-1, 0]).mean()
-        print(f"  wave {w}: " + " ".join(f"{nm}={v:.0f}" for nm, v in zip(names, dt)) + f" | wave_sum+tail={nxt:.0f} channel={per:.0f}")
-    print("  barrier arrival spread (ticks, max-min over waves): " + " ".join(str(int(t[blk, :, c, 4].max() - t[blk, :, c, 4].min())) for c in range(8)))
+        T = t[blk, w]
+        fin = (T[1:, 0] - T[:-1, 5]).mean()          # barrier -> top of main: finishing the previous channel
+        rd = (T[:, 7] - T[:, 0]).mean()              # slots + prepared rows read from LDS
+        scan = (T[:, 6] - T[:, 7]).mean()            # exps, lane chains, the two row scans, h chain
+        walk = (T[:, 1] - T[:, 6]).mean()            # adjoint walk (+ exchange stores)
+        xw = (T[:, 2] - T[:, 1]).mean()
+        prep = (T[:, 3] - T[:, 2]).mean()
+        fetch = (T[:, 4] - T[:, 3]).mean()
+        bar = (T[:, 5] - T[:, 4]).mean()
+        per = (T[1:, 0] - T[:-1, 0]).mean()
+        print(f"  wave {w}: finish={fin:.0f} lds rd={rd:.0f} recompute+scans={scan:.0f} walk={walk:.0f} xch tail={xw:.0f} prepare={prep:.0f} "
+              f"fetch={fetch:.0f} barrier={bar:.0f} | channel={per:.0f}")
+    print("  barrier arrival spread (max-min over waves): " + " ".join(str(int(t[blk, :, c, 4].max() - t[blk, :, c, 4].min())) for c in range(8)))
