@@ -442,7 +442,9 @@ int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream);
 
 /* ---- W (rows x inner) times a tokens-last matrix, on the bf16 matrix cores with float32 accuracy ------------- */
 /* out[b] = W . X[b] for b < batch;  X[b] = x + b*x_bs, `inner` rows of `tokens` contiguous floats, row stride x_rs;
- * out[b] = out + b*out_bs, `rows` rows, row stride out_rs (strides in elements).  rows % 64 == 0, inner % 16 == 0.
+ * out[b] = out + b*out_bs, `rows` rows, row stride out_rs (strides in elements).  Any rows / inner (ABI 6): the weight
+ * image is padded with zeros to 64 rows / 16 columns (x_proj: 36 x 128 and its transpose 128 x 36), rows past `rows` are
+ * not stored, rows of X past `inner` are not read.
  * transposed_weight = 0: weight is [rows][inner] with leading dimension w_ld; 1: weight is [inner][rows] (w_ld its
  * leading dimension) and is read transposed.  MMConv's dsc_conv_x on the sampler output (src/UM_Net/MMUNet.py:262):
  * forward = (Cout x 3Cin) . samples, input gradient = transposed weight . dout.
@@ -455,6 +457,7 @@ typedef struct {
     const float *x;       int64_t x_rs, x_bs;
     float *out;           int64_t out_rs, out_bs;
     void *workspace;
+    int32_t accumulate;   /* ABI 6: non-zero: out += W . X (x_proj's input gradient lands on the scan's, selective_scan_interface.py:277) */
 } mmu_gemm_tokens_params;
 
 size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner);
@@ -462,8 +465,43 @@ int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream);
 /* The weight images of MANY products in one launch (a model prepares all its DSC weights once per forward pass).
  * table: DEVICE array of n_items rows of six int64 {weight pointer, its leading dimension, image pointer (16-byte
  * aligned, mmu_gemm_tokens_workspace_bytes(rows, inner) bytes), rows, inner, transposed_weight}; max_elements = the
- * largest rows * inner among them.  The caller has checked rows % 64 == 0 and inner % 16 == 0 for every row. */
+ * largest PADDED rows * inner among them (rows rounded up to 64, inner to 16). */
 int mmu_gemm_tokens_prepare_batch(const int64_t *table, int n_items, int64_t max_elements, void *stream);
+
+/* ---- Mamba's dt_proj on tokens-last operands (ABI 6) ------------------------------------------------------------ */
+/* forward  (mmu_dt_proj_fwd): delta[d][t] = sum_r weight[d][r] * dt[r][t]      (selective_scan_interface.py:182; the bias
+ *                             and softplus are the scan's)
+ * backward (mmu_dt_proj_bwd): dt[r][t]    = sum_d weight[d][r] * delta[d][t]   (:274; `delta` holds d delta, `dt`
+ *                             receives d dt -- the first `rank` rows of d x_dbl)
+ * weight [dim][rank] with leading dimension w_ld; dt `rank` rows, delta `dim` rows of `tokens` contiguous floats with
+ * row strides dt_rs / delta_rs (elements).  rank 1..8, tokens % 4 == 0, rows 16-byte aligned.  The weight gradient is
+ * mmu_gemm_nt_splitk's. */
+typedef struct {
+    int32_t rank, dim;
+    int64_t tokens;
+    const float *dt;      int64_t dt_rs;      /* written by mmu_dt_proj_bwd */
+    const float *weight;  int64_t w_ld;
+    float *delta;         int64_t delta_rs;   /* read by mmu_dt_proj_bwd */
+} mmu_dt_proj_params;
+int mmu_dt_proj_fwd(const mmu_dt_proj_params *p, void *stream);
+int mmu_dt_proj_bwd(const mmu_dt_proj_params *p, void *stream);
+
+/* ---- Mamba's x_proj on tokens-last operands (ABI 6) -------------------------------------------------------------- */
+/* forward  (mmu_x_proj_fwd): x_dbl[r][t] = sum_d weight[r][d] * x[d][t]          (selective_scan_interface.py:181)
+ * backward (mmu_x_proj_bwd): x[d][t]   += sum_r weight[r][d] * x_dbl[r][t]       (:277; `x` holds d conv and is updated
+ *                            in place, `x_dbl` holds d x_dbl)
+ * weight [rows][dim] with leading dimension w_ld, rows = dt_rank + 2 d_state in {33, 34, 36, 40}, dim % 4 == 0;
+ * x `dim` rows, x_dbl `rows` rows of `tokens` contiguous floats (row strides x_rs / x_dbl_rs).  Exact float32 products on
+ * the vector pipe (streaming; csrc/dt_proj.hip).  The weight gradient is mmu_gemm_nt_splitk's. */
+typedef struct {
+    int32_t rows, dim;
+    int64_t tokens;
+    const float *x;       int64_t x_rs;       /* updated by mmu_x_proj_bwd */
+    const float *weight;  int64_t w_ld;
+    float *x_dbl;         int64_t x_dbl_rs;   /* read by mmu_x_proj_bwd */
+} mmu_x_proj_params;
+int mmu_x_proj_fwd(const mmu_x_proj_params *p, void *stream);
+int mmu_x_proj_bwd(const mmu_x_proj_params *p, void *stream);
 
 /* ---- C (m x n) = sum over tokens of A[i][t] * B[j][t]: token-contraction ("NT") product on the fp32 matrix cores - */
 /* The weight gradient of every projection applied per token: in_proj / out_proj / x_proj / dt_proj of the Mamba blocks

@@ -121,7 +121,17 @@ class AdamWParams(ctypes.Structure):
 class GemmTokensParams(ctypes.Structure):
     _fields_ = [("rows", _i32), ("inner", _i32), ("tokens", _i32), ("batch", _i32), ("transposed_weight", _i32),
                 ("weight", _vp), ("w_ld", _i64), ("x", _vp), ("x_rs", _i64), ("x_bs", _i64),
-                ("out", _vp), ("out_rs", _i64), ("out_bs", _i64), ("workspace", _vp)]
+                ("out", _vp), ("out_rs", _i64), ("out_bs", _i64), ("workspace", _vp), ("accumulate", _i32)]
+
+
+class DtProjParams(ctypes.Structure):
+    _fields_ = [("rank", _i32), ("dim", _i32), ("tokens", _i64), ("dt", _vp), ("dt_rs", _i64), ("weight", _vp), ("w_ld", _i64),
+                ("delta", _vp), ("delta_rs", _i64)]
+
+
+class XProjParams(ctypes.Structure):
+    _fields_ = [("rows", _i32), ("dim", _i32), ("tokens", _i64), ("x", _vp), ("x_rs", _i64), ("weight", _vp), ("w_ld", _i64),
+                ("x_dbl", _vp), ("x_dbl_rs", _i64)]
 
 
 class GemmNtParams(ctypes.Structure):
@@ -212,7 +222,7 @@ EXPORTS = (
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
     "mmu_conv3x3_small_wgrad_workspace_floats",
     "mmu_tri_split", "mmu_tri_combine", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
-    "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma",
+    "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma", "mmu_dt_proj_fwd", "mmu_dt_proj_bwd", "mmu_x_proj_fwd", "mmu_x_proj_bwd",
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_adamw_multi", "mmu_coords_bwd_workspace_floats", "mmu_channel_sum", "mmu_scatter_stride2", "mmu_dice_bce_fwd", "mmu_dice_bce_bwd", "mmu_dice_bce_workspace_floats", "mmu_gated_mul_bwd_workspace_floats", "mmu_cbam_gate_fwd", "mmu_cbam_gate_bwd", "mmu_maxpool3s2_fwd", "mmu_maxpool3s2_bwd_codes", "mmu_deferred_begin", "mmu_deferred_pause", "mmu_deferred_end", "mmu_deferred_jobs", "mmu_deferred_launch", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
@@ -261,7 +271,8 @@ def lib():
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
                      ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams),
-                     ("mmu_gemm_nt_splitk", GemmNtParams),
+                     ("mmu_gemm_nt_splitk", GemmNtParams), ("mmu_dt_proj_fwd", DtProjParams), ("mmu_dt_proj_bwd", DtProjParams),
+                     ("mmu_x_proj_fwd", XProjParams), ("mmu_x_proj_bwd", XProjParams),
                      ("mmu_cbam_stats_fwd", CbamStatsParams), ("mmu_cbam_stats_bwd", CbamStatsParams),
                      ("mmu_gated_mul_fwd", GatedMulParams), ("mmu_gated_mul_bwd", GatedMulParams),
                      ("mmu_conv7x7_2to1_fwd", Conv7x7Params), ("mmu_conv7x7_2to1_bwd", Conv7x7Params),

@@ -49,17 +49,19 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 
 // W [M][K] with leading dimension ldw (trans = 0) or W [K][M] read transposed (trans = 1)
 //   -> [M/64][K/16][hi|lo][half][64 rows][8 k] bf16
+// M, K: the weight's own dimensions; the image covers them rounded up to 64 rows / 16 columns, zero beyond.
 __global__ __launch_bounds__(256) void gemm_tokens_prep_kernel(const float *__restrict__ w, long ldw,
                                                                unsigned short *__restrict__ out, int M, int K, int trans) {
-    const long n = (long)M * K;
+    const int Mp = (M + 63) & ~63, Kp = (K + CK - 1) & ~(CK - 1);
+    const long n = (long)Mp * Kp;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     const int k8 = (int)(idx & 7), row = (int)((idx >> 3) & 63), half = (int)((idx >> 9) & 1);
     long r = idx >> 10;
-    const int nch = K / CK;
+    const int nch = Kp / CK;
     const int ch = (int)(r % nch), mt = (int)(r / nch);
     const int m = mt * 64 + row, k = ch * CK + half * 8 + k8;
-    const float v = trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k];
+    const float v = (m < M && k < K) ? (trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k]) : 0.f;
     const __bf16 h = (__bf16)v;
     const __bf16 l = (__bf16)(v - (float)h);
     const long base = ((long)(mt * nch + ch) * 2) * (2 * 64 * 8) + ((long)half * 64 + row) * 8 + k8;
@@ -76,14 +78,15 @@ __global__ __launch_bounds__(256) void gemm_tokens_prep_batch_kernel(const long 
     const long ldw = row[1];
     unsigned short *out = reinterpret_cast<unsigned short *>(row[2]);
     const int M = (int)row[3], K = (int)row[4], trans = (int)row[5];
-    const long n = (long)M * K;
-    const int nch = K / CK;
+    const int Mp = (M + 63) & ~63, Kp = (K + CK - 1) & ~(CK - 1);
+    const long n = (long)Mp * Kp;
+    const int nch = Kp / CK;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
         const int k8 = (int)(idx & 7), rw = (int)((idx >> 3) & 63), half = (int)((idx >> 9) & 1);
         const long r = idx >> 10;
         const int ch = (int)(r % nch), mt = (int)(r / nch);
         const int m = mt * 64 + rw, k = ch * CK + half * 8 + k8;
-        const float v = trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k];
+        const float v = (m < M && k < K) ? (trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k]) : 0.f;
         const __bf16 h = (__bf16)v;
         const __bf16 l = (__bf16)(v - (float)h);
         const long base = ((long)(mt * nch + ch) * 2) * (2 * 64 * 8) + ((long)half * 64 + rw) * 8 + k8;
@@ -97,7 +100,8 @@ struct GemmArgs {
     const unsigned short *wp;
     float *out;
     long x_rs, x_bs, o_rs, o_bs;
-    int M, K, T, B, tiles_t, n_mt, total_tiles;
+    int M, K, T, B, tiles_t, n_mt, total_tiles;   // M, K: padded to 64 / 16
+    int Mv, Kv, acc;                              // the matrix' own rows / inner size; acc: out += W . X
 };
 
 __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
@@ -138,8 +142,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
             const unsigned voff = (unsigned)(tok < p.T ? tok : 0) * 4u;
             const unsigned row0 = (unsigned)(l_ch * CK + half * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (row0 + j) * (unsigned)p.x_rs * 4u, 0);
+            for (int j = 0; j < 8; ++j) {   // rows past the matrix (inner padded to 16): a valid row again, its weights are zero
+                const unsigned rj = row0 + j < (unsigned)p.Kv ? row0 + j : (unsigned)p.Kv - 1u;
+                dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, rj * (unsigned)p.x_rs * 4u, 0);
+            }
             wdst = reinterpret_cast<const v4u *>(p.wp + ((long)l_mt * nch + l_ch) * (2 * 2 * 64 * 8))[ptid];
             if (l_ch + 1 < nch) {
                 ++l_ch;
@@ -230,9 +236,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
                 for (int n = 0; n < 4; ++n) {
                     const int tok = t0 + wv * 128 + n * 32 + (lane & 31);
                     if (tok < p.T) {
-                        float *op = p.out + (long)b * p.o_bs + (long)(mt * 64 + m * 32 + 4 * (lane >> 5)) * p.o_rs + tok;
+                        const int r0 = mt * 64 + m * 32 + 4 * (lane >> 5);
+                        float *op = p.out + (long)b * p.o_bs + (long)r0 * p.o_rs + tok;
+                        if (r0 + 28 < p.Mv && !p.acc) {   // all 16 rows of this lane inside the matrix, plain store
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * p.o_rs] = acc[m][n][e];
+                            for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * p.o_rs] = acc[m][n][e];
+                        } else {
+                            // all 16 loads of the old values first, then the stores: interleaved, every load would wait
+                            // behind the store in front of it (the compiler cannot tell the rows apart)
+                            float old[16];
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int ro = (e & 3) + 8 * (e >> 2);
+                                old[e] = (p.acc && r0 + ro < p.Mv) ? op[(long)ro * p.o_rs] : 0.f;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int ro = (e & 3) + 8 * (e >> 2);
+                                if (r0 + ro < p.Mv) op[(long)ro * p.o_rs] = old[e] + acc[m][n][e];
+                            }
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
@@ -248,13 +271,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
 
 extern "C" size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner) {
     if (rows <= 0 || inner <= 0) return 0;
-    return (size_t)rows * inner * 2 * sizeof(unsigned short);
+    return (size_t)((rows + 63) & ~63) * ((inner + CK - 1) & ~(CK - 1)) * 2 * sizeof(unsigned short);
 }
 
 extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream) {
     MMU_CHECK(p != nullptr, "gemm_tokens_mfma: null params");
-    MMU_CHECK(p->rows > 0 && p->rows % 64 == 0 && p->inner > 0 && p->inner % 16 == 0,
-              "gemm_tokens_mfma: rows must be a multiple of 64 and inner of 16 (got %d, %d)", p->rows, p->inner);
+    MMU_CHECK(p->rows > 0 && p->inner > 0, "gemm_tokens_mfma: rows and inner must be positive (got %d, %d)", p->rows, p->inner);
+    const int Mp = (p->rows + 63) & ~63, Kp = (p->inner + CK - 1) & ~(CK - 1);
     MMU_CHECK(p->tokens > 0 && p->batch > 0, "gemm_tokens_mfma: empty problem");
     MMU_CHECK(p->tokens % 4 == 0 && p->x_rs % 4 == 0 && p->x_bs % 4 == 0 && ((uintptr_t)p->x & 15) == 0,
               "gemm_tokens_mfma: tokens, x_rs, x_bs must be multiples of 4 and x 16-byte aligned");
@@ -262,7 +285,7 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     MMU_CHECK(p->x && p->out && p->workspace, "gemm_tokens_mfma: x, out, workspace are required");
     MMU_CHECK(((uintptr_t)p->workspace & 15) == 0, "gemm_tokens_mfma: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const long nw = (long)p->rows * p->inner;
+    const long nw = (long)Mp * Kp;
     if (p->weight) {   // NULL: the workspace already holds this weight's image (mmu_gemm_tokens_prepare_batch)
         gemm_tokens_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->weight, p->w_ld, (unsigned short *)p->workspace,
                                                                              p->rows, p->inner, p->transposed_weight ? 1 : 0);
@@ -274,9 +297,10 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     GemmArgs a;
     a.x = p->x; a.wp = (const unsigned short *)p->workspace; a.out = p->out;
     a.x_rs = p->x_rs; a.x_bs = p->x_bs; a.o_rs = p->out_rs; a.o_bs = p->out_bs;
-    a.M = p->rows; a.K = p->inner; a.T = p->tokens; a.B = p->batch;
+    a.M = Mp; a.K = Kp; a.T = p->tokens; a.B = p->batch;
+    a.Mv = p->rows; a.Kv = p->inner; a.acc = p->accumulate ? 1 : 0;
     a.tiles_t = (p->tokens + TT - 1) / TT;
-    a.n_mt = p->rows / 64;
+    a.n_mt = Mp / 64;
     const long total = (long)a.tiles_t * a.n_mt * p->batch;
     MMU_CHECK(total < (1L << 30), "gemm_tokens_mfma: too many tiles");
     a.total_tiles = (int)total;

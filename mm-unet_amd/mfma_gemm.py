@@ -1,6 +1,6 @@
 """``gemm_tokens`` -- ``W (M, K) @ X (K, T)`` for tokens-last ``X`` on the bf16 matrix cores with float32 accuracy
-(csrc/gemm_tokens_mfma.hip; hi/lo bf16 split, three MFMAs per product).  float32 only, M % 64 == 0, K % 16 == 0;
-callers keep their hipBLASLt path for everything else."""
+(csrc/gemm_tokens_mfma.hip; hi/lo bf16 split, three MFMAs per product).  float32 only; any M / K since ABI 6 (the weight
+image is zero-padded to 64 rows / 16 columns); ``dt_proj`` / ``dt_proj_input_grad``: csrc/dt_proj.hip."""
 import os
 
 import torch
@@ -49,7 +49,7 @@ class prepared_weights:
         for w in self.weights:
             m, k = w.shape[0], w.numel() // w.shape[0]
             for rows, inner, trans in ((m, k, 0), (k, m, 1)):
-                if rows % 64 == 0 and inner % 16 == 0:
+                if True:   # any rows / inner since ABI 6 (zero-padded images)
                     nbytes = (int(L.mmu_gemm_tokens_workspace_bytes(rows, inner)) + 255) // 256 * 256
                     items.append((w, rows, inner, trans, off, nbytes))
                     off += nbytes
@@ -60,7 +60,7 @@ class prepared_weights:
             img = self._arena[o:o + nbytes]
             self._images[(w.data_ptr(), rows, inner, trans)] = img
             rows_.append([w.data_ptr(), w.numel() // w.shape[0], img.data_ptr(), rows, inner, trans])
-            self._max = max(self._max, rows * inner)
+            self._max = max(self._max, ((rows + 63) // 64 * 64) * ((inner + 15) // 16 * 16))
         self._table = torch.tensor(rows_, dtype=torch.int64).to(dev) if rows_ else None
         self._key = tuple(w.data_ptr() for w in self.weights)
 
@@ -89,7 +89,7 @@ def prepared_for(weight, rows, inner, transposed_weight):
 
 
 def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, out_bs, transposed_weight=False,
-                prepared=None):
+                prepared=None, accumulate=False):
     """out[b] = W . X[b]; ``weight`` is (rows, inner) -- or (inner, rows) read transposed -- with unit inner stride;
     ``x`` / ``out`` are float32 tensors whose storage holds the strided operands described by the element strides.
     ``prepared``: this weight's image from :class:`prepared_weights` (looked up by address when not given)."""
@@ -113,9 +113,100 @@ def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, 
     p.x, p.x_rs, p.x_bs = x.data_ptr(), x_rs, x_bs
     p.out, p.out_rs, p.out_bs = out.data_ptr(), out_rs, out_bs
     p.workspace = ws.data_ptr()
+    p.accumulate = int(bool(accumulate))   # out += W . X
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().mmu_gemm_tokens_mfma(p, _lib.stream_of(x)))
     return out
+
+
+def dt_proj(weight, dt_rows, delta=None):
+    """delta (dim, T) = weight (dim, rank) @ dt_rows (rank, T) -- Mamba's dt_proj on tokens-last rows
+    (csrc/dt_proj.hip; selective_scan_interface.py:182).  float32, rank <= 8, T % 4 == 0."""
+    _lib.require_gpu(weight, dt_rows)
+    dim, rank = weight.shape
+    T = dt_rows.shape[1]
+    if delta is None:
+        delta = torch.empty((dim, T), device=dt_rows.device, dtype=torch.float32)
+    _dt_proj_call("mmu_dt_proj_fwd", weight, dt_rows, delta)
+    return delta
+
+
+def dt_proj_input_grad(weight, ddelta, ddt_rows):
+    """ddt_rows (rank, T) = weight^T (rank, dim) @ ddelta (dim, T), written in place (csrc/dt_proj.hip;
+    selective_scan_interface.py:274)."""
+    _lib.require_gpu(weight, ddelta, ddt_rows)
+    _dt_proj_call("mmu_dt_proj_bwd", weight, ddt_rows, ddelta)
+    return ddt_rows
+
+
+def dt_proj_supported(weight, dt_rows, delta):
+    return (ENABLED and weight.dim() == 2 and 1 <= weight.shape[1] <= 8 and weight.stride(1) == 1
+            and not torch.is_autocast_enabled()
+            and all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in (weight, dt_rows, delta))
+            and all(t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+                    for t in (dt_rows, delta))
+            and dt_rows.shape[1] % 4 == 0 and dt_rows.shape[1] == delta.shape[1]
+            and dt_rows.shape[0] == weight.shape[1] and delta.shape[0] == weight.shape[0])
+
+
+def _dt_proj_call(name, weight, dt_rows, delta):
+    if not dt_proj_supported(weight, dt_rows, delta):
+        raise RuntimeError(f"{name}: float32 tokens-last matrices with unit token stride, rank <= 8, tokens % 4 == 0 required")
+    p = _lib.DtProjParams()
+    p.rank, p.dim, p.tokens = weight.shape[1], weight.shape[0], dt_rows.shape[1]
+    p.dt, p.dt_rs = dt_rows.data_ptr(), dt_rows.stride(0)
+    p.weight, p.w_ld = weight.data_ptr(), weight.stride(0)
+    p.delta, p.delta_rs = delta.data_ptr(), delta.stride(0)
+    with torch.cuda.device(delta.device):
+        _lib.check(getattr(_lib.lib(), name)(p, _lib.stream_of(delta)))
+
+
+X_PROJ_ROWS = (33, 34, 36, 40)   # dt_rank + 2 * d_state the streaming x_proj kernels are instantiated for
+
+
+def x_proj_supported(weight, x, x_dbl):
+    return (ENABLED and weight.dim() == 2 and weight.shape[0] in X_PROJ_ROWS and weight.stride(1) == 1
+            and weight.shape[1] % 4 == 0 and weight.shape[1] <= 1024 and weight.shape[1] * ((weight.shape[0] + 3) // 4 * 4) * 4 <= 65536
+            and not torch.is_autocast_enabled()
+            and all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in (weight, x, x_dbl))
+            and all(t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (x, x_dbl))
+            and x.shape[1] % 4 == 0 and x.shape[1] == x_dbl.shape[1] and x.shape[0] == weight.shape[1]
+            and x_dbl.shape[0] == weight.shape[0])
+
+
+def _x_proj_call(name, weight, x, x_dbl):
+    if not x_proj_supported(weight, x, x_dbl):
+        raise RuntimeError(f"{name}: float32 tokens-last matrices with unit token stride, rows in {X_PROJ_ROWS}, dim % 4 == 0 required")
+    p = _lib.XProjParams()
+    p.rows, p.dim, p.tokens = weight.shape[0], weight.shape[1], x.shape[1]
+    p.x, p.x_rs = x.data_ptr(), x.stride(0)
+    p.weight, p.w_ld = weight.data_ptr(), weight.stride(0)
+    p.x_dbl, p.x_dbl_rs = x_dbl.data_ptr(), x_dbl.stride(0)
+    with torch.cuda.device(x.device):
+        _lib.check(getattr(_lib.lib(), name)(p, _lib.stream_of(x)))
+
+
+def x_proj(weight, x, x_dbl=None):
+    """x_dbl (rows, T) = weight (rows, dim) @ x (dim, T): exact float32 products, streaming (csrc/dt_proj.hip;
+    selective_scan_interface.py:181)."""
+    _lib.require_gpu(weight, x)
+    if x_dbl is None:
+        x_dbl = torch.empty((weight.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
+    _x_proj_call("mmu_x_proj_fwd", weight, x, x_dbl)
+    return x_dbl
+
+
+def x_proj_input_grad_add(weight, dx_dbl, dx):
+    """dx (dim, T) += weight^T @ dx_dbl (rows, T), in place (selective_scan_interface.py:277)."""
+    _lib.require_gpu(weight, dx_dbl, dx)
+    _x_proj_call("mmu_x_proj_bwd", weight, dx, dx_dbl)
+    return dx
+
+
+def tokens_supported(*tensors):
+    """gemm_tokens on ANY rows / inner (zero-padded weight image, masked rows): what the operands must satisfy."""
+    return (ENABLED and not torch.is_autocast_enabled()
+            and all(t.is_cuda and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 for t in tensors))
 
 
 # False (or MMUNET_GEMM_NT=0): callers keep their batched-GEMM split-K (tests compare the two)

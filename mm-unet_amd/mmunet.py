@@ -476,6 +476,7 @@ class MM_Net(nn.Module):
             rcgs = [m.mamba for m in self.modules() if isinstance(m, RCG)]   # their projections take the same GEMM
             self._dsc_prep = [mfma_gemm.prepared_weights(
                 lambda: [m.dsc_conv_x.weight for m in blocks] + [w for m in rcgs for w in (m.in_proj.weight, m.out_proj.weight)]
+                + [getattr(m, n).weight for m in rcgs for n in ("x_proj", "x_proj_b", "x_proj_s") if hasattr(m, n)]
                 + [m.block2[0].weight for m in self.modules() if isinstance(m, ResidualBlock) and m.downsample])]
         # A = -exp(A_log) of all 50 Mamba blocks in two launches; the 56 BatchNorm batch counters in one; the bf16 hi/lo
         # images of the 47 DSC weights (both orientations) in one

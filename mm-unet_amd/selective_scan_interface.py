@@ -31,7 +31,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _lib, causal_conv1d_hip, deferred, selective_scan_hip
+from . import _lib, causal_conv1d_hip, deferred, mfma_gemm, selective_scan_hip
 from .tall_gemm import nt_splitk
 
 try:  # torch >= 2.4
@@ -201,14 +201,37 @@ def _post_small(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_weight,
     return dwx, dwdt
 
 
+OWN_PROJ = os.environ.get("MMUNET_OWN_PROJ", "1") != "0"   # "0": x_proj / dt_proj and their input gradients as library GEMMs
+
+
+def _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, tokens):
+    """x_proj / dt_proj (and their input gradients) on csrc/gemm_tokens_mfma.hip + csrc/dt_proj.hip: float32, a
+    tokens-last conv matrix with unit token stride, dt_rank <= 8, enough tokens to give every CU a 512-token tile."""
+    return (OWN_PROJ and tokens % 4 == 0 and tokens >= 16384 and conv_m.dim() == 2 and conv_m.stride(1) == 1
+            and conv_m.stride(0) % 4 == 0 and x_proj_weight.is_contiguous() and delta_proj_weight.is_contiguous()
+            and 1 <= delta_proj_weight.shape[1] <= 8 and x_proj_weight.shape[0] in mfma_gemm.X_PROJ_ROWS
+            and x_proj_weight.shape[1] % 4 == 0 and x_proj_weight.shape[1] * 4 * ((x_proj_weight.shape[0] + 3) // 4 * 4) <= 65536
+            and mfma_gemm.tokens_supported(conv_m, x_proj_weight, delta_proj_weight))
+
+
 def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias):
     """delta, B, C from the conv output (selective_scan_interface.py:181-210), computed tokens-last:
     x_dblT = W_x @ conv (r+2N, B*L) -- the transpose of the reference's x_dbl -- so that delta, B and C
     are row blocks of it and nothing has to be transposed."""
     batch, dim, L = conv1d_out.shape
     r = delta_proj_weight.shape[1]
-    x_dblT = x_proj_weight @ _dbl_view(conv1d_out)                       # (r + 2N, B*L)
-    delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
+    conv_m = _dbl_view(conv1d_out)
+    if _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, batch * L):
+        # W_x (36 x 128) as a zero-padded matrix-core product with masked rows (csrc/gemm_tokens_mfma.hip: 98 us at the
+        # largest block; the streaming float32 kernel of csrc/dt_proj.hip takes 114, the library 97), W_dt (128 x 4) as
+        # a streaming kernel (48 us; the library 76)
+        T = batch * L
+        x_dblT = torch.empty((x_proj_weight.shape[0], T), device=conv_m.device, dtype=torch.float32)
+        mfma_gemm.gemm_tokens(x_proj_weight, conv_m, x_dblT, x_proj_weight.shape[0], dim, T, 1, conv_m.stride(0), 0, T, 0)
+        delta = mfma_gemm.dt_proj(delta_proj_weight, x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
+    else:
+        x_dblT = x_proj_weight @ conv_m                                  # (r + 2N, B*L)
+        delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
     if B is None:
         B = _rows_as_bnl(x_dblT[r:r + d_state], batch, L)
         if B_proj_bias is not None:
@@ -365,11 +388,20 @@ def _inner_backward(ctx, dout):
     else:
         ddelta_m = _dbl_view(ddelta)                                            # (D, B*L)
         ddelta_proj_weight = nt_splitk(ddelta_m, x_dblT[:r]).to(delta_proj_weight.dtype)  # (D, r)      (:273)
-        torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])         # (r, B*L)              (:274)
         conv_m = _dbl_view(conv1d_out)
-        dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
         dconv_m = _dbl_view(dconv1d_out)                                        # (D, B*L)
-        if dconv_m.data_ptr() == dconv1d_out.data_ptr():
+        own = (dconv_m.data_ptr() == dconv1d_out.data_ptr() and direct and dx_dblT.is_contiguous()
+               and _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, batch * L)
+               and mfma_gemm.dt_proj_supported(delta_proj_weight, dx_dblT[:r], ddelta_m)
+               and mfma_gemm.tokens_supported(dconv_m, dx_dblT) and dconv_m.stride(1) == 1 and dconv_m.stride(0) % 4 == 0)
+        if own:
+            mfma_gemm.dt_proj_input_grad(delta_proj_weight, ddelta_m, dx_dblT[:r])  # (r, B*L)         (:274)
+        else:
+            torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])     # (r, B*L)              (:274)
+        dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
+        if own:
+            mfma_gemm.x_proj_input_grad_add(x_proj_weight, dx_dblT, dconv_m)   # d conv += W_x^T d x_dbl, in place   (:277)
+        elif dconv_m.data_ptr() == dconv1d_out.data_ptr():
             dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
         else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
             dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dblT)

@@ -56,6 +56,7 @@ def test_param_structs_match_header_field_order():
                         ("mmu_conv3x3_mfma_params", _lib.Conv3x3MfmaParams),
                         ("mmu_gemm_tokens_params", _lib.GemmTokensParams),
                         ("mmu_gemm_nt_params", _lib.GemmNtParams),
+                        ("mmu_dt_proj_params", _lib.DtProjParams), ("mmu_x_proj_params", _lib.XProjParams),
                         ("mmu_conv1x1_one_params", _lib.Conv1x1OneParams),
                         ("mmu_maxpool_params", _lib.MaxPoolParams),
                         ("mmu_conv7x7_params", _lib.Conv7x7Params),

@@ -835,7 +835,9 @@ def test_conv3x3_mfma_vs_conv2d_fp64(case):
 
 
 @pytest.mark.parametrize("case", [(64, 48, 700, 3, False), (128, 192, 512, 1, False), (192, 64, 1300, 1, True),
-                                  (64, 16, 36, 2, True)])
+                                  (64, 16, 36, 2, True),
+                                  # rows / inner that are no multiples of 64 / 16 (ABI 6): x_proj 36 x 128 and its transpose
+                                  (36, 128, 1300, 1, False), (128, 36, 2048, 1, True), (100, 21, 516, 2, False)])
 def test_gemm_tokens_mfma_vs_fp64(case):
     """gemm_tokens (bf16 hi/lo split on the matrix cores, producer / consumer waves) == W @ X[b] in float64:
     strided batches out of one tokens-last matrix, ragged token tiles, transposed weight."""
@@ -849,6 +851,83 @@ def test_gemm_tokens_mfma_vs_fp64(case):
     out = torch.full((B, M, T), float("nan"), device=DEV)
     gemm_tokens(Wd, X.to(DEV), out, M, K, T, B, B * T, T, T, M * T, transposed_weight=trans)
     close(out, ref.float(), 5e-5, 5e-5, "W @ X")   # three bf16 products per term: ~2^-16 relative each
+
+
+def test_gemm_tokens_accumulates_and_leaves_masked_rows_alone():
+    """accumulate=True: out += W^T . X on the rows of the matrix only (x_proj's input gradient added onto the scan's,
+    selective_scan_interface.py:277); the padding rows of the 64-row tile are never written."""
+    from mm_unet_amd.mfma_gemm import gemm_tokens
+    gen = torch.Generator().manual_seed(5)
+    D, R, T = 96, 36, 1536
+    W = torch.randn(R, D, generator=gen) / D ** 0.5
+    G = torch.randn(R, T, generator=gen)
+    base = torch.randn(D + 8, T, generator=gen)            # 8 guard rows behind the matrix
+    out = base.clone().to(DEV)
+    gemm_tokens(W.to(DEV), G.to(DEV), out, D, R, T, 1, T, 0, T, 0, transposed_weight=True, accumulate=True)
+    ref = base.double()
+    ref[:D] += W.double().t() @ G.double()
+    close(out[:D], ref[:D].float(), 5e-5, 5e-5, "out += W^T G")
+    assert torch.equal(out[D:].cpu(), base[D:]), "rows past the matrix were written"
+
+
+@pytest.mark.parametrize("case", [(4, 128, 4096 + 512), (1, 6, 1028), (8, 40, 2048)])
+def test_dt_proj_kernels_vs_fp64(case):
+    """csrc/dt_proj.hip: delta = W_dt . dt and d dt = W_dt^T . d delta on tokens-last rows that are slices of a larger
+    matrix (row stride > tokens), against float64."""
+    from mm_unet_amd.mfma_gemm import dt_proj, dt_proj_input_grad
+    R, D, T = case
+    gen = torch.Generator().manual_seed(R + D + T)
+    W = torch.randn(D, R, generator=gen)
+    xdbl = torch.randn(R + 32, T, generator=gen).to(DEV)                 # dt = its first R rows
+    delta = dt_proj(W.to(DEV), xdbl[:R])
+    close(delta, (W.double() @ xdbl[:R].cpu().double()).float(), 1e-6, 1e-5, "delta")
+    g = torch.randn(D, T, generator=gen)
+    dx = torch.full((R + 32, T), 7.0, device=DEV)
+    dt_proj_input_grad(W.to(DEV), g.to(DEV), dx[:R])
+    close(dx[:R], (W.double().t() @ g.double()).float(), 1e-6, 2e-5, "d dt")
+    assert bool((dx[R:] == 7.0).all()), "rows past dt_rank were written"
+
+
+@pytest.mark.parametrize("case", [(36, 128, 4096 + 1024), (33, 8, 1028), (40, 64, 300 * 1024 + 4)])
+def test_x_proj_stream_kernels_vs_fp64(case):
+    """csrc/dt_proj.hip: x_dbl = W_x . conv and d conv += W_x^T . d x_dbl (exact float32 products, streaming) against
+    float64, incl. a token count that makes every block walk several token groups."""
+    from mm_unet_amd.mfma_gemm import x_proj, x_proj_input_grad_add
+    RW, D, T = case
+    gen = torch.Generator().manual_seed(RW + D)
+    W = torch.randn(RW, D, generator=gen) / D ** 0.5
+    x = torch.randn(D, T, generator=gen)
+    out = x_proj(W.to(DEV), x.to(DEV))
+    close(out, (W.double() @ x.double()).float(), 1e-5, 1e-5, "x_dbl")
+    g = torch.randn(RW, T, generator=gen)
+    base = torch.randn(D, T, generator=gen)
+    dx = base.clone().to(DEV)
+    x_proj_input_grad_add(W.to(DEV), g.to(DEV), dx)
+    close(dx, (base.double() + W.double().t() @ g.double()).float(), 1e-5, 2e-5, "d conv")
+
+
+def test_mamba_inner_own_projections_match_library_route(monkeypatch):
+    """x_proj / dt_proj and their input gradients on the build's kernels (gemm_tokens with a zero-padded 36-row image,
+    dt_proj.hip) against the same mamba_inner with library GEMMs (MMUNET_OWN_PROJ off): output and every gradient."""
+    import mm_unet_amd.selective_scan_interface as ssi
+    from mm_unet_amd.mamba_simple import Mamba
+    torch.manual_seed(3)
+    m = Mamba(d_model=64, d_state=16, bimamba_type="none").to(DEV)
+    x = torch.randn(8, 4096, 64, device=DEV)
+    g = torch.randn(8, 4096, 64, device=DEV)
+    res = {}
+    for own in (True, False):
+        monkeypatch.setattr(ssi, "OWN_PROJ", own)
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        out = m(xi)
+        out = out[0] if isinstance(out, tuple) else out
+        out.backward(g)
+        res[own] = (out.detach(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    close(res[True][0], res[False][0], 2e-4, 2e-4, "out")
+    close(res[True][1], res[False][1], 5e-4, 5e-4 * float(res[False][1].abs().max()), "d input")
+    for k, v in res[False][2].items():
+        close(res[True][2][k], v, 2e-3, 2e-3 * float(v.abs().max()) + 1e-6, f"d {k}")
 
 
 def test_dsc_gemm_mfma_path_matches_library_path():
