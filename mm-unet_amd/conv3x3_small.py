@@ -176,8 +176,13 @@ class Conv3x3SmallFn(torch.autograd.Function):
             parked = None
             if isinstance(ctx.slot, SharedGrad):
                 parked = ctx.slot.take()
-            elif ctx.slot is not None and ctx.slot.grad is not None:
-                parked, ctx.slot.grad = ctx.slot.grad, None
+            elif ctx.slot is not None:
+                if ctx.slot.grad is not None:
+                    parked, ctx.slot.grad = ctx.slot.grad, None
+                # from here on nobody collects a parked gradient any more: a producer whose backward runs AFTER this one
+                # (another node order, a second autograd.grad over part of the graph) must return its gradient the normal
+                # way instead of parking it for good
+                ctx.slot.armed = False
             if parked is not None:
                 if parked.shape != x.shape or parked.dtype != x.dtype or not parked.is_contiguous():
                     raise RuntimeError("conv3x3_small: parked input gradient does not match the input")

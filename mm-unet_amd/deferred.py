@@ -14,7 +14,8 @@ in one kernel, with the summation order of the kernels it replaces.
 
 Eagerly ``launch()`` binds by itself.  Contract: the weight gradients are leaves of the backward pass (stored into
 ``param.grad``, not accumulated into or read before ``launch()``) -- ``TrainStep`` opens a scope only around the backward
-pass it captures.  Process-wide: one scope at a time.
+pass it captures and CHECKS the contract there (``Scope.verify_destinations``: every result address inside exactly one
+``param.grad``, none twice).  Process-wide: one scope at a time.
 """
 import torch
 
@@ -133,6 +134,40 @@ class Scope:
             raise RuntimeError(f"deferred.Scope: {len(work)} workgroups, work list holds {self.work.shape[0]}")
         self._rows, self._work = rows, work
         self.n_jobs, self.n_work = len(rows), len(work)
+
+    # which fields of a job row are result pointers (csrc/deferred_reduce.hip: kind -> row layout)
+    _DEST_FIELDS = {0: (2,), 1: (2, 3), 2: (2, 3), 3: (2, 3), 4: (2, 3, 4), 5: (2, 3, 4), 6: (2,), 7: (2, 3)}
+
+    def destinations(self):
+        """(kind, address) of every result the recorded jobs will write."""
+        out = []
+        for r in self._rows or []:
+            out += [(int(r[0]), int(r[f])) for f in self._DEST_FIELDS.get(int(r[0]), (2,)) if r[f]]
+        return out
+
+    def verify_destinations(self, params):
+        """The contract of a deferred sum is that NOTHING reads its result before ``launch()`` has run -- true for a
+        gradient that autograd stores straight into ``param.grad``, false as soon as the gradient takes a detour (a
+        non-leaf weight: a cast, a permuted copy, a re-parametrisation; a parameter used twice, whose second gradient
+        AccumulateGrad ADDS to the unfilled first; a tensor hook): the step would then train on stale or garbage
+        gradients, silently (it happened once: DESIGN.md 5.1).  Called by ``TrainStep`` after the captured backward:
+        every destination must lie inside exactly one ``param.grad`` of the model and none may repeat."""
+        spans = sorted((p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * p.grad.element_size(), n)
+                       for n, p in params if p.grad is not None)
+        starts = [a for a, _, _ in spans]
+        import bisect
+        seen = {}
+        for kind, ptr in self.destinations():
+            i = bisect.bisect_right(starts, ptr) - 1
+            if i < 0 or not (spans[i][0] <= ptr < spans[i][1]):
+                raise RuntimeError(f"deferred.Scope: a deferred reduction of kind {kind} writes to {ptr:#x}, which is no "
+                                   "parameter gradient of the model: its result is read (cloned, cast, accumulated) before "
+                                   "the deferred launch.  Compute that gradient inside deferred.paused(), or construct "
+                                   "TrainStep(deferred_reductions=False).")
+            if ptr in seen:
+                raise RuntimeError(f"deferred.Scope: two deferred reductions (kinds {seen[ptr]}, {kind}) write to {ptr:#x} "
+                                   f"({spans[i][2]}.grad): a parameter that receives two gradients cannot have them deferred")
+            seen[ptr] = kind
 
     def bind(self):
         """Writes the recorded jobs into the device tables (not inside a capture)."""

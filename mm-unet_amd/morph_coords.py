@@ -92,8 +92,10 @@ class ZigzagInProjFn(torch.autograd.Function):
         g = _dbl(dxz.float(), 4 * K, B, H * W)
         slot = ctx.slot
         parked = None
-        if slot is not None and slot.grad is not None:
-            parked, slot.grad = slot.grad, None
+        if slot is not None:
+            if slot.grad is not None:
+                parked, slot.grad = slot.grad, None
+            slot.armed = False   # a producer that runs after this node hands its gradient to autograd (see conv3x3_small)
         doff = parked if parked is not None else torch.empty_like(offset)
         dw = torch.empty_like(w)
         p = _params(offset, K)

@@ -119,7 +119,9 @@ class TrainStep:
         if self.multi_tensor_adamw and adamw_multi.supported(self.optimizer) and \
                 all(isinstance(s.get("step"), torch.Tensor) and s["step"].is_cuda for s in self.optimizer.state.values()) \
                 and len(self.optimizer.state) > 0 and \
-                (whole or all(isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda for g in self.optimizer.param_groups)):
+                all(isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda for g in self.optimizer.param_groups):
+            # (a Python-float learning rate would be copied to the device inside the capture -- a pageable host-to-device
+            #  copy in a capturing stream -- and baked into the graph: such optimizers keep optimizer.step())
             self._adamw = adamw_multi.MultiTensorAdamW(self.optimizer)
             self._adamw.reserve()
         with torch.cuda.graph(self._graph):
@@ -135,6 +137,9 @@ class TrainStep:
                 self._adamw.plan()             # (the parameters the captured backward has given gradients)
             self._adamw.bind()                 # addresses into the table the captured launches read
         if self._scope is not None:
+            # the deferred sums' contract, checked on what the capture actually recorded: raises (before any replay) when
+            # a result is not a parameter gradient or is written twice
+            self._scope.verify_destinations(list(self.model.named_parameters()))
             self._scope.bind()                 # (the same for the deferred reductions' job table)
             self._scope_captured, self._scope = self._scope, None   # its tables and partial buffers live with the graph
         self._whole = whole

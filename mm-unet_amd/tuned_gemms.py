@@ -31,13 +31,34 @@ def enable():
         return
     if not os.path.exists(FILE):
         return
-    # a private copy: whatever TunableOp may write back goes there, never into the package (N ranks share the file)
+    # a private copy, created exclusively (no predictable name, no symlink to follow) and removed at exit; TunableOp is
+    # told not to write anything back
+    import atexit
     import shutil
     import tempfile
-    mine = os.path.join(tempfile.gettempdir(), f"mmunet_tuned_gemm_{os.getpid()}.csv")
-    shutil.copyfile(FILE, mine)
+    fd, mine = tempfile.mkstemp(prefix="mmunet_tuned_gemm_", suffix=".csv")
+    with os.fdopen(fd, "wb") as dst, open(FILE, "rb") as src:
+        shutil.copyfileobj(src, dst)
+    atexit.register(lambda: os.path.exists(mine) and os.remove(mine))
     tun = torch.cuda.tunable
     tun.enable(True)
     tun.tuning_enable(False)        # look-up only
+    if hasattr(tun, "write_file_on_exit"):
+        tun.write_file_on_exit(False)
     tun.set_filename(mine, insert_device_ordinal=False)
-    tun.read_file(mine)
+    global _status
+    try:
+        ok = bool(tun.read_file(mine))
+    except Exception:   # noqa: BLE001 -- a file the validators reject must not stop training: defaults everywhere
+        ok = False
+    _status = {"file": os.path.basename(FILE), "validators_ok": ok,
+               "entries": len(tun.get_results()) if ok and hasattr(tun, "get_results") else 0}
+
+
+_status = {"file": None, "validators_ok": False, "entries": 0}
+
+
+def status():
+    """What ``enable()`` found: the file, whether TunableOp's validators (library versions, GPU) accepted it, the number
+    of recorded selections in effect -- ``bench.py`` prints it in its line (``config.tuned_gemm_lookups``)."""
+    return dict(_status)

@@ -66,8 +66,8 @@ def mamba(p, h, bimamba_type, nslices):
 
     def branch(xz_, sfx, a_name):
         return _inner(xz_, p[f"conv1d{sfx}.weight"], p[f"conv1d{sfx}.bias"], p[f"x_proj{sfx}.weight"],
-                      p[f"dt_proj{sfx}.weight"], -torch.exp(p[a_name].float()), p[f"D{sfx}"].float(),
-                      p[f"dt_proj{sfx}.bias"].float())
+                      p[f"dt_proj{sfx}.weight"], -torch.exp(p[a_name].to(torch.get_default_dtype())), p[f"D{sfx}"].to(torch.get_default_dtype()),
+                      p[f"dt_proj{sfx}.bias"].to(torch.get_default_dtype()))
 
     wo, bo = p["out_proj.weight"], p.get("out_proj.bias")
     if bimamba_type == "v3":
@@ -113,8 +113,8 @@ def mmconv(p, x, K, cout, nslices=4, extend_scope=1.0):
                                   p["gn_offset.weight"], p["gn_offset.bias"]))
     y_off = off[:, :K]
     c = K // 2
-    rows = torch.arange(H, dtype=torch.float32).view(1, 1, H, 1)
-    cols = torch.arange(W, dtype=torch.float32).view(1, 1, 1, W)
+    rows = torch.arange(H, dtype=torch.get_default_dtype()).view(1, 1, H, 1)
+    cols = torch.arange(W, dtype=torch.get_default_dtype()).view(1, 1, 1, W)
     # MMUNet.py:156-172: the sums are written into a detached clone but are built from the live offsets
     cum = [None] * K
     cum[c] = torch.zeros(B, H, W)

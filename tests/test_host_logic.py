@@ -159,3 +159,25 @@ def test_mamba_type_resolution():
         assert {"A_b_log", "conv1d_s.weight", "dt_proj_b.bias", "D_s"} <= set(m.state_dict().keys())
     with pytest.raises(ValueError):
         Mamba(8, bimamba_type="v9")
+
+
+def test_deferred_scope_rejects_results_that_are_not_parameter_gradients():
+    """deferred.Scope.verify_destinations (TrainStep runs it on what the capture recorded): a deferred sum whose result
+    is not inside exactly one param.grad -- a non-leaf weight's gradient, a second gradient of the same parameter --
+    must stop the capture instead of training on stale gradients."""
+    import torch
+    from mm_unet_amd import deferred
+    a, b = torch.nn.Parameter(torch.zeros(8, 4)), torch.nn.Parameter(torch.zeros(16))
+    a.grad, b.grad = torch.zeros(8, 4), torch.zeros(16)
+    params = [("a", a), ("b", b)]
+    sc = deferred.Scope("cpu")
+    pa, pb = a.grad.data_ptr(), b.grad.data_ptr()
+    sc._rows = [[0, 1, pa, 0, 32, 2, 0, 0], [2, 1, pb, pb + 32, 1, 8, 1, 4], [4, 1, 0, pa + 64, 0, 1, 16, 0]]
+    sc.verify_destinations(params)                                  # inside the gradients (kind 4 with a NULL dA), no repeats
+    orphan = torch.zeros(8, 4)
+    sc._rows = [[0, 1, orphan.data_ptr(), 0, 32, 2, 0, 0]]
+    with pytest.raises(RuntimeError, match="no parameter gradient"):
+        sc.verify_destinations(params)
+    sc._rows = [[0, 1, pa, 0, 32, 2, 0, 0], [6, 1, pa, 0, 0, 0, 0, 0]]
+    with pytest.raises(RuntimeError, match="two deferred reductions"):
+        sc.verify_destinations(params)
