@@ -272,12 +272,14 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
         // (Measured and dropped in round 4: issuing the finishing reads behind this channel's reads and consuming them
         // behind its 16 exps -- 1,066 vs 1,066 us, 6 more VGPRs.)
 #ifndef MMU_W8_PRIO
-#define MMU_W8_PRIO 1
+#define MMU_W8_PRIO 0
 #endif
         // VALU issue goes to the OLDER of the two waves of a SIMD (waves 0-3): it runs its channel at nearly the
         // single-wave rate (3,000 cycles) and then waits 1,400 at the barrier while the younger one, starved until then,
-        // finishes alone at 0.7 of the shared rate (stamps, round 4).  The younger half leads through the first half
-        // of the channel (finish + recompute + scans) and hands the lead back for the walk: both arrive together.
+        // finishes alone (stamps, round 4).  MMU_W8_PRIO=1 lets the younger half lead through the first half of the
+        // channel and hand the lead back for the walk: the waves then arrive together (barrier waits 1,400 -> 300
+        // cycles, SQ_WAIT_ANY -9 %) -- and the kernel takes 987 instead of 970 us: what was barrier wait becomes issue
+        // stall (SQ_WAIT_INST_ANY +26 %), the SIMD's vector pipe is the limit either way.  Off.
         if (MMU_W8_PRIO && w >= 4) __builtin_amdgcn_s_setprio(1);
         if constexpr (fin) {
             Fin fbuf;

@@ -8,14 +8,15 @@ import torch
 from . import _lib, deferred
 
 ENABLED = True   # False: callers use their ATen GEMMs (tests compare the two)
+ANY_SHAPE = os.environ.get("MMUNET_GEMM_TOKENS_ANY_SHAPE", "1") != "0"   # rows / inner that are no multiples of 64 / 16
 MIN_TILES = int(os.environ.get("MMUNET_GEMM_TOKENS_MIN_TILES", "192"))   # measured break-even against hipBLASLt on the DSC shapes (csrc/gemm_tokens_mfma.hip header)
 
 
 def supported(rows, inner, tokens, *tensors):
     """Shapes the matrix-core kernel covers AND wins on: enough output tiles of 64 rows x 512 tokens to fill the
     chip (deep-K problems with few tokens would need split-K and stay with hipBLASLt)."""
-    tiles = (rows // 64) * ((tokens + 511) // 512)
-    return (ENABLED and rows % 64 == 0 and inner % 16 == 0 and tokens % 4 == 0 and tiles >= MIN_TILES
+    tiles = ((rows + 63) // 64) * ((tokens + 511) // 512)      # any rows / inner since ABI 6 (zero-padded weight images)
+    return (ENABLED and (ANY_SHAPE or (rows % 64 == 0 and inner % 16 == 0)) and tokens % 4 == 0 and tiles >= MIN_TILES
             and not torch.is_autocast_enabled()
             and all(t.is_cuda and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 for t in tensors))
 
