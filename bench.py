@@ -137,20 +137,23 @@ def scan_rooflines(dev, iters=20):
         u, delta, A, B, C, D, z, bias, dout = _scan_case(dev, b, d, l, n, "dbl")
         shape = {"batch": b, "dim": d, "seqlen": l, "dstate": n, "dtype": "f32"}
         ms_f = _timed(dev, lambda: ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False), iters)
-        x = ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False)[1]
-        ms_b = _timed(dev, lambda: ss.bwd(u, delta, A, B, C, D, z, bias, dout, x, None, None, True, False), iters)
+        # the backward as mamba_inner calls it: the forward's un-gated `out` is kept and handed over (the reference's
+        # backward reads it too, selective_scan.cpp:338) -- 8 D streams: u, delta, z, dout, out in; du, ddelta, dz out
+        out, x = ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=True)[:2]
+        ms_b = _timed(dev, lambda: ss.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, None, True, False), iters)
+        del out
         streaming = b * d >= 512
         leg("roofline" + tag,
-            "mmu_selective_scan_fwd = scan_fwd_stream_kernel (one launch: every (batch, channel) row scanned front to "
-            "back, state carried in registers)" if streaming else
+            "mmu_selective_scan_fwd = scan_fwd_stream16_kernel (one launch: every (batch, channel) row scanned front to "
+            "back, state carried in registers; 16 tokens per lane, two state pairs per wave in its half-waves)" if streaming else
             "mmu_selective_scan_fwd = chunk_reduce8 + chunk_carry_par + chunk_apply_fwd8 (chunk-parallel: too few "
             "rows to stream)", shape, s_ * b * l * (4 * d + 2 * n), ms_f,
-            "VALU issue, not HBM: one v_exp_f32 + ~5.6 VALU instructions per (d, n, t) element group against a budget "
-            "of ~6.5 issue slots at 70 % of HBM (DESIGN.md 4.1)", _traffic("scan_fwd_traffic.json") if tag == "" else None,
+            "the vector pipe, not HBM: one v_exp_f32 + ~7 VALU instructions per (d, n, t) element group (466 + 84 "
+            "transcendental per wave and 512-token tile); the time follows the instruction count (DESIGN.md 4.1)", _traffic("scan_fwd_traffic.json") if tag == "" else None,
             issue_floor_ms=_scan_issue_floor_ms(b, d, l, n, backward=False))
         leg("roofline_bwd" + tag,
             "mmu_selective_scan_bwd = chunk_reduce8<bwd> + chunk_carry_par + chunk_apply_bwd_w8 (512-token tiles, one "
-            "state pair per wave) + reduce_partials_w8",
+            "state pair per wave, 4-step row scans on the chunk carries, the forward's `out` read) + reduce_partials_w8",
             shape, s_ * b * l * (8 * d + 2 * n) + 4 * b * l * 2 * n, ms_b,
             "VALU issue: ~15 packed fp32 + 2 exp + 6.6 DPP instructions per (d, state pair, t) in the apply kernel "
             "(recompute + adjoint scan + 8 gradient streams) at ~2.5 ns per packed instruction and SIMD, DESIGN.md 4.2",
@@ -355,6 +358,16 @@ def main():
                        "global_batch": args.batch * world, "image": [3, args.size, args.size],
                        "parallelism": f"dp{world}", "grad_allreduce_bytes": step.reducer.payload_bytes(),
                        "launch": "hip-graph replay" if graph else "eager",
+                       # what the timed step consists of: on one rank ONE replayed graph holds forward, loss, backward and
+                       # AdamW; on several ranks the graph ends with the backward pass, the gradient exchange (pack ->
+                       # RCCL all-reduce -> unpack, 3 buckets) and the table-driven AdamW follow it as eager launches
+                       # -- so the per-rank step at N > 1 is not the N = 1 step plus an all-reduce
+                       "step_structure": ("graph[fwd + loss + bwd + adamw]" if world == 1 else
+                                          "graph[fwd + loss + bwd] + eager[grad all-reduce x3 buckets + adamw]") if graph
+                       else "eager[fwd + loss + bwd (+ overlapped all-reduce) + optimizer.step]",
+                       # the library GEMMs that remain (deep-K products of the small maps) take recorded selections in
+                       # look-up mode: were they accepted by this box's library versions?
+                       "tuned_gemm_lookups": __import__("mm_unet_amd.tuned_gemms", fromlist=["status"]).status(),
                        "final_loss": round(float(loss), 5)},
         }
         if not args.no_roofline:

@@ -42,7 +42,12 @@ def _worker(rank, world, port, use_graph, q):
         torch.cuda.synchronize()
         live = step.reducer.live_parameters()
         digest = torch.stack([p.detach().double().sum() for p in live]).cpu()
-        q.put((rank, losses, digest.numpy(), len(live), step.reducer.payload_bytes()))
+        # after the exchange every rank holds the SAME (mean) gradient in its static gradient tensors
+        # (graph mode: static tensors that outlive the step; the eager step has released its gradients by now)
+        gdigest = torch.stack([p.grad.detach().double().abs().sum() if p.grad is not None else torch.zeros((), dtype=torch.float64, device=dev)
+                               for p in live]).cpu()
+        mode = (step._graph is not None, getattr(step, "_whole", None), getattr(step, "_adamw", None) is not None)
+        q.put((rank, losses, digest.numpy(), len(live), step.reducer.payload_bytes(), gdigest.numpy(), mode))
     finally:
         dist.destroy_process_group()
 
@@ -53,7 +58,17 @@ def _run(use_graph, port):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
+    res = []
+    import queue
+    import time
+    t_end = time.time() + 600
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=5))
+        except queue.Empty:
+            assert time.time() < t_end, "timed out"
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died: " + str([p.exitcode for p in procs])
+    res.sort(key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -65,10 +80,16 @@ def test_two_ranks_graph_matches_eager():
     eager = _run(False, 29611)
     graph = _run(True, 29612)
     for res in (eager, graph):
-        (_, l0, d0, n0, b0), (_, l1, d1, n1, b1) = res
+        (_, l0, d0, n0, b0, g0, m0), (_, l1, d1, n1, b1, g1, m1) = res
         assert n0 == n1 and b0 == b1 and b0 > 0
         np.testing.assert_array_equal(d0, d1)            # replicas identical after 5 steps
         assert all(np.isfinite(l0)) and all(np.isfinite(l1))
+        if res is graph:
+            # the structure bench.py times at N > 1 (config.step_structure): the graph holds forward + backward only
+            # (3 replays here after 2 eager warm-ups), the exchange and the table-driven AdamW run after each replay
+            assert m0 == m1 == (True, False, True), (m0, m1)
+            np.testing.assert_array_equal(g0, g1)        # both ranks hold the averaged gradient of the last replay
+            assert float(g0.sum()) > 0
     # same trajectory in both launch modes (per-rank losses differ: each rank has its own samples).  The first
     # steps are eager warm-up in both modes; afterwards the network amplifies any difference in rounding
     # (library convolutions pick algorithms per call; tests/golden *_sens: train-mode logits move by 6e-3 under a

@@ -29,7 +29,7 @@ fb = sum(fetch.values()) * 1024 * 2
 wb = sum(write.values()) * 1024
 b, d, l, n = 8, 128, 65536, 16
 alg = 4 * b * l * (4 * d + 2 * n) if which == "fwd" else 4 * b * l * (8 * d + 2 * n) + 4 * b * l * 2 * n
-res = {"hbm_bytes_per_launch": int(fb + wb), "fetch_bytes_corrected_x2": int(fb), "write_bytes": int(wb),
+res = {"round": 4, "hbm_bytes_per_launch": int(fb + wb), "fetch_bytes_corrected_x2": int(fb), "write_bytes": int(wb),
        "algorithmic_bytes": alg, "ratio_to_algorithmic": round((fb + wb) / alg, 3),
        "per_kernel_fetch_x2": {k: int(v * 2048) for k, v in fetch.items()},
        "per_kernel_write": {k: int(v * 1024) for k, v in write.items()},
