@@ -62,7 +62,9 @@ def test_mamba_unfused_path_matches_fused():
     close(out, g["out"], 1e-4, 1e-4, "un-fused out")
 
 
-@pytest.mark.parametrize("name", ["mmconv_c16_k3_16x16", "mmconv_c16_k3_15x16", "mmconv_c32to8_k1_8x8"])
+# (19 x 19 and 38 x 38: the deepest maps of the reference's own training resolution, 608 x 608 -- config.yml:26)
+@pytest.mark.parametrize("name", ["mmconv_c16_k3_16x16", "mmconv_c16_k3_15x16", "mmconv_c32to8_k1_8x8",
+                                  "mmconv_c16_k3_19x19", "mmconv_c8_k3_38x38"])
 def test_mmconv_vs_reference(name):
     from mm_unet_amd.mmunet import MMConv
     g = golden(name)

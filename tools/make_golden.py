@@ -109,7 +109,10 @@ def main():
     if what in ("modules", "all"):
         import make_golden_modules
         make_golden_modules.main()
-    if what in ("mmnet128", "all"):     # the better-conditioned train-mode fixture of round 3 (~3 min of CPU)
+    if what == "mmconv":                # python tools/make_golden.py mmconv <fixture name> ...: single MMConv fixtures
+        import make_golden_modules
+        make_golden_modules.make_mmconv(ref_import.load_reference_model(), only=set(sys.argv[2:]))
+    if what in ("mmnet128", "all"):     # the better-conditioned train-mode fixture of round 3 (~30 min of CPU here)
         import make_golden_modules
         R = ref_import.load_reference_model()
         make_golden_modules.make_mmnet_train128(R)

@@ -46,9 +46,14 @@ def make_mamba(R):
              nslices=np.array(ns), btype=np.array(btype), **_sd(m), **grads, **extra)
 
 
-def make_mmconv(R):
+def make_mmconv(R, only=None):
+    # (round 4: 19 x 19 and 38 x 38 -- the two deepest maps of the reference's own training resolution, 608 x 608
+    #  (config.yml:26): neither side a power of two, 361 / 1,444 tokens)
     for name, cin, cout, k, h, w in (("c16_k3_16x16", 16, 16, 3, 16, 16), ("c16_k3_15x16", 16, 16, 3, 15, 16),
-                                     ("c32to8_k1_8x8", 32, 8, 1, 8, 8)):
+                                     ("c32to8_k1_8x8", 32, 8, 1, 8, 8), ("c16_k3_19x19", 16, 16, 3, 19, 19),
+                                     ("c8_k3_38x38", 8, 8, 3, 38, 38)):
+        if only is not None and name not in only:
+            continue
         torch.manual_seed(3)
         m = R.MMConv(cin, cout, kernel_size=k, num_slices=4)
         m.train()
@@ -270,6 +275,7 @@ def make_blocks(R):
 
 def main():
     R = ref_import.load_reference_model()
+
     print("Mamba fixtures (reference mamba_simple.Mamba on CPU)")
     make_mamba(R)
     print("MMConv fixtures")
