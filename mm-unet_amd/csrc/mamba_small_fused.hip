@@ -49,7 +49,9 @@ __device__ unsigned long long g_small_stamps[2 * 8 * 16];   // [fwd / bwd][wave]
 namespace {
 
 struct SmallArgs {
-    int B, H, W, lw, N;  // lw = log2(W): H and W are powers of two (H * W = 64 * TL is one), no integer division anywhere
+    int B, H, W, lw, N;  // lw = log2(W) when W is a power of two (shifts instead of divisions), -1 otherwise
+    int Lr;              // H * W: the real tokens; the kernels' tables hold L = 64 * TL >= Lr slots, the rest are padding
+                         // (y_off = d rows = 0 there: behind the last real token in the forward scan, g = 0 in the adjoint)
     int ns, npp;         // state-range parts per batch item (grid.y) and states per part (N = ns * npp)
     float scope;
     const float *off;    // [B, 2K, H, W]
@@ -68,20 +70,28 @@ struct SmallArgs {
         const float *__restrict__ Aw, const float *__restrict__ Dw, const float *__restrict__ wout,                  \
         const float *__restrict__ altho
 
-// zig-zag token of pixel (h, w) and back; W = 1 << lw
-__device__ __forceinline__ int zig_of(int h, int w, int H, int lw) {
+// zig-zag token of pixel (h, w) and back (two-row zig-zag, MMUNet.py:196-242); lw >= 0: W = 1 << lw
+__device__ __forceinline__ int zig_of(int h, int w, int H, int W, int lw) {
     const int He = H & ~1;
-    return h < He ? ((h >> 1) << (lw + 1)) + 2 * w + (h & 1) : (He << lw) + w;
+    if (lw >= 0) return h < He ? ((h >> 1) << (lw + 1)) + 2 * w + (h & 1) : (He << lw) + w;
+    return h < He ? (h >> 1) * (2 * W) + 2 * w + (h & 1) : He * W + w;
 }
-__device__ __forceinline__ void unzig(int l, int H, int lw, int &h, int &w) {
+__device__ __forceinline__ void unzig(int l, int H, int W, int lw, int &h, int &w) {
     const int He = H & ~1;
-    if (l < (He << lw)) {
-        const int p = l >> (lw + 1), r = l & ((2 << lw) - 1);
+    if (l < He * W) {
+        int p, r;
+        if (lw >= 0) {
+            p = l >> (lw + 1);
+            r = l & ((2 << lw) - 1);
+        } else {
+            p = (int)((unsigned)l / (unsigned)(2 * W));
+            r = l - p * 2 * W;
+        }
         h = 2 * p + (r & 1);
         w = r >> 1;
     } else {
         h = He;
-        w = l - (He << lw);
+        w = l - He * W;
     }
 }
 
@@ -124,10 +134,14 @@ __device__ __forceinline__ void run_load(const float *q, float (&v)[TL]) {
             const float4 f = *reinterpret_cast<const float4 *>(q + i);
             v[i] = f.x; v[i + 1] = f.y; v[i + 2] = f.z; v[i + 3] = f.w;
         }
-    } else if constexpr (TL == 2) {
-        const float2 f = *reinterpret_cast<const float2 *>(q);
-        v[0] = f.x; v[1] = f.y;
+    } else if constexpr (TL % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < TL; i += 2) {
+            const float2 f = *reinterpret_cast<const float2 *>(q + i);
+            v[i] = f.x; v[i + 1] = f.y;
+        }
     } else {
+        static_assert(TL == 1, "odd runs other than 1 are not instantiated");
         v[0] = q[0];
     }
 }
@@ -136,8 +150,9 @@ __device__ __forceinline__ void run_store(float *q, const float (&v)[TL]) {
     if constexpr (TL % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < TL; i += 4) *reinterpret_cast<float4 *>(q + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-    } else if constexpr (TL == 2) {
-        *reinterpret_cast<float2 *>(q) = make_float2(v[0], v[1]);
+    } else if constexpr (TL % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < TL; i += 2) *reinterpret_cast<float2 *>(q + i) = make_float2(v[i], v[i + 1]);
     } else {
         q[0] = v[0];
     }
@@ -149,20 +164,33 @@ __device__ __forceinline__ void stage_zig(const SmallArgs &p, const float *__res
     constexpr int NT = 128 * K;                    // threads: 64 per channel, 2K channels
     constexpr int IT = (K * 64 * TL + NT - 1) / NT;  // values per thread
     constexpr int L = 64 * TL;
+    const int Lr = p.Lr, n = K * Lr;               // src: [K][H][W] of one batch item, Lr = H * W <= L values per channel
     float v[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int idx = it * NT + threadIdx.x;
-        v[it] = idx < K * L ? src[idx] : 0.f;
+        v[it] = idx < n ? src[idx] : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int idx = it * NT + threadIdx.x;
-        if (idx < K * L) {
-            const int k = idx / L, r = idx & (L - 1);
-            const int h = r >> p.lw, ww = r & (p.W - 1);
-            dst[k * L + zig_of(h, ww, p.H, p.lw)] = v[it];
+        if (idx < n) {
+            int k, r, h, ww;
+            if (p.lw >= 0 && Lr == L) {
+                k = idx / L; r = idx & (L - 1);
+                h = r >> p.lw; ww = r & (p.W - 1);
+            } else {
+                k = (int)((unsigned)idx / (unsigned)Lr); r = idx - k * Lr;
+                h = (int)((unsigned)r / (unsigned)p.W); ww = r - h * p.W;
+            }
+            dst[k * L + zig_of(h, ww, p.H, p.W, p.lw)] = v[it];
         }
+    }
+    // the padding slots [Lr, L) of every channel row (the zig-zag order maps the Lr pixels onto [0, Lr))
+    const int pad = L - Lr;
+    for (int i = threadIdx.x; i < K * pad; i += NT) {
+        const int k = i / pad;
+        dst[k * L + Lr + (i - k * pad)] = 0.f;
     }
 }
 
@@ -306,7 +334,7 @@ __global__ __launch_bounds__(128 * K) void mamba_small_fwd_kernel(SmallArgs p, W
     const bool first = part == 0;     // the terms that are not sums over the states belong to part 0
     SMALL_STAMP(0, 0);
     const ChanW<K> cwv = load_chan<K>(d, first, W_ARGS);
-    stage_zig<K, TL>(p, p.off + (long)b * 2 * K * L, yoff);
+    stage_zig<K, TL>(p, p.off + (long)b * 2 * K * p.Lr, yoff);
     stage_wl<D>(wl, wx, Aw, N, n0, npp);
     __syncthreads();
     SMALL_STAMP(0, 1);
@@ -377,10 +405,10 @@ __global__ __launch_bounds__(128 * K) void mamba_small_fwd_kernel(SmallArgs p, W
     float dummy;
     const float wgt = coord_weight(cwv.altho, dummy);
     constexpr int c = K / 2;
-    float *yb = p.y + ((long)part * p.B + b) * K * L;
-    for (int l = tid; l < L; l += blockDim.x) {
+    float *yb = p.y + ((long)part * p.B + b) * K * p.Lr;
+    for (int l = tid; l < p.Lr; l += blockDim.x) {
         int h, ww;
-        unzig(l, p.H, p.lw, h, ww);
+        unzig(l, p.H, p.W, p.lw, h, ww);
         float oz[D], off[K], cum[K];
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) oz[dd] = ut[dd * L + l];
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(128 * K) void mamba_small_fwd_kernel(SmallArgs p, W
             float sq = 0.f;
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) sq = fmaf(wout[k * D + dd], oz[dd], sq);
-            yb[((k * p.H + h) << p.lw) + ww] = fmaf(wgt, sq, first ? (float)h + p.scope * cum[k] : 0.f);
+            yb[(k * p.H + h) * p.W + ww] = fmaf(wgt, sq, first ? (float)h + p.scope * cum[k] : 0.f);
         }
     }
     SMALL_STAMP(0, 4);
@@ -444,8 +472,8 @@ __global__ __launch_bounds__(128 * K) void mamba_small_bwd_kernel(SmallArgs p, W
     const bool first = part == 0;
     SMALL_STAMP(1, 0);
     const ChanW<K> cwv = load_chan<K>(d, first, W_ARGS);
-    stage_zig<K, TL>(p, p.off + (long)b * 2 * K * L, yoff);
-    stage_zig<K, TL>(p, p.dy + (long)b * K * L, dyz);
+    stage_zig<K, TL>(p, p.off + (long)b * 2 * K * p.Lr, yoff);
+    stage_zig<K, TL>(p, p.dy + (long)b * K * p.Lr, dyz);
     stage_wl<D>(wl, wx, Aw, N, n0, npp);
     for (int i = tid; i < NV; i += blockDim.x) wpart[i] = 0.f;   // (the other parts' rows of dW_x / dA stay 0)
     __syncthreads();
@@ -691,8 +719,8 @@ __global__ __launch_bounds__(128 * K) void mamba_small_bwd_kernel(SmallArgs p, W
     SMALL_STAMP(1, 6);
     {
         constexpr int c = K / 2;
-        float *db = p.doff + ((long)part * p.B + b) * K * L;
-        for (int l = tid; l < L; l += blockDim.x) {
+        float *db = p.doff + ((long)part * p.B + b) * K * p.Lr;
+        for (int l = tid; l < p.Lr; l += blockDim.x) {
             float g[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) g[k] = 0.f;
@@ -718,9 +746,9 @@ __global__ __launch_bounds__(128 * K) void mamba_small_bwd_kernel(SmallArgs p, W
                 }
             }
             int h, ww;
-            unzig(l, p.H, p.lw, h, ww);
+            unzig(l, p.H, p.W, p.lw, h, ww);
 #pragma unroll
-            for (int k = 0; k < K; ++k) db[((k * p.H + h) << p.lw) + ww] = g[k];
+            for (int k = 0; k < K; ++k) db[(k * p.H + h) * p.W + ww] = g[k];
         }
     }
     SMALL_STAMP(1, 7);
@@ -798,12 +826,15 @@ __global__ __launch_bounds__(256) void mamba_small_reduce_kernel(const float *__
     doff[idx] = s;
 }
 
-// tokens per lane: L = 64 * TL with TL in {1, 2, 4, 8, 16}
+// tokens per lane: the smallest TL in {1, 2, 4, 6, 8, 12, 16} with 64 * TL >= L (L = height * width <= 1,024: any
+// map, power-of-two sides or not -- 19 x 19 = 361 tokens of the reference's 608 x 608 training resolution run as
+// TL = 6 with 23 padding slots)
 bool plan(int L, int &TL) {
-    for (int t = 1; t <= 16; t *= 2) {
-        if (L == 64 * t) {
+    static const int tls[] = {1, 2, 4, 6, 8, 12, 16};
+    for (int t : tls) {
+        if (L <= 64 * t) {
             TL = t;
-            return true;
+            return L >= 1;
         }
     }
     return false;
@@ -844,9 +875,8 @@ int check(const mmu_mamba_small_params *p, const char *name, int &TL) {
     MMU_CHECK(p->taps == 1 || p->taps == 3, "%s: 1 or 3 taps supported (got %d)", name, p->taps);
     MMU_CHECK(p->batch > 0 && p->height > 0 && p->width > 0, "%s: empty tensor", name);
     MMU_CHECK(p->dstate >= 1 && p->dstate <= 64, "%s: d_state must be in 1..64 (got %d)", name, p->dstate);
-    MMU_CHECK(plan(p->height * p->width, TL) && (p->width & (p->width - 1)) == 0,
-              "%s: height and width must be powers of two with height * width in 64 .. 1024 (got %d x %d)", name,
-              p->height, p->width);
+    MMU_CHECK(plan(p->height * p->width, TL), "%s: height * width must be at most 1,024 (got %d x %d)", name, p->height,
+              p->width);
     MMU_CHECK(p->parts >= 1 && p->dstate % p->parts == 0, "%s: parts (%d) must divide d_state (%d)", name, p->parts,
               p->dstate);
     MMU_CHECK(p->offset && p->in_proj_weight && p->conv_weight && p->x_proj_weight && p->dt_proj_weight && p->A &&
@@ -858,8 +888,12 @@ int check(const mmu_mamba_small_params *p, const char *name, int &TL) {
 SmallArgs to_args(const mmu_mamba_small_params *p) {
     SmallArgs a = {};
     a.B = p->batch; a.H = p->height; a.W = p->width; a.N = p->dstate;
-    a.lw = 0;
-    while ((1 << a.lw) < p->width) ++a.lw;
+    a.lw = -1;
+    if ((p->width & (p->width - 1)) == 0) {
+        a.lw = 0;
+        while ((1 << a.lw) < p->width) ++a.lw;
+    }
+    a.Lr = p->height * p->width;
     a.ns = p->parts; a.npp = p->dstate / p->parts;
     a.scope = p->extend_scope;
     a.off = p->offset; a.y = p->y; a.dy = p->dy;
@@ -881,7 +915,9 @@ int set_lds_attr(F kernel, size_t bytes, const char *name) {
         case 1: KERNEL(K_, 1, __VA_ARGS__); break;       \
         case 2: KERNEL(K_, 2, __VA_ARGS__); break;       \
         case 4: KERNEL(K_, 4, __VA_ARGS__); break;       \
+        case 6: KERNEL(K_, 6, __VA_ARGS__); break;       \
         case 8: KERNEL(K_, 8, __VA_ARGS__); break;       \
+        case 12: KERNEL(K_, 12, __VA_ARGS__); break;     \
         default: KERNEL(K_, 16, __VA_ARGS__); break;     \
     }
 #define SMALL_DISPATCH(KERNEL, ...)                      \
@@ -905,12 +941,13 @@ extern "C" int mmu_debug_small_stamps(unsigned long long *host_out) {
 
 extern "C" int mmu_mamba_small_supported(int taps, int height, int width, int dstate) {
     int TL;
-    return (taps == 1 || taps == 3) && dstate >= 1 && dstate <= 64 && height > 0 && width > 0 &&
-           (width & (width - 1)) == 0 && plan(height * width, TL);
+    return (taps == 1 || taps == 3) && dstate >= 1 && dstate <= 64 && height > 0 && width > 0 && plan(height * width, TL);
 }
 
 extern "C" int mmu_mamba_small_parts(int batch, int taps, int height, int width, int dstate, int backward) {
-    return default_parts(batch, taps, height * width, dstate, backward);
+    int TL = 16;
+    plan(height * width, TL);
+    return default_parts(batch, taps, 64 * TL, dstate, backward);
 }
 
 // floats of the backward workspace: batch * parts weight-gradient partial vectors + parts partial d offset maps
@@ -931,7 +968,7 @@ extern "C" int mmu_mamba_small_fwd(const mmu_mamba_small_params *p, void *stream
     if (int r = check(p, "mamba_small_fwd", TL)) return r;
     MMU_CHECK(p->y != nullptr, "mamba_small_fwd: y is required");
     const SmallArgs a = to_args(p);
-    const size_t lds = sizeof(float) * fwd_lds_floats(p->taps, p->height * p->width, a.npp);
+    const size_t lds = sizeof(float) * fwd_lds_floats(p->taps, 64 * TL, a.npp);
     hipStream_t st = (hipStream_t)stream;
 #define SMALL_FWD(K_, T_, a_)                                                                         \
     if (int r = set_lds_attr(mamba_small_fwd_kernel<K_, T_>, lds, "mamba_small_fwd")) return r;       \
@@ -953,7 +990,7 @@ extern "C" int mmu_mamba_small_bwd(const mmu_mamba_small_params *p, void *stream
     // workspace: [B * parts][NV] weight-gradient partials, then [parts][B][K][L] partial d offset
     a.part = p->workspace;
     a.doff = p->workspace + (size_t)a.B * a.ns * NV;
-    const size_t lds = sizeof(float) * bwd_lds_floats(K, p->height * p->width, a.npp, NV);
+    const size_t lds = sizeof(float) * bwd_lds_floats(K, 64 * TL, a.npp, NV);
     hipStream_t st = (hipStream_t)stream;
 #define SMALL_BWD(K_, T_, a_)                                                                         \
     if (int r = set_lds_attr(mamba_small_bwd_kernel<K_, T_>, lds, "mamba_small_bwd")) return r;       \
