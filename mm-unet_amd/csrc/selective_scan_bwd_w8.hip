@@ -50,10 +50,20 @@ namespace {
 
 constexpr int W8_TT = 512, W8_AS = 544, W8_SUB = 272, W8_XS = 1632, W8_SUB2 = 272;
 
-template <typename io_t>
-__device__ __forceinline__ float ld1(const io_t *p) { return to_f32(*p); }
-template <typename io_t>
-__device__ __forceinline__ void st1(io_t *p, float v) { *p = from_f32<io_t>(v); }
+// The per-lane stream pointers live in the GLOBAL address space by type: they are made opaque to the compiler below
+// (asm "+v"), and a generic pointer would lose the address-space inference there -- flat_load / flat_store, which
+// count in lgkmcnt as well and return out of order.
+#define MMU_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float ld1(const MMU_GLOBAL float *p) { return *p; }
+__device__ __forceinline__ float ld1(const MMU_GLOBAL bf16_t *p) {
+    bf16_t v;
+    v.bits = *reinterpret_cast<const MMU_GLOBAL uint16_t *>(p);
+    return to_f32(v);
+}
+__device__ __forceinline__ void st1(MMU_GLOBAL float *p, float v) { *p = v; }
+__device__ __forceinline__ void st1(MMU_GLOBAL bf16_t *p, float v) {
+    *reinterpret_cast<MMU_GLOBAL uint16_t *>(p) = from_f32<bf16_t>(v).bits;
+}
 
 // Y_IN: the forward's y (before gating) is read from p.out instead of being recomputed: no C h products, no y row in
 // the exchange (a third of its LDS traffic), no eight-wave sum per token.
@@ -99,15 +109,15 @@ __global__ __launch_bounds__(512, 1) void chunk_apply_bwd_w8_kernel(ScanArgs p) 
     // running per-lane pointers (token T of the tile; one 64-bit add per stream and channel -- the scalar file has
     // no room for nine uniform bases and their strides): f_* = the channel of the next fetch (two ahead of the
     // loop), o_* = the loop's channel
-    const io_t *f_dl = (const io_t *)p.delta + (long)b * p.delta_bs + (long)dbeg * p.delta_ds + t0 + T;
-    const io_t *f_u = (const io_t *)p.u + (long)b * p.u_bs + (long)dbeg * p.u_ds + t0 + T;
-    const io_t *f_go = (const io_t *)p.dout + (long)b * p.dout_bs + (long)dbeg * p.dout_ds + t0 + T;
-    const io_t *f_z = HAS_Z ? (const io_t *)p.z + (long)b * p.z_bs + (long)dbeg * p.z_ds + t0 + T : nullptr;
-    const io_t *f_y = Y_IN ? (const io_t *)p.out + (long)b * p.out_bs + (long)dbeg * p.out_ds + t0 + T : nullptr;
-    io_t *o_du = (io_t *)p.du + (long)b * p.du_bs + (long)dbeg * p.du_ds + t0 + T;
-    io_t *o_dd = (io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)dbeg * p.ddelta_ds + t0 + T;
-    io_t *o_dz = HAS_Z ? (io_t *)p.dz + (long)b * p.dz_bs + (long)dbeg * p.dz_ds + t0 + T : nullptr;
-    io_t *o_oz = HAS_OZ ? (io_t *)p.out_z + (long)b * p.out_z_bs + (long)dbeg * p.out_z_ds + t0 + T : nullptr;
+    const MMU_GLOBAL io_t *f_dl = (const MMU_GLOBAL io_t *)((const io_t *)p.delta + (long)b * p.delta_bs + (long)dbeg * p.delta_ds + t0 + T);
+    const MMU_GLOBAL io_t *f_u = (const MMU_GLOBAL io_t *)((const io_t *)p.u + (long)b * p.u_bs + (long)dbeg * p.u_ds + t0 + T);
+    const MMU_GLOBAL io_t *f_go = (const MMU_GLOBAL io_t *)((const io_t *)p.dout + (long)b * p.dout_bs + (long)dbeg * p.dout_ds + t0 + T);
+    const MMU_GLOBAL io_t *f_z = (const MMU_GLOBAL io_t *)(HAS_Z ? (const io_t *)p.z + (long)b * p.z_bs + (long)dbeg * p.z_ds + t0 + T : nullptr);
+    const MMU_GLOBAL io_t *f_y = (const MMU_GLOBAL io_t *)(Y_IN ? (const io_t *)p.out + (long)b * p.out_bs + (long)dbeg * p.out_ds + t0 + T : nullptr);
+    MMU_GLOBAL io_t *o_du = (MMU_GLOBAL io_t *)((io_t *)p.du + (long)b * p.du_bs + (long)dbeg * p.du_ds + t0 + T);
+    MMU_GLOBAL io_t *o_dd = (MMU_GLOBAL io_t *)((io_t *)p.ddelta + (long)b * p.ddelta_bs + (long)dbeg * p.ddelta_ds + t0 + T);
+    MMU_GLOBAL io_t *o_dz = (MMU_GLOBAL io_t *)(HAS_Z ? (io_t *)p.dz + (long)b * p.dz_bs + (long)dbeg * p.dz_ds + t0 + T : nullptr);
+    MMU_GLOBAL io_t *o_oz = (MMU_GLOBAL io_t *)(HAS_OZ ? (io_t *)p.out_z + (long)b * p.out_z_bs + (long)dbeg * p.out_z_ds + t0 + T : nullptr);
     // one opaque 64-bit register pair per stream: left visible, the bf16 build splits each into a uniform base (kept in
     // VGPRs: the scalar file is full) plus a lane offset -- 12 more VGPRs, 20 spilled, 18 v_mov_b64 per two channels
     asm volatile("" : "+v"(f_dl), "+v"(f_u), "+v"(f_go), "+v"(f_z), "+v"(f_y));
