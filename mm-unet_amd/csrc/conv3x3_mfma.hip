@@ -191,11 +191,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
     prefetch();
     MMU_LDS_BARRIER();
     int c_tj = 0, c_ch = 0;
+    // The two waves of a SIMD (w and w + 4) run the same program between the same barriers: both convert and store the next
+    // chunk (~340 vector instructions per 108 MFMAs) at the top of an iteration, then both queue on the matrix pipe.
+    // MMU_CONV3_STAGGER=1 makes waves 4-7 stage BEHIND their MFMAs, so that on every SIMD one wave's staging runs beside the
+    // other's matrix work -- measured (round 4): 118.2 / 118.4 us against 118.6 / 121.7 without, i.e. nothing; off.
+#ifndef MMU_CONV3_STAGGER
+#define MMU_CONV3_STAGGER 0
+#endif
+    const bool late = MMU_CONV3_STAGGER && wv >= 4;
     for (int it = 0; it < niter; ++it) {
         const unsigned char *cur = lds + (it & 1) * STAGE_BYTES;
         const unsigned char *patch_hi = cur, *patch_lo = cur + PATCH_BYTES, *w_hi = cur + 2 * PATCH_BYTES;
-        stage(lds + ((it + 1) & 1) * STAGE_BYTES);
-        prefetch();
+        if (!late) {
+            stage(lds + ((it + 1) & 1) * STAGE_BYTES);
+            prefetch();
+        }
         // keep the loads ahead of the MFMAs: left alone, the scheduler sinks them behind the last MFMA (their
         // destination registers then double as fragment registers) and every chunk waits out a full memory latency
         __builtin_amdgcn_sched_barrier(0);
@@ -223,6 +233,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
                 }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (late) {
+            stage(lds + ((it + 1) & 1) * STAGE_BYTES);
+            prefetch();
         }
         if (++c_ch == nch) {
             // ---- tile done: C layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
