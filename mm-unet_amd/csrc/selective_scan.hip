@@ -297,7 +297,6 @@ __global__ __launch_bounds__(512, 4) void chunk_reduce8_kernel(ScanArgs p) {
                 e[2 * k] = exp2_2(mul_bcast<0>(cum2[k], a2));
                 e[2 * k + 1] = exp2_2(mul_bcast<1>(cum2[k], a2));
             }
-            const v2f Pt = exp2_2(a2 * tot);
             a2n = *reinterpret_cast<const v2f *>(cA + 2 * (pr + 1 < NP ? pr + 1 : pr));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -312,13 +311,17 @@ __global__ __launch_bounds__(512, 4) void chunk_reduce8_kernel(ScanArgs p) {
             const float s1 = BWD ? row_scan_add_up(s.y) : row_scan_add_down(s.y);
             if (writer) {
                 float *r = sR + q * 2 * N + 4 * pr;
-                r[0] = Pt.x;
                 r[1] = s0;
-                if (2 * pr + 1 < N) {
-                    r[2] = Pt.y;
-                    r[3] = s1;
-                }
+                if (2 * pr + 1 < N) r[3] = s1;
             }
+        }
+        // the chunks' decay products exp2(A2[n] * sum of the chunk's deltas): ONE exp per lane for the whole channel -- lane
+        // l takes state l & 15 (l & 15 + 16 k for larger N) of its own row's chunk -- instead of two per pair and lane (every
+        // lane of a row used to compute the same sixteen values, 11 % of the kernel's transcendentals)
+        {
+            // (the chunk total stands on the row's last lane (backward) / first lane (forward): row_newbcast hands it to the row)
+            const float tot_row = BWD ? dpp_mov<0x150 + 15, 0xf>(0.f, tot) : dpp_mov<0x150, 0xf>(0.f, tot);
+            for (int n = lane & 15; n < N; n += 16) sR[q * 2 * N + 2 * n] = fast_exp2(cA[n] * tot_row);
         }
         // drain the prefetch group BEFORE the record stores: the loop header would otherwise have to wait for
         // its youngest load (bias) with vmcnt(0), i.e. for this channel's stores to be acknowledged
