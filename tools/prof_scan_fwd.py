@@ -1,4 +1,5 @@
-"""Runs ONLY the selective-scan forward (inference form, no `out`) at the headline shape, N launches."""
+"""Runs ONLY the selective-scan forward at the headline shape, N launches: the inference form (no `out`) by default,
+PROF_FWD_OUT=1: with the un-gated `out` written too (what mamba_inner's training forward asks for since round 4)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mm_unet_amd import selective_scan_hip as ss
@@ -16,5 +17,5 @@ z = torch.randn(b, d, l, device=DEV, generator=g)
 delta = 0.5 * torch.rand(b, d, l, device=DEV, generator=g)
 torch.cuda.synchronize()
 for _ in range(it):
-    ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=False)
+    ss.fwd(u, delta, A, B, C, D, z, bias, True, want_out=os.environ.get("PROF_FWD_OUT") == "1")
 torch.cuda.synchronize()
