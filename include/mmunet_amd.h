@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 6
+#define MMU_ABI_VERSION 7
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -336,6 +336,55 @@ typedef struct {
 
 int mmu_tri_split(const mmu_tri_params *p, void *stream);
 int mmu_tri_combine(const mmu_tri_params *p, void *stream);
+
+/* ---- f2: the three token orders folded into the block's conv1d and its gate (csrc/tri_fused.hip) ---------- */
+/* requirements/mamba_simple.py:212-270 calls mamba_inner_fn_no_out_proj (selective_scan_interface.py:155-289) on xz, on
+ * xz.flip(-1) and on the slice-interleaved xz, and adds out + out_b.flip(-1) + unslice(out_s).  Only the conv1d reads x
+ * and the gate z is the same tensor in every direction, so:
+ *   tri_conv_fwd : x (batch, dim, L; the x half of xz, any batch / channel stride) -> the three silu(causal_conv1d)
+ *                  outputs [dim][batch][L], each in ITS scan order (f: natural, b: position L-1-t, s: position i*nslices+s
+ *                  for token s*(L/nslices)+i), with the three directions' own weights [dim][4] / biases [dim]
+ *                  (causal_conv1d_fwd.cu:39-158, width 4, SiLU);
+ *   tri_conv_bwd : the three d conv_out (scan order) -> dx (natural order) and the three dweight / dbias; per-block
+ *                  partial sums in `workspace` (mmu_tri_conv_bwd_workspace_floats() floats) added in a fixed order;
+ *   tri_gate_fwd : out[t] = silu(z[t]) * (y_f[t] + y_b[L-1-t] + y_s[i*nslices+s]), y_* the un-gated scan outputs
+ *                  (selective_scan with z = NULL), [dim][batch][L] in scan order  (= mamba_simple.py:270's sum);
+ *   tri_gate_bwd : dout -> dz (natural order) and the three dy in scan order.
+ * float32, 4 <= nslices <= 64, L divisible by nslices. */
+typedef struct {
+    int32_t batch, dim, seqlen, nslices, dtype;
+    const void *x;
+    int64_t x_bs, x_ds;
+    const float *weight_f, *weight_b, *weight_s;
+    const float *bias_f, *bias_b, *bias_s;        /* NULL: no bias */
+    void *out_f, *out_b, *out_s;                  /* fwd */
+    const void *dout_f, *dout_b, *dout_s;         /* bwd */
+    void *dx;
+    int64_t dx_bs, dx_ds;
+    float *dweight_f, *dweight_b, *dweight_s;
+    float *dbias_f, *dbias_b, *dbias_s;           /* NULL: not wanted */
+    float *workspace;
+} mmu_tri_conv_params;
+
+typedef struct {
+    int32_t batch, dim, seqlen, nslices, dtype;
+    const void *z;
+    int64_t z_bs, z_ds;
+    const void *y_f, *y_b, *y_s;
+    void *out;                                    /* fwd */
+    int64_t out_bs, out_ds;
+    const void *dout;                             /* bwd */
+    int64_t dout_bs, dout_ds;
+    void *dz;
+    int64_t dz_bs, dz_ds;
+    void *dy_f, *dy_b, *dy_s;
+} mmu_tri_gate_params;
+
+int mmu_tri_conv_fwd(const mmu_tri_conv_params *p, void *stream);
+size_t mmu_tri_conv_bwd_workspace_floats(int batch, int dim, int seqlen, int nslices);
+int mmu_tri_conv_bwd(const mmu_tri_conv_params *p, void *stream);
+int mmu_tri_gate_fwd(const mmu_tri_gate_params *p, void *stream);
+int mmu_tri_gate_bwd(const mmu_tri_gate_params *p, void *stream);
 
 /* ---- GroupNorm [-> BatchNorm2d] [-> ReLU | tanh] as one normalisation (a9/a11 blocks) ------------------ */
 /* nn.GroupNorm(groups, C) optionally followed by nn.BatchNorm2d(C) (training or eval statistics) and an

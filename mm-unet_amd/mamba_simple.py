@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from .causal_conv1d_interface import causal_conv1d_fn
 from .selective_scan_interface import _dbl_view, mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn
-from . import deferred, tri_order
+from . import deferred, tri_inner, tri_order
 from .tall_gemm import proj_bcl, proj_tokens
 
 
@@ -188,6 +188,12 @@ class Mamba(nn.Module):
                                           g("dt_proj").weight, A, None, None, g("D").float(),
                                           delta_bias=g("dt_proj").bias.float(), delta_softplus=True)
 
+    def _dir_params(self, suffix):
+        g = lambda n: getattr(self, n + suffix)  # noqa: E731
+        A = neg_exp(getattr(self, {"": "A_log", "_b": "A_b_log", "_s": "A_s_log"}[suffix]))
+        return (g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A, g("D").float(),
+                g("dt_proj").bias.float())
+
     def _out_proj(self, y):
         """(B, d_inner, L) -> (B, L, d_model): out_proj applied tokens-last (mamba_simple.py:270)."""
         batch, _, seqlen = y.shape
@@ -203,6 +209,12 @@ class Mamba(nn.Module):
         if seqlen % self.nslices != 0:
             raise RuntimeError(f"Mamba v3: seqlen {seqlen} must be divisible by nslices {self.nslices}")
         ns = self.nslices
+        if not self.return_branch_outputs:
+            # one conv1d pass for the three token orders, three scans without z, one sum + gate pass (tri_inner.py): the
+            # re-ordered copies of xz and the three gated outputs are never formed
+            dirs = [self._dir_params(sfx) for sfx in ("", "_b", "_s")]
+            if tri_inner.supported(xz, ns, [d[0] for d in dirs], [t for d in dirs for t in d]):
+                return tri_inner.tri_mamba_inner(xz, ns, dirs), None, None, None
         fused = tri_order.supported(xz, nslices=ns)
         if fused:   # flip + slice-interleave in one pass; the three input gradients meet in one kernel
             xz_a, xz_f, xz_s = tri_order.tri_split(xz, ns)

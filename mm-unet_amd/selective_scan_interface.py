@@ -247,6 +247,35 @@ def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj
     return x_dblT, delta, B, C
 
 
+def _project_backward(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_weight, delta_proj_weight):
+    """Backward of :func:`_project` once the scan has left d delta and (in rows r.. of ``dx_dblT``) dB / dC
+    (selective_scan_interface.py:273-277): returns (d x_proj_weight, d delta_proj_weight, d conv1d_out), the last one
+    = ``dconv1d_out + W_x^T d x_dbl`` (in place when ``dconv1d_out`` is laid out [D][B][L])."""
+    batch, dim, L = ddelta.shape
+    r = delta_proj_weight.shape[1]
+    direct = dx_dblT.dtype == torch.float32
+    ddelta_m = _dbl_view(ddelta)                                            # (D, B*L)
+    ddelta_proj_weight = nt_splitk(ddelta_m, x_dblT[:r]).to(delta_proj_weight.dtype)  # (D, r)      (:273)
+    conv_m = _dbl_view(conv1d_out)
+    dconv_m = _dbl_view(dconv1d_out)                                        # (D, B*L)
+    own = (dconv_m.data_ptr() == dconv1d_out.data_ptr() and direct and dx_dblT.is_contiguous()
+           and _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, batch * L)
+           and mfma_gemm.dt_proj_supported(delta_proj_weight, dx_dblT[:r], ddelta_m)
+           and mfma_gemm.tokens_supported(dconv_m, dx_dblT) and dconv_m.stride(1) == 1 and dconv_m.stride(0) % 4 == 0)
+    if own:
+        mfma_gemm.dt_proj_input_grad(delta_proj_weight, ddelta_m, dx_dblT[:r])  # (r, B*L)         (:274)
+    else:
+        torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])     # (r, B*L)              (:274)
+    dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
+    if own:
+        mfma_gemm.x_proj_input_grad_add(x_proj_weight, dx_dblT, dconv_m)   # d conv += W_x^T d x_dbl, in place   (:277)
+    elif dconv_m.data_ptr() == dconv1d_out.data_ptr():
+        dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
+    else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
+        dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dblT)
+    return dx_proj_weight, ddelta_proj_weight, dconv_m.view(dim, batch, L).permute(1, 0, 2)
+
+
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                    out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, checkpoint_lvl,
                    with_out_proj):
@@ -386,26 +415,8 @@ def _inner_backward(ctx, dout):
         dx_proj_weight, ddelta_proj_weight = _post_small(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out,
                                                          x_proj_weight, delta_proj_weight)
     else:
-        ddelta_m = _dbl_view(ddelta)                                            # (D, B*L)
-        ddelta_proj_weight = nt_splitk(ddelta_m, x_dblT[:r]).to(delta_proj_weight.dtype)  # (D, r)      (:273)
-        conv_m = _dbl_view(conv1d_out)
-        dconv_m = _dbl_view(dconv1d_out)                                        # (D, B*L)
-        own = (dconv_m.data_ptr() == dconv1d_out.data_ptr() and direct and dx_dblT.is_contiguous()
-               and _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, batch * L)
-               and mfma_gemm.dt_proj_supported(delta_proj_weight, dx_dblT[:r], ddelta_m)
-               and mfma_gemm.tokens_supported(dconv_m, dx_dblT) and dconv_m.stride(1) == 1 and dconv_m.stride(0) % 4 == 0)
-        if own:
-            mfma_gemm.dt_proj_input_grad(delta_proj_weight, ddelta_m, dx_dblT[:r])  # (r, B*L)         (:274)
-        else:
-            torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])     # (r, B*L)              (:274)
-        dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
-        if own:
-            mfma_gemm.x_proj_input_grad_add(x_proj_weight, dx_dblT, dconv_m)   # d conv += W_x^T d x_dbl, in place   (:277)
-        elif dconv_m.data_ptr() == dconv1d_out.data_ptr():
-            dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
-        else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
-            dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dblT)
-        dconv1d_out = dconv_m.view(dim, batch, L).permute(1, 0, 2)
+        dx_proj_weight, ddelta_proj_weight, dconv1d_out = _project_backward(
+            ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_weight, delta_proj_weight)
     dx, dconv1d_weight, dconv1d_bias = causal_conv1d_hip.causal_conv1d_bwd(x, conv1d_weight, conv1d_bias,
                                                                            dconv1d_out, dx, True)
     dconv1d_bias = dconv1d_bias if conv1d_bias is not None else None
