@@ -15,6 +15,9 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   "roofline_bwd", "roofline_d6", "roofline_bwd_d6", "roofline_conv1d", "roofline_conv1d_bwd":
                   the same for the scan backward (bytes s*B*L*(8D+2N) + 4*B*L*2N), for both at the 6-channel census
                   shape of MMConv's Mamba blocks (B=8, D=6, L=65536), and for causal conv1d (2 / 3 * s*B*D*L);
+  "roofline_noz", "roofline_bwd_noz": the scan at the headline shape with z = NULL -- what the three large blocks call since
+                  the gate moved into csrc/tri_fused.hip (bytes s*B*L*(3D+2N) / s*B*L*(5D+2N) + 4*B*L*2N);
+                  "roofline_tri_*": that file's four streaming kernels (4 / 5 / 9 / 5 [B, D, L] streams);
   "roofline_gemm_nt": the token-contraction weight-gradient product (csrc/gemm_nt_splitk.hip) at out_proj's shape of the
                   128-channel Mamba blocks (128 x 64 over B*L = 524,288 tokens), bytes s*(M+N)*B*L, same timing method;
   "roofline_conv": the MFMA-bound kernel of the path (csrc/conv3x3_mfma.hip at CBAM's shape [8,64,256,256] 64->64 and
@@ -160,6 +163,37 @@ def scan_rooflines(dev, iters=20):
             _traffic("scan_bwd_traffic.json") if tag == "" else None,
             issue_floor_ms=_scan_issue_floor_ms(b, d, l, n, backward=True))
         if tag == "":
+            # since f2 (tri_inner.py) the three large blocks call the scan WITHOUT z: u, delta in, y out (3 D streams);
+            # backward u, delta, dout in, du, ddelta out (5) + the fp32 dB / dC rows
+            y_nz, x_nz = ss.fwd(u, delta, A, B, C, D, None, bias, True)[:2]
+            ms_fn = _timed(dev, lambda: ss.fwd(u, delta, A, B, C, D, None, bias, True), iters)
+            ms_bn = _timed(dev, lambda: ss.bwd(u, delta, A, B, C, D, None, bias, dout, x_nz, None, None, True, False), iters)
+            del y_nz
+            leg("roofline_noz", "mmu_selective_scan_fwd with z = NULL (scan_fwd_stream16_kernel<HAS_Z = false>): the call "
+                "the tri-directional block makes since the gate moved into tri_gate (csrc/tri_fused.hip)", shape,
+                s_ * b * l * (3 * d + 2 * n), ms_fn, "the vector pipe (as `roofline`)",
+                issue_floor_ms=_scan_issue_floor_ms(b, d, l, n, backward=False))
+            leg("roofline_bwd_noz", "mmu_selective_scan_bwd with z = NULL (chunk_reduce8<bwd> + chunk_carry_par + "
+                "chunk_apply_bwd_w8<HAS_Z = false> + reduce_partials_w8)", shape,
+                s_ * b * l * (5 * d + 2 * n) + 4 * b * l * 2 * n, ms_bn, "VALU issue (as `roofline_bwd`)",
+                issue_floor_ms=_scan_issue_floor_ms(b, d, l, n, backward=True))
+            # f2's own four kernels at the largest block (64 slices): each a pure stream
+            from mm_unet_amd import tri_inner
+            xz = torch.randn(2 * d, b, l, device=dev).permute(1, 0, 2)
+            cws = [torch.randn(d, 4, device=dev) for _ in range(3)]
+            cbs = [torch.randn(d, device=dev) for _ in range(3)]
+            ys = tri_inner.tri_conv_fwd(xz[:, :d], 64, cws, cbs)
+            dxz = torch.empty_like(xz)
+            tshape = {"batch": b, "dim": d, "seqlen": l, "nslices": 64, "dtype": "f32"}
+            unit = s_ * b * d * l
+            for nm, k, fn in (("tri_conv_fwd", 4, lambda: tri_inner.tri_conv_fwd(xz[:, :d], 64, cws, cbs)),
+                              ("tri_gate_fwd", 5, lambda: tri_inner.tri_gate_fwd(xz[:, d:], 64, ys)),
+                              ("tri_gate_bwd", 9, lambda: tri_inner.tri_gate_bwd(xz[:, d:], 64, ys, dout, dxz[:, d:])),
+                              ("tri_conv_bwd", 5, lambda: tri_inner.tri_conv_bwd(xz[:, :d], 64, cws, cbs, ys, dxz[:, :d]))):
+                leg("roofline_" + nm, "mmu_" + nm + " (csrc/tri_fused.hip)", tshape, k * unit, _timed(dev, fn, iters),
+                    "HBM (streaming, %d [B, D, L] streams)" % k if nm != "tri_conv_bwd" else
+                    "instruction issue: three conv pre-activations, three silu', 12 + 12 FMAs per token at 2 workgroups per CU")
+            del xz, ys, dxz
             w = torch.randn(d, 4, device=dev)
             cb = torch.randn(d, device=dev)
             ms_cf = _timed(dev, lambda: cc.causal_conv1d_fwd(u, w, cb, True), iters)
@@ -365,9 +399,10 @@ def main():
                        "step_structure": ("graph[fwd + loss + bwd + adamw]" if world == 1 else
                                           "graph[fwd + loss + bwd] + eager[grad all-reduce x3 buckets + adamw]") if graph
                        else "eager[fwd + loss + bwd (+ overlapped all-reduce) + optimizer.step]",
-                       # the library GEMMs that remain (deep-K products of the small maps) take recorded selections in
-                       # look-up mode: were they accepted by this box's library versions?
-                       "tuned_gemm_lookups": __import__("mm_unet_amd.tuned_gemms", fromlist=["status"]).status(),
+                       # float32 step: every matrix product runs in this build's kernels (no rocBLAS / hipBLASLt launch;
+                       # the one library kernel left is MIOpen's 7 x 7 stem convolution); bf16 autocast: library GEMMs
+                       # with their default selections
+                       "library_gemms": "none" if args.dtype == "f32" else "rocBLAS / hipBLASLt defaults",
                        "final_loss": round(float(loss), 5)},
         }
         if not args.no_roofline:

@@ -24,6 +24,7 @@
 // the two kinds of wave still contend for VALU issue and the LDS port.
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -63,10 +64,14 @@ __global__ __launch_bounds__(256) void gemm_tokens_prep_kernel(const float *__re
     const int m = mt * 64 + row, k = ch * CK + half * 8 + k8;
     const float v = (m < M && k < K) ? (trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k]) : 0.f;
     const __bf16 h = (__bf16)v;
-    const __bf16 l = (__bf16)(v - (float)h);
+    const float r1 = v - (float)h;
+    const __bf16 l = (__bf16)r1;
     const long base = ((long)(mt * nch + ch) * 2) * (2 * 64 * 8) + ((long)half * 64 + row) * 8 + k8;
     out[base] = __builtin_bit_cast(unsigned short, h);
     out[base + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+    // third part (bits 17-24 of the mantissa), behind the whole two-part image: read by the 32-token kernel only
+    out[2 * n + (long)(mt * nch + ch) * (2 * 64 * 8) + ((long)half * 64 + row) * 8 + k8] =
+        __builtin_bit_cast(unsigned short, (__bf16)(r1 - (float)l));
 }
 
 // The same images for MANY weights in one launch (mmu_gemm_tokens_prepare_batch): blockIdx.y picks a row of the device
@@ -88,10 +93,13 @@ __global__ __launch_bounds__(256) void gemm_tokens_prep_batch_kernel(const long 
         const int m = mt * 64 + rw, k = ch * CK + half * 8 + k8;
         const float v = (m < M && k < K) ? (trans ? w[(long)k * ldw + m] : w[(long)m * ldw + k]) : 0.f;
         const __bf16 h = (__bf16)v;
-        const __bf16 l = (__bf16)(v - (float)h);
+        const float r1 = v - (float)h;
+        const __bf16 l = (__bf16)r1;
         const long base = ((long)(mt * nch + ch) * 2) * (2 * 64 * 8) + ((long)half * 64 + rw) * 8 + k8;
         out[base] = __builtin_bit_cast(unsigned short, h);
         out[base + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, l);
+        out[2 * n + (long)(mt * nch + ch) * (2 * 64 * 8) + ((long)half * 64 + rw) * 8 + k8] =
+            __builtin_bit_cast(unsigned short, (__bf16)(r1 - (float)l));
     }
 }
 
@@ -267,11 +275,184 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
     }
 }
 
+// ---- few tokens, deep inner dimension -------------------------------------------------------------------------
+// The DSC products and projections of the maps <= 64 x 64 (8 x (512 x 1536) . (1536 x 256), 8 x (256 x 768) . (768 x
+// 1,024), 8 x (128 x 384) . (384 x 4,096), the 64 <-> 128 / 256 projections at 4,096 tokens, ...) have 64-128 tiles of
+// 64 rows x 512 tokens: the kernel above leaves most CUs idle on them (and they were library GEMMs, ~75 launches of
+// 24-30 us per step + a zero-fill each).  Here a workgroup takes 64 rows x 32 TOKENS and its four waves split the
+// inner dimension (chunk c to wave c % 4): 512-2,048 workgroups.  No LDS staging at all -- a lane's B fragment of
+// v_mfma_f32_32x32x16_bf16 is 8 consecutive k for ONE token, i.e. 8 dword loads at the row stride, 32 lanes on 32
+// consecutive tokens (one 128-byte line per row); its A fragment is 16 bytes of the prepared weight image.  Loads run
+// one chunk ahead in registers.  The four partial tiles meet in LDS and are added in wave order (deterministic).
+// Work items are numbered so that the row tiles of one token block run on the same XCD (workgroup ids go round-robin over
+// the 8 XCDs): X is fetched into one L2 instead of n_mt of them.
+// NB = 32-token blocks per wave (tile = 64 rows x 32 NB tokens): the A fragments (three 16-byte loads per row tile and
+// chunk -- three quarters of the kernel's L1 traffic at NB = 1) serve NB token blocks.
+template <int NB>
+__global__ __launch_bounds__(256) void gemm_tokens_small_kernel(GemmArgs p, int per_xcd) {
+    __shared__ float red[4 * 32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if ((int)blockIdx.x >> 3 >= per_xcd || item >= p.total_tiles) return;
+    int t = item;
+    const int mt = t % p.n_mt;
+    t /= p.n_mt;
+    const int tt = t % p.tiles_t;
+    const int b = t / p.tiles_t;
+    const int nch = p.K / CK;
+    const int half = lane >> 5;
+    const int tok0 = tt * (32 * NB) + (lane & 31);
+    // X through a buffer resource: the row offset of a load is SCALAR ((chunk * 16 + j) rows), the lane's part (its k half
+    // and its token) one VGPR that never changes -- as plain pointers every load cost seven vector instructions of 64-bit
+    // address arithmetic, two of them quarter-rate multiplies (more issue time than the chunk's twelve MFMAs)
+    const rsrc_t xrs = make_rsrc(p.x + (long)b * p.x_bs);
+    unsigned xoff[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+        xoff[n] = ((unsigned)(half * 8) * (unsigned)p.x_rs + (unsigned)(tok0 + 32 * n < p.T ? tok0 + 32 * n : 0)) * 4u;
+    const v4u *wimg = reinterpret_cast<const v4u *>(p.wp) + (long)mt * nch * 256 + half * 64 + (lane & 31);
+    const v4u *wimg3 = reinterpret_cast<const v4u *>(p.wp) + (long)(p.M / 64) * nch * 256 + (long)mt * nch * 128 + half * 64 + (lane & 31);
+    f32x16 acc[NB][2];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][m][e] = 0.f;
+    auto loadx = [&](int ch, float(&v)[NB][8]) {
+        if (ch * CK + CK <= p.Kv) {   // every row of the chunk inside the matrix
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned soff = (unsigned)(ch * CK + j) * (unsigned)p.x_rs * 4u;
+#pragma unroll
+                for (int n = 0; n < NB; ++n) v[n][j] = buf_load1(xrs, xoff[n], soff);
+            }
+        } else {                      // the last chunk of an inner size that is no multiple of 16: rows past the matrix
+            const int r0 = ch * CK + half * 8;   // read a valid row again (their weights are zero)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + j < p.Kv ? r0 + j : p.Kv - 1;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    v[n][j] = buf_load1(xrs, xoff[n] - (unsigned)(half * 8) * (unsigned)p.x_rs * 4u + (unsigned)r * (unsigned)p.x_rs * 4u, 0);
+            }
+        }
+    };
+    auto loadw = [&](int ch, v4u(&w)[6]) {
+        const v4u *q = wimg + (long)ch * 256, *q3 = wimg3 + (long)ch * 128;
+        w[0] = q[0]; w[1] = q[32]; w[2] = q[128]; w[3] = q[160];   // hi rows 0-31, 32-63; mid rows 0-31, 32-63
+        w[4] = q3[0]; w[5] = q3[32];                                // lo
+    };
+    // FLOAT32-GRADE products: both operands as three bf16 parts (8 + 8 + 8 mantissa bits), the six products down to
+    // 2^-16 of the leading one (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi).  These are the deep products of the small
+    // maps: as library GEMMs they were exact float32, and with the two-part split of the 512-token kernel the
+    // d_state-64 model's logits moved from 5.2e-4 to 1.2e-3 off the oracle (tools/dbg/config5_fwd_err.py).
+    // Two chunks of this wave in flight (register sets 0 / 1, the loop unrolled by two so that they are static).
+    float xv[2][NB][8];
+    v4u wr[2][6];
+    auto compute = [&](const float(&xs)[NB][8], const v4u(&ws)[6]) {
+        bf16x8 bh[NB], bm[NB], bl[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = xs[n][2 * q], c = xs[n][2 * q + 1];
+                hw[q] = pack_bf16(a, c);
+                const float ra = a - __builtin_bit_cast(float, hw[q] << 16), rc = c - __builtin_bit_cast(float, hw[q] & 0xffff0000u);
+                mw[q] = pack_bf16(ra, rc);
+                lw[q] = pack_bf16(ra - __builtin_bit_cast(float, mw[q] << 16), rc - __builtin_bit_cast(float, mw[q] & 0xffff0000u));
+            }
+            const v4u hq = {hw[0], hw[1], hw[2], hw[3]}, mq = {mw[0], mw[1], mw[2], mw[3]}, lq = {lw[0], lw[1], lw[2], lw[3]};
+            bh[n] = __builtin_bit_cast(bf16x8, hq);
+            bm[n] = __builtin_bit_cast(bf16x8, mq);
+            bl[n] = __builtin_bit_cast(bf16x8, lq);
+        }
+        // the six terms, smallest first; within a term the 2 NB accumulators are independent chains
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, ws[m]), am = __builtin_bit_cast(bf16x8, ws[2 + m]),
+                                 al = __builtin_bit_cast(bf16x8, ws[4 + m]);
+                    const bf16x8 a = term == 0 ? al : (term == 2 || term == 3) ? am : ah;
+                    const bf16x8 bb = (term == 0 || term == 3 || term == 5) ? bh[n] : (term == 1) ? bl[n] : bm[n];
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[n][m], 0, 0, 0);
+                }
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        if (wv + 4 * s < nch) {
+            loadx(wv + 4 * s, xv[s]);
+            loadw(wv + 4 * s, wr[s]);
+        }
+    for (int ch = wv; ch < nch; ch += 8) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = ch + 4 * s;
+            if (c < nch) {
+                compute(xv[s], wr[s]);
+                if (c + 8 < nch) {
+                    loadx(c + 8, xv[s]);
+                    loadw(c + 8, wr[s]);
+                }
+            }
+        }
+    }
+    // the four waves' partial tiles, one token block at a time through the 32 KB of LDS, added in wave order
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        if (n) __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wv * 32 + m * 16 + e) * 64 + lane] = acc[n][m][e];
+        __syncthreads();
+        const int tok = tok0 + 32 * n;
+        if (tok < p.T) {
+            float *ob = p.out + (long)b * p.o_bs + tok;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int v = 8 * wv + i;
+                const float s = ((red[v * 64 + lane] + red[(32 + v) * 64 + lane]) + red[(64 + v) * 64 + lane]) + red[(96 + v) * 64 + lane];
+                const int e = v & 15;
+                const int row = mt * 64 + (v >> 4) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (row < p.Mv) {
+                    float *o = ob + (long)row * p.o_rs;
+                    *o = p.acc ? *o + s : s;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// 64-row x 512-token tiles below which the 32-token kernel takes the product (MMUNET_GEMM_TOKENS_SMALL_BELOW; 0: never)
+static long gemm_tokens_small_below() {
+    static long v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMUNET_GEMM_TOKENS_SMALL_BELOW");
+        v = e ? atol(e) : 520;   // swept on the training step: 0 / 192 / 320 / 520 / 1100 / 2100 = 34.36 / 32.30 / 32.18 / 32.05 / 32.12 / 32.18 ms
+    }
+    return v;
+}
+
+static int gemm_tokens_small_nb() {   // MMUNET_GEMM_TOKENS_SMALL_NB=1: always one token block per wave (A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMUNET_GEMM_TOKENS_SMALL_NB");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 
 extern "C" size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner) {
     if (rows <= 0 || inner <= 0) return 0;
-    return (size_t)((rows + 63) & ~63) * ((inner + CK - 1) & ~(CK - 1)) * 2 * sizeof(unsigned short);
+    return (size_t)((rows + 63) & ~63) * ((inner + CK - 1) & ~(CK - 1)) * 3 * sizeof(unsigned short);   // hi | lo images, then the third parts
 }
 
 extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *stream) {
@@ -291,9 +472,6 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
                                                                              p->rows, p->inner, p->transposed_weight ? 1 : 0);
         MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma(prep)");
     }
-    static unsigned long long attr_mask = 0;  // per device
-    if (hipError_t e = mmu_set_lds_once(gemm_tokens_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
-        return mmu_fail("gemm_tokens_mfma: LDS attribute: %s", hipGetErrorString(e));
     GemmArgs a;
     a.x = p->x; a.wp = (const unsigned short *)p->workspace; a.out = p->out;
     a.x_rs = p->x_rs; a.x_bs = p->x_bs; a.o_rs = p->out_rs; a.o_bs = p->out_bs;
@@ -301,6 +479,25 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     a.Mv = p->rows; a.Kv = p->inner; a.acc = p->accumulate ? 1 : 0;
     a.tiles_t = (p->tokens + TT - 1) / TT;
     a.n_mt = Mp / 64;
+    if ((long)a.tiles_t * a.n_mt * p->batch < gemm_tokens_small_below()) {   // too few 512-token tiles to fill the chip
+        // two token blocks per wave when that still leaves two workgroups per CU
+        const long items64 = (long)((p->tokens + 63) / 64) * a.n_mt * p->batch;
+        const int nb = items64 >= 2L * mmu_cu_count() && gemm_tokens_small_nb() != 1 ? 2 : 1;
+        a.tiles_t = (p->tokens + 32 * nb - 1) / (32 * nb);
+        const long items = (long)a.tiles_t * a.n_mt * p->batch;
+        MMU_CHECK(items < (1L << 28), "gemm_tokens_mfma: too many tiles");
+        a.total_tiles = (int)items;
+        const int per_xcd = (int)((items + 7) / 8);
+        if (nb == 2)
+            gemm_tokens_small_kernel<2><<<per_xcd * 8, 256, 0, st>>>(a, per_xcd);
+        else
+            gemm_tokens_small_kernel<1><<<per_xcd * 8, 256, 0, st>>>(a, per_xcd);
+        MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma(small)");
+        return 0;
+    }
+    static unsigned long long attr_mask = 0;  // per device
+    if (hipError_t e = mmu_set_lds_once(gemm_tokens_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
+        return mmu_fail("gemm_tokens_mfma: LDS attribute: %s", hipGetErrorString(e));
     const long total = (long)a.tiles_t * a.n_mt * p->batch;
     MMU_CHECK(total < (1L << 30), "gemm_tokens_mfma: too many tiles");
     a.total_tiles = (int)total;

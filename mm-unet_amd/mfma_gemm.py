@@ -9,12 +9,13 @@ from . import _lib, deferred
 
 ENABLED = True   # False: callers use their ATen GEMMs (tests compare the two)
 ANY_SHAPE = os.environ.get("MMUNET_GEMM_TOKENS_ANY_SHAPE", "1") != "0"   # rows / inner that are no multiples of 64 / 16
-MIN_TILES = int(os.environ.get("MMUNET_GEMM_TOKENS_MIN_TILES", "192"))   # measured break-even against hipBLASLt on the DSC shapes (csrc/gemm_tokens_mfma.hip header)
+# products with fewer 64-row x 512-token tiles than this stay with the library (0: none do -- below 192 tiles the C entry
+# point switches to its 32-token kernel with the inner dimension split over the waves, csrc/gemm_tokens_mfma.hip)
+MIN_TILES = int(os.environ.get("MMUNET_GEMM_TOKENS_MIN_TILES", "0"))
 
 
 def supported(rows, inner, tokens, *tensors):
-    """Shapes the matrix-core kernel covers AND wins on: enough output tiles of 64 rows x 512 tokens to fill the
-    chip (deep-K problems with few tokens would need split-K and stay with hipBLASLt)."""
+    """Shapes the matrix-core kernels cover: any rows / inner, tokens a multiple of 4, float32, 16-byte aligned."""
     tiles = ((rows + 63) // 64) * ((tokens + 511) // 512)      # any rows / inner since ABI 6 (zero-padded weight images)
     return (ENABLED and (ANY_SHAPE or (rows % 64 == 0 and inner % 16 == 0)) and tokens % 4 == 0 and tiles >= MIN_TILES
             and not torch.is_autocast_enabled()

@@ -15,7 +15,7 @@ import torch
 from . import _lib, deferred, mfma_gemm
 
 _SLAB = 2048
-_NT_MIN = int(os.environ.get("MMUNET_GEMM_NT_MIN_TOKENS", str(4 * _SLAB)))   # fewer tokens: one library GEMM
+_NT_MIN = int(os.environ.get("MMUNET_GEMM_NT_MIN_TOKENS", "256"))   # fewer tokens: one library GEMM
 
 
 def nt_splitk(X, Y):
@@ -317,8 +317,7 @@ class _Conv1x1Stride2Fn(torch.autograd.Function):
             dxs = torch.empty((B, I, T), device=G.device, dtype=torch.float32)
             # (the matrix-core kernel also below its usual break-even of 192 tiles: the library's strided-batch kernel
             #  for 64 x 128 against 8 x 4,096 tokens takes 121 us, 64 workgroups of this one ~10)
-            tiles = (I // 64) * ((B * T + 511) // 512)
-            if (mfma_gemm.ENABLED and I % 64 == 0 and O % 16 == 0 and T % 4 == 0 and tiles >= 48 and W2.is_contiguous()
+            if (mfma_gemm.ENABLED and T % 4 == 0 and W2.is_contiguous()
                     and not torch.is_autocast_enabled() and G3.data_ptr() % 16 == 0 and W2.data_ptr() % 16 == 0):
                 mfma_gemm.gemm_tokens(W2, G3, dxs, I, O, T, B, T, O * T, T, I * T, transposed_weight=True,
                                       prepared=ctx.prep_t)

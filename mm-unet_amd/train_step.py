@@ -16,7 +16,7 @@ buffers; shapes are fixed at capture time.
 """
 import torch
 
-from . import adamw_multi, deferred, tuned_gemms
+from . import adamw_multi, deferred
 from .dp import GradAllReducer
 
 
@@ -65,7 +65,6 @@ class TrainStep:
     def __init__(self, model, loss_fn, optimizer, group=None, amp_dtype=None, bucket_bytes=16 << 20, overlap=True,
                  use_graph=False, multi_tensor_adamw=True, deferred_reductions=True):
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
-        tuned_gemms.enable()     # recorded library-GEMM selections for the shapes that stay in rocBLAS / hipBLASLt
         self.amp_dtype = amp_dtype
         self.use_graph = use_graph
         self.multi_tensor_adamw = multi_tensor_adamw
@@ -190,7 +189,6 @@ class InferStep:
     host-bound (150 ms for bs 8; the GPU needs a fraction of that).  Shapes are fixed at capture time."""
 
     def __init__(self, model, amp_dtype=None, use_graph=True):
-        tuned_gemms.enable()
         self.model, self.amp_dtype, self.use_graph = model.eval(), amp_dtype, use_graph
         self._graph = None
         self._warm = False
