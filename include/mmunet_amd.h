@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 7
+#define MMU_ABI_VERSION 8
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -385,6 +385,27 @@ size_t mmu_tri_conv_bwd_workspace_floats(int batch, int dim, int seqlen, int nsl
 int mmu_tri_conv_bwd(const mmu_tri_conv_params *p, void *stream);
 int mmu_tri_gate_fwd(const mmu_tri_gate_params *p, void *stream);
 int mmu_tri_gate_bwd(const mmu_tri_gate_params *p, void *stream);
+
+/* ---- MM_Net's stem: nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False) (csrc/stem7_mfma.hip) ---- */
+/* src/UM_Net/MMUNet.py:492.  Forward and weight gradient on the bf16 matrix cores with float32-grade products (both
+ * operands split into three bf16 parts, six MFMAs per product, float32 accumulation).  input [batch][3][height][width],
+ * out / dout [batch][64][height/2][width/2], weight / dweight [64][3][7][7], all float32, contiguous; height even, width
+ * a multiple of 16.  workspace: mmu_stem7_workspace_bytes(batch, height, width, backward) bytes, 16-byte aligned (forward:
+ * the weight's bf16 images, written by the call; weight gradient: per-workgroup partial sums, added in a fixed order).
+ * The image is the network's input: there is no input gradient. */
+typedef struct {
+    int32_t batch, height, width;
+    const float *input;
+    const float *weight;      /* fwd */
+    float *out;               /* fwd */
+    const float *dout;        /* wgrad */
+    float *dweight;           /* wgrad */
+    void *workspace;
+} mmu_stem7_params;
+
+size_t mmu_stem7_workspace_bytes(int batch, int height, int width, int backward);
+int mmu_stem7_fwd(const mmu_stem7_params *p, void *stream);
+int mmu_stem7_wgrad(const mmu_stem7_params *p, void *stream);
 
 /* ---- GroupNorm [-> BatchNorm2d] [-> ReLU | tanh] as one normalisation (a9/a11 blocks) ------------------ */
 /* nn.GroupNorm(groups, C) optionally followed by nn.BatchNorm2d(C) (training or eval statistics) and an

@@ -106,6 +106,11 @@ class TriGateParams(ctypes.Structure):
                 + [("dz", _vp)] + [(n, _i64) for n in ("dz_bs", "dz_ds")] + [(n, _vp) for n in ("dy_f", "dy_b", "dy_s")])
 
 
+class Stem7Params(ctypes.Structure):
+    _fields_ = ([(n, _i32) for n in ("batch", "height", "width")]
+                + [(n, _vp) for n in ("input", "weight", "out", "dout", "dweight", "workspace")])
+
+
 class NormParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "channels", "groups", "hw", "has_bn", "training", "act", "has_gn",
                                        "dinput_channel_major")]
@@ -238,7 +243,7 @@ EXPORTS = (
     "mmu_bilinear_resize_bwd", "mmu_conv3x3_small_fwd_splits", "mmu_conv3x3_small_fwd", "mmu_conv3x3_small_bwd",
     "mmu_conv3x3_small_wgrad_workspace_floats",
     "mmu_tri_split", "mmu_tri_combine", "mmu_tri_conv_fwd", "mmu_tri_conv_bwd", "mmu_tri_conv_bwd_workspace_floats",
-    "mmu_tri_gate_fwd", "mmu_tri_gate_bwd", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
+    "mmu_tri_gate_fwd", "mmu_tri_gate_bwd", "mmu_stem7_workspace_bytes", "mmu_stem7_fwd", "mmu_stem7_wgrad", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma", "mmu_dt_proj_fwd", "mmu_dt_proj_bwd", "mmu_x_proj_fwd", "mmu_x_proj_bwd",
     "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_adamw_multi", "mmu_coords_bwd_workspace_floats", "mmu_channel_sum", "mmu_scatter_stride2", "mmu_dice_bce_fwd", "mmu_dice_bce_bwd", "mmu_dice_bce_workspace_floats", "mmu_gated_mul_bwd_workspace_floats", "mmu_cbam_gate_fwd", "mmu_cbam_gate_bwd", "mmu_maxpool3s2_fwd", "mmu_maxpool3s2_bwd_codes", "mmu_deferred_begin", "mmu_deferred_pause", "mmu_deferred_end", "mmu_deferred_jobs", "mmu_deferred_launch", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
@@ -251,7 +256,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 7   # = MMU_ABI_VERSION of include/mmunet_amd.h
+ABI_VERSION = 8   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():
@@ -287,6 +292,7 @@ def lib():
                      ("mmu_tri_split", TriParams), ("mmu_tri_combine", TriParams),
                      ("mmu_tri_conv_fwd", TriConvParams), ("mmu_tri_conv_bwd", TriConvParams),
                      ("mmu_tri_gate_fwd", TriGateParams), ("mmu_tri_gate_bwd", TriGateParams),
+                     ("mmu_stem7_fwd", Stem7Params), ("mmu_stem7_wgrad", Stem7Params),
                      ("mmu_norm_fused_fwd", NormParams), ("mmu_norm_fused_bwd", NormParams),
                      ("mmu_mamba_pre_small", MambaPreParams), ("mmu_mamba_post_small", MambaPostParams),
                      ("mmu_conv3x3_mfma", Conv3x3MfmaParams), ("mmu_conv3x3_wgrad_mfma", Conv3x3MfmaParams), ("mmu_gemm_tokens_mfma", GemmTokensParams),
@@ -306,6 +312,8 @@ def lib():
         fn.argtypes = [ctypes.POINTER(st), _vp]
     L.mmu_causal_conv1d_bwd_workspace_floats.restype = ctypes.c_size_t
     L.mmu_causal_conv1d_bwd_workspace_floats.argtypes = [ctypes.c_int] * 3
+    L.mmu_stem7_workspace_bytes.restype = ctypes.c_size_t
+    L.mmu_stem7_workspace_bytes.argtypes = [ctypes.c_int] * 4
     L.mmu_tri_conv_bwd_workspace_floats.restype = ctypes.c_size_t
     L.mmu_tri_conv_bwd_workspace_floats.argtypes = [ctypes.c_int] * 4
     L.mmu_conv3x3_small_fwd_splits.restype = ctypes.c_int

@@ -11,13 +11,13 @@ import contextlib
 
 from . import loss as loss_mod
 from . import (conv3x3_mfma, conv3x3_small, conv_s2, mamba_simple, mamba_small_fused, maxpool, mfma_gemm, morph_coords,
-               morph_mix, morph_sample, norm_fused, pointwise, resize, selective_scan_interface, tall_gemm, tri_inner, tri_order)
+               morph_mix, morph_sample, norm_fused, pointwise, resize, selective_scan_interface, stem7, tall_gemm, tri_inner, tri_order)
 
 _FLAGS = ((conv3x3_mfma, "ENABLED"), (conv3x3_small, "ENABLED"), (conv_s2, "ENABLED"), (mamba_simple, "BCL_ENABLED"),
           (mamba_small_fused, "ENABLED"), (maxpool, "ENABLED"), (mfma_gemm, "ENABLED"), (mfma_gemm, "NT_ENABLED"),
           (morph_coords, "ENABLED"), (morph_mix, "ENABLED"), (morph_sample, "ENABLED"), (norm_fused, "ENABLED"), (pointwise, "ENABLED"),
           (pointwise, "GATED_MUL"), (pointwise, "STATS"), (pointwise, "CBAM_GATE"), (resize, "ENABLED"), (tall_gemm, "STRIDE2_ENABLED"),
-          (tri_order, "ENABLED"), (tri_inner, "ENABLED"), (selective_scan_interface, "PRE_SMALL_FUSED"),
+          (tri_order, "ENABLED"), (tri_inner, "ENABLED"), (stem7, "ENABLED"), (selective_scan_interface, "PRE_SMALL_FUSED"),
           (selective_scan_interface, "POST_SMALL_FUSED"), (selective_scan_interface, "OWN_PROJ"), (loss_mod, "FUSED"))
 
 

@@ -24,7 +24,7 @@ from . import conv3x3_mfma, conv3x3_small, conv_s2, mamba_small_fused, mfma_gemm
 from . import morph_sample as morph_sample_mod
 from .morph_sample import morph_sample
 from .resize import bilinear_resize
-from . import maxpool as maxpool_op, pointwise
+from . import maxpool as maxpool_op, pointwise, stem7
 from .tall_gemm import conv1x1_stride2, conv1x1_stride2_supported, dsc_gemm
 from .selective_scan_interface import mamba_inner_fn_no_out_proj
 
@@ -266,6 +266,8 @@ def run_fused(seq, x, residual=None, in_slot=None, first_slot=None):
             x = conv1x1_stride2(x, m.weight, in_slot if i == 0 else None)
         elif conv_s2.module_supported(m, x):      # 3 x 3 / stride 2 opening of a down-sampling residual block
             x = conv_s2.module_call(m, x)
+        elif stem7.supported(m, x):               # the 7 x 7 / stride 2 stem on the network's input image
+            x = stem7.stem_conv(m, x)
         else:
             x = m(x)
         i += 1

@@ -52,6 +52,7 @@ def test_param_structs_match_header_field_order():
                         ("mmu_resize_params", _lib.ResizeParams), ("mmu_conv3x3s_params", _lib.Conv3x3sParams),
                         ("mmu_tri_params", _lib.TriParams), ("mmu_norm_params", _lib.NormParams),
                         ("mmu_tri_conv_params", _lib.TriConvParams), ("mmu_tri_gate_params", _lib.TriGateParams),
+                        ("mmu_stem7_params", _lib.Stem7Params),
                         ("mmu_mamba_pre_params", _lib.MambaPreParams),
                         ("mmu_mamba_post_params", _lib.MambaPostParams),
                         ("mmu_conv3x3_mfma_params", _lib.Conv3x3MfmaParams),

@@ -202,3 +202,25 @@ def test_fused_tri_block_inside_a_deferred_scope():
         grads[use_scope] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
     for n in grads[False]:
         assert torch.equal(grads[False][n], grads[True][n]), n
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 46, 112), (3, 16, 16), (1, 130, 208)])
+def test_stem7_mfma_vs_float64(B, H, W):
+    """csrc/stem7_mfma.hip -- Conv2d(3, 64, 7, stride 2, padding 3, no bias): forward and weight gradient against
+    float64 F.conv2d (three-part bf16 split = float32-grade: tighter than any float32 convolution needs)."""
+    from mm_unet_amd import stem7
+    gen = torch.Generator().manual_seed(H * W + B)
+    conv = torch.nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False).to(DEV)
+    x = torch.randn(B, 3, H, W, generator=gen).to(DEV)
+    assert stem7.supported(conv, x)
+    out = stem7.stem_conv(conv, x)
+    wd = conv.weight.detach().double().requires_grad_()
+    ref = F.conv2d(x.double(), wd, None, stride=2, padding=3)
+    assert out.shape == ref.shape
+    err = float((out.double() - ref).abs().max())
+    assert err < 5e-6 * float(ref.abs().max()), err
+    dout = torch.randn(ref.shape, generator=gen).to(DEV)
+    (ref * dout.double()).sum().backward()
+    out.backward(dout)
+    e = float((conv.weight.grad.double() - wd.grad).abs().max())
+    assert e < 5e-6 * float(wd.grad.abs().max()), e

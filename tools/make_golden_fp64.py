@@ -50,7 +50,16 @@ def run(dtype, xb, tb):
 
 def main():
     oracle.build()
-    g = np.load(os.path.join(ROOT, "tests", "golden", "mmnet_128_train.npz"), allow_pickle=False)
+    # default: the 4 x 3 x 128 x 128 fixture; "mmnet_64": the train-mode half of the 2 x 3 x 64 x 64 fixture (round 4:
+    # its distributional check against the float32 reference alone moved with every change of a rounding -- the stem on
+    # the build's own kernel took its 90th percentile from 31 % to 39.5 % -- so it, too, is judged against the truth)
+    which = sys.argv[1] if len(sys.argv) > 1 else "mmnet_128_train"
+    g0 = np.load(os.path.join(ROOT, "tests", "golden", which + ".npz"), allow_pickle=False)
+    if which == "mmnet_64":
+        g = {"xb": g0["xb"], "tb": g0["tb"], "gabs_names": g0["gabs_names"], "gabs": g0["train_gabs"],
+             "loss": g0["train_loss"], "logits": g0["train_logits"]}
+    else:
+        g = g0
     xb, tb = torch.from_numpy(g["xb"]), torch.from_numpy(g["tb"])
     names = [str(s) for s in g["gabs_names"]]
     t0 = time.time()
@@ -72,9 +81,17 @@ def main():
           f"{float((torch.from_numpy(g['logits']).double() - l64).abs().max()):.2e}")
     print(f"  |grad| sums vs float64: reference float32 median {np.median(dr):.2e} p90 {np.quantile(dr, 0.9):.2e} max {dr.max():.2e}; "
           f"oracle float32 median {np.median(do):.2e} p90 {np.quantile(do, 0.9):.2e} max {do.max():.2e}")
-    out = os.path.join(ROOT, "tests", "golden", "mmnet_128_train_fp64.npz")
+    # the float32 oracle again on an input perturbed by 1.5e-5 relative = 2^-16, the size of the error of a two-part bf16
+    # product (conv3x3_mfma / conv_s2_mfma / the 512-token GEMM): how far a float32 implementation moves under the
+    # perturbation those kernels ARE -- the yardstick for the build's distance from the truth in the chaotic 64 x 64 case
+    gen = torch.Generator().manual_seed(11)
+    _, _, g32n = run(torch.float32, xb * (1.0 + 1.5e-5 * torch.randn(xb.shape, generator=gen)), tb)
+    a32n = np.array([float(g32n[k].double().abs().sum()) for k in names])
+    dn = np.abs(a32n - a64) / np.maximum(a64, 1e-30)
+    print(f"  oracle float32 with 2^-16 input noise vs float64: median {np.median(dn):.2e} p90 {np.quantile(dn, 0.9):.2e}")
+    out = os.path.join(ROOT, "tests", "golden", ("mmnet_64_train" if which == "mmnet_64" else which) + "_fp64.npz")
     np.savez_compressed(out, gabs_names=np.array(names), gabs64=a64, logits64=l64.numpy(), loss64=np.array(loss64),
-                        gabs_oracle32=a32)
+                        gabs_oracle32=a32, gabs_oracle32_noise16=a32n)
     print("wrote", out, os.path.getsize(out), "bytes")
 
 
