@@ -18,7 +18,7 @@
 // positions in the slice order; the transpose between the two happens in LDS (odd row pitch: conflict-free both ways).
 // The conv taps reach 3 tokens back in each order: the natural neighbours are three halo columns on either side of a
 // run, the slice-order neighbours are slices s-1..s-3 at the same i, wrapping to the top slices at i-1.
-// float32, conv width 4, 4 <= nslices <= 64.
+// float32 or bfloat16 activations (float32 arithmetic, weights and weight gradients), conv width 4, 4 <= nslices <= 64.
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
 
@@ -30,28 +30,28 @@ constexpr int TGP = TI + 1;  // gate kernels: no halo
 
 struct TcArgs {
     int batch, dim, L, ns, Ls, ntiles, nblk;
-    const float *x;
+    const void *x;            // activations: io_t (float or bf16_t); weights, biases, partial sums: float
     long x_bs, x_ds;
     const float *w[3], *b[3];
-    float *out[3];
-    const float *g[3];
-    float *dx;
+    void *out[3];
+    const void *g[3];
+    void *dx;
     long dx_bs, dx_ds;
     float *ws[3];   // per direction [batch][dim][nblk][5]
 };
 
 struct TgArgs {
     int batch, dim, L, ns, Ls;
-    const float *z;
+    const void *z;
     long z_bs, z_ds;
-    const float *y[3];
-    float *out;
+    const void *y[3];
+    void *out;
     long out_bs, out_ds;
-    const float *dout;
+    const void *dout;
     long dout_bs, dout_ds;
-    float *dz;
+    void *dz;
     long dz_bs, dz_ds;
-    float *dy[3];
+    void *dy[3];
 };
 
 __device__ __forceinline__ float silu_(float a) { return a * sigmoidf_(a); }
@@ -76,8 +76,8 @@ __device__ __forceinline__ void load_taps(const TcArgs &p, int d, Taps &t) {
 // neighbours in the natural order, also across a slice boundary); tokens outside [0, L) read as 0.
 // KS slices per wave are loaded before the first LDS store (all of them when nslices is a template constant): a
 // workgroup with 18-73 KB of LDS has 2-8 waves per SIMD, one exposed memory round trip per slice is what it cannot hide.
-template <int KS>
-__device__ __forceinline__ void stage_x(const float *__restrict__ xr, float *xt, int ns, int Ls, int L, int i0, int tx, int ry) {
+template <int KS, typename io_t>
+__device__ __forceinline__ void stage_x(const io_t *__restrict__ xr, float *xt, int ns, int Ls, int L, int i0, int tx, int ry) {
     for (int sb = ry; sb < ns; sb += 4 * KS) {
         float a[KS], h[KS];
 #pragma unroll
@@ -85,8 +85,8 @@ __device__ __forceinline__ void stage_x(const float *__restrict__ xr, float *xt,
             const int sl = sb + 4 * k;
             const int t0 = sl * Ls + i0 - 3;
             const int t = t0 + tx, th = t0 + 64 + tx;
-            a[k] = (sl < ns && t >= 0 && t < L) ? xr[t] : 0.f;
-            h[k] = (sl < ns && tx < 6 && th >= 0 && th < L) ? xr[th] : 0.f;
+            a[k] = (sl < ns && t >= 0 && t < L) ? to_f32(xr[t]) : 0.f;
+            h[k] = (sl < ns && tx < 6 && th >= 0 && th < L) ? to_f32(xr[th]) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
@@ -117,7 +117,7 @@ __device__ __forceinline__ float slice_pre(const float *xt, const float (&w)[4],
     return a;
 }
 
-template <int NS>
+template <int NS, typename io_t>
 __global__ __launch_bounds__(256) void tri_conv_fwd_kernel(TcArgs p) {
     extern __shared__ float lds[];
     const int ns = NS > 0 ? NS : p.ns;
@@ -126,15 +126,15 @@ __global__ __launch_bounds__(256) void tri_conv_fwd_kernel(TcArgs p) {
     const int d = row / p.batch, b = row - d * p.batch;
     const int i0 = blockIdx.x * TI;
     const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const float *xr = p.x + (long)b * p.x_bs + (long)d * p.x_ds;
+    const io_t *xr = (const io_t *)p.x + (long)b * p.x_bs + (long)d * p.x_ds;
     const long ob = (long)row * L;
     constexpr int KS = NS > 0 ? NS / 4 : 1;
     Taps tp;
     load_taps(p, d, tp);
-    stage_x<KS>(xr, lds, ns, Ls, L, i0, tx, ry);
+    stage_x<KS, io_t>(xr, lds, ns, Ls, L, i0, tx, ry);
     __syncthreads();
     const int ni = Ls - i0 < TI ? Ls - i0 : TI;
-    float *of = p.out[0] + ob, *obk = p.out[1] + ob, *os = p.out[2] + ob + (long)i0 * ns;
+    io_t *of = (io_t *)p.out[0] + ob, *obk = (io_t *)p.out[1] + ob, *os = (io_t *)p.out[2] + ob + (long)i0 * ns;
     if (tx < ni) {
 #pragma unroll 4
         for (int sl = ry; sl < ns; sl += 4) {
@@ -149,20 +149,20 @@ __global__ __launch_bounds__(256) void tri_conv_fwd_kernel(TcArgs p) {
                 ab = fmaf(tp.w[1][3 - m], v[3 + m], ab);    // x_flip[p'-3+(3-m)] = x[t+m]
             }
             const int t = sl * Ls + i0 + tx;
-            of[t] = silu_(af);
-            obk[L - 1 - t] = silu_(ab);
+            of[t] = from_f32<io_t>(silu_(af));
+            obk[L - 1 - t] = from_f32<io_t>(silu_(ab));
         }
     }
     for (int j = threadIdx.x; j < ni * ns; j += 256) {
         const int il = j / ns, s = j - il * ns;
-        os[j] = silu_(slice_pre(lds, tp.w[2], tp.b[2], ns, s, il, i0));
+        os[j] = from_f32<io_t>(silu_(slice_pre(lds, tp.w[2], tp.b[2], ns, s, il, i0)));
     }
 }
 
 // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of one row and keeps the 15 weight-gradient sums
 // (3 directions x (4 taps + bias)) in registers across them; the block sums are plain stores into the workspace and are
 // added in a fixed order afterwards (causal_conv1d.hip's scheme: bit-reproducible, nothing to zero).
-template <int NS>
+template <int NS, typename io_t>
 __global__ __launch_bounds__(256, NS > 0 ? 2 : 1) void tri_conv_bwd_kernel(TcArgs p) {
     extern __shared__ float lds[];
     __shared__ float red[4][15];
@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256, NS > 0 ? 2 : 1) void tri_conv_bwd_kernel(TcArg
     const int row = blockIdx.y;
     const int d = row / p.batch, b = row - d * p.batch;
     const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const float *xr = p.x + (long)b * p.x_bs + (long)d * p.x_ds;
-    float *dxr = p.dx + (long)b * p.dx_bs + (long)d * p.dx_ds;
+    const io_t *xr = (const io_t *)p.x + (long)b * p.x_bs + (long)d * p.x_ds;
+    io_t *dxr = (io_t *)p.dx + (long)b * p.dx_bs + (long)d * p.dx_ds;
     const long ob = (long)row * L;
-    const float *gf = p.g[0] + ob, *gb = p.g[1] + ob, *gs = p.g[2] + ob;
+    const io_t *gf = (const io_t *)p.g[0] + ob, *gb = (const io_t *)p.g[1] + ob, *gs = (const io_t *)p.g[2] + ob;
     float *xt = lds, *df = xt + ns * TP, *db = df + ns * TP, *dsl = db + ns * TP;
     Taps tp;
     load_taps(p, d, tp);
@@ -193,28 +193,28 @@ __global__ __launch_bounds__(256, NS > 0 ? 2 : 1) void tri_conv_bwd_kernel(TcArg
         for (int k = 0; k < KS; ++k) {
             const int sl = ry + 4 * k;
             const int tl = sl * Ls + i0 - 3 + tx;
-            xa[k] = (sl < ns && tl >= 0 && tl < L) ? xr[tl] : 0.f;
+            xa[k] = (sl < ns && tl >= 0 && tl < L) ? to_f32(xr[tl]) : 0.f;
             // natural order at positions i0 .. i0+TI+2, flipped order at the tokens i0-3 .. i0+TI-1: column c of df / db
             const int t = sl * Ls + i0 + tx, tb = t - 3;
-            gfa[k] = (sl < ns && t < L) ? gf[t] : 0.f;
-            gba[k] = (sl < ns && tb >= 0 && tb < L) ? gb[L - 1 - tb] : 0.f;
+            gfa[k] = (sl < ns && t < L) ? to_f32(gf[t]) : 0.f;
+            gba[k] = (sl < ns && tb >= 0 && tb < L) ? to_f32(gb[L - 1 - tb]) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {   // x columns 64..69 of every slice
             const int j = threadIdx.x + 256 * k, sl = j / 6;
             const int th = sl * Ls + i0 - 3 + 64 + (j - 6 * sl);
-            xh[k] = (j < 6 * ns && th >= 0 && th < L) ? xr[th] : 0.f;
+            xh[k] = (j < 6 * ns && th >= 0 && th < L) ? to_f32(xr[th]) : 0.f;
         }
         if (threadIdx.x < 3 * ns) {
             const int t = esl * Ls + i0 + ec, tb = t - 3;
-            gfe = t < L ? gf[t] : 0.f;
-            gbe = (tb >= 0 && tb < L) ? gb[L - 1 - tb] : 0.f;
+            gfe = t < L ? to_f32(gf[t]) : 0.f;
+            gbe = (tb >= 0 && tb < L) ? to_f32(gb[L - 1 - tb]) : 0.f;
         }
         // slice order at i0 .. i0+TI (column c of dsl)
 #pragma unroll
         for (int k = 0; k < JP; ++k) {
             const int j = threadIdx.x + 256 * k;
-            gsa[k] = (j < (TI + 1) * ns && (long)i0 * ns + j < L) ? gs[(long)i0 * ns + j] : 0.f;
+            gsa[k] = (j < (TI + 1) * ns && (long)i0 * ns + j < L) ? to_f32(gs[(long)i0 * ns + j]) : 0.f;
         }
     };
     issue((int)blockIdx.x * TI);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, NS > 0 ? 2 : 1) void tri_conv_bwd_kernel(TcArg
                     }
                     a = fmaf(tp.w[2][m], dsl[sp * TP + c], a);
                 }
-                dxr[sl * Ls + i0 + tx] = a;
+                dxr[sl * Ls + i0 + tx] = from_f32<io_t>(a);
                 const float dpf = rf[0], dpb = rb[3], dps = dsl[sl * TP + tx];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void tri_wgrad_reduce_kernel(TrArgs p) {
     if (lane == 0 && p.dbias[k]) p.dbias[k][d] = vb;
 }
 
-template <int NS>
+template <int NS, typename io_t>
 __global__ __launch_bounds__(256) void tri_gate_fwd_kernel(TgArgs p) {
     __shared__ float tile[64 * TGP];
     const int ns = NS > 0 ? NS : p.ns;
@@ -342,24 +342,24 @@ __global__ __launch_bounds__(256) void tri_gate_fwd_kernel(TgArgs p) {
     const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int ni = Ls - i0 < TI ? Ls - i0 : TI;
     const long ob = (long)row * L;
-    const float *src = p.y[2] + ob + (long)i0 * ns;
+    const io_t *src = (const io_t *)p.y[2] + ob + (long)i0 * ns;
     for (int j = threadIdx.x; j < ni * ns; j += 256) {
         const int il = j / ns, s = j - il * ns;
-        tile[s * TGP + il] = src[j];
+        tile[s * TGP + il] = to_f32(src[j]);
     }
     __syncthreads();
     if (tx >= ni) return;
-    const float *zr = p.z + (long)b * p.z_bs + (long)d * p.z_ds;
-    const float *yf = p.y[0] + ob, *yb = p.y[1] + ob;
-    float *o = p.out + (long)b * p.out_bs + (long)d * p.out_ds;
+    const io_t *zr = (const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds;
+    const io_t *yf = (const io_t *)p.y[0] + ob, *yb = (const io_t *)p.y[1] + ob;
+    io_t *o = (io_t *)p.out + (long)b * p.out_bs + (long)d * p.out_ds;
     for (int sl = ry; sl < ns; sl += 4) {
         const int t = sl * Ls + i0 + tx;
-        const float zz = zr[t];
-        o[t] = (yf[t] + yb[L - 1 - t] + tile[sl * TGP + tx]) * silu_(zz);
+        const float zz = to_f32(zr[t]);
+        o[t] = from_f32<io_t>((to_f32(yf[t]) + to_f32(yb[L - 1 - t]) + tile[sl * TGP + tx]) * silu_(zz));
     }
 }
 
-template <int NS>
+template <int NS, typename io_t>
 __global__ __launch_bounds__(256) void tri_gate_bwd_kernel(TgArgs p) {
     __shared__ float tile[64 * TGP];
     const int ns = NS > 0 ? NS : p.ns;
@@ -370,35 +370,35 @@ __global__ __launch_bounds__(256) void tri_gate_bwd_kernel(TgArgs p) {
     const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int ni = Ls - i0 < TI ? Ls - i0 : TI;
     const long ob = (long)row * L;
-    const float *src = p.y[2] + ob + (long)i0 * ns;
+    const io_t *src = (const io_t *)p.y[2] + ob + (long)i0 * ns;
     for (int j = threadIdx.x; j < ni * ns; j += 256) {
         const int il = j / ns, s = j - il * ns;
-        tile[s * TGP + il] = src[j];
+        tile[s * TGP + il] = to_f32(src[j]);
     }
     __syncthreads();
     if (tx < ni) {
-        const float *zr = p.z + (long)b * p.z_bs + (long)d * p.z_ds;
-        const float *gr = p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds;
-        float *dzr = p.dz + (long)b * p.dz_bs + (long)d * p.dz_ds;
-        const float *yf = p.y[0] + ob, *yb = p.y[1] + ob;
-        float *df = p.dy[0] + ob, *db = p.dy[1] + ob;
+        const io_t *zr = (const io_t *)p.z + (long)b * p.z_bs + (long)d * p.z_ds;
+        const io_t *gr = (const io_t *)p.dout + (long)b * p.dout_bs + (long)d * p.dout_ds;
+        io_t *dzr = (io_t *)p.dz + (long)b * p.dz_bs + (long)d * p.dz_ds;
+        const io_t *yf = (const io_t *)p.y[0] + ob, *yb = (const io_t *)p.y[1] + ob;
+        io_t *df = (io_t *)p.dy[0] + ob, *db = (io_t *)p.dy[1] + ob;
         for (int sl = ry; sl < ns; sl += 4) {
             const int t = sl * Ls + i0 + tx;
-            const float zz = zr[t], g = gr[t];
-            const float sum = yf[t] + yb[L - 1 - t] + tile[sl * TGP + tx];
+            const float zz = to_f32(zr[t]), g = to_f32(gr[t]);
+            const float sum = to_f32(yf[t]) + to_f32(yb[L - 1 - t]) + tile[sl * TGP + tx];
             const float sg = sigmoidf_(zz);
-            dzr[t] = g * sum * sg * (1.f + zz * (1.f - sg));
+            dzr[t] = from_f32<io_t>(g * sum * sg * (1.f + zz * (1.f - sg)));
             const float dy = g * zz * sg;
-            df[t] = dy;
-            db[L - 1 - t] = dy;
+            df[t] = from_f32<io_t>(dy);
+            db[L - 1 - t] = from_f32<io_t>(dy);
             tile[sl * TGP + tx] = dy;    // (a slot is read and written by its own thread only in this phase)
         }
     }
     __syncthreads();
-    float *dst = p.dy[2] + ob + (long)i0 * ns;
+    io_t *dst = (io_t *)p.dy[2] + ob + (long)i0 * ns;
     for (int j = threadIdx.x; j < ni * ns; j += 256) {
         const int il = j / ns, s = j - il * ns;
-        dst[j] = tile[s * TGP + il];
+        dst[j] = from_f32<io_t>(tile[s * TGP + il]);
     }
 }
 
@@ -410,7 +410,7 @@ inline int tri_bwd_blocks(int rows, int ntiles) {
 
 int tc_check(const mmu_tri_conv_params *p, const char *name) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
-    MMU_CHECK(p->dtype == MMU_DTYPE_F32, "%s: float32 only (got dtype %d)", name, p->dtype);
+    MMU_CHECK(p->dtype == MMU_DTYPE_F32 || p->dtype == MMU_DTYPE_BF16, "%s: float32 or bfloat16 (got dtype %d)", name, p->dtype);
     MMU_CHECK(p->batch > 0 && p->dim > 0 && p->seqlen > 0, "%s: empty tensor", name);
     MMU_CHECK(p->nslices >= 4 && p->nslices <= 64, "%s: 4..64 slices (got %d)", name, p->nslices);
     MMU_CHECK(p->seqlen % p->nslices == 0, "%s: seqlen %d must be divisible by nslices %d", name, p->seqlen, p->nslices);
@@ -422,17 +422,17 @@ int tc_check(const mmu_tri_conv_params *p, const char *name) {
 void tc_fill(const mmu_tri_conv_params *p, TcArgs &a) {
     a.batch = p->batch; a.dim = p->dim; a.L = p->seqlen; a.ns = p->nslices; a.Ls = p->seqlen / p->nslices;
     a.ntiles = (a.Ls + TI - 1) / TI;
-    a.x = (const float *)p->x; a.x_bs = p->x_bs; a.x_ds = p->x_ds;
+    a.x = p->x; a.x_bs = p->x_bs; a.x_ds = p->x_ds;
     a.w[0] = p->weight_f; a.w[1] = p->weight_b; a.w[2] = p->weight_s;
     a.b[0] = p->bias_f; a.b[1] = p->bias_b; a.b[2] = p->bias_s;
-    a.out[0] = (float *)p->out_f; a.out[1] = (float *)p->out_b; a.out[2] = (float *)p->out_s;
-    a.g[0] = (const float *)p->dout_f; a.g[1] = (const float *)p->dout_b; a.g[2] = (const float *)p->dout_s;
-    a.dx = (float *)p->dx; a.dx_bs = p->dx_bs; a.dx_ds = p->dx_ds;
+    a.out[0] = p->out_f; a.out[1] = p->out_b; a.out[2] = p->out_s;
+    a.g[0] = p->dout_f; a.g[1] = p->dout_b; a.g[2] = p->dout_s;
+    a.dx = p->dx; a.dx_bs = p->dx_bs; a.dx_ds = p->dx_ds;
 }
 
 int tg_check(const mmu_tri_gate_params *p, const char *name) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
-    MMU_CHECK(p->dtype == MMU_DTYPE_F32, "%s: float32 only (got dtype %d)", name, p->dtype);
+    MMU_CHECK(p->dtype == MMU_DTYPE_F32 || p->dtype == MMU_DTYPE_BF16, "%s: float32 or bfloat16 (got dtype %d)", name, p->dtype);
     MMU_CHECK(p->batch > 0 && p->dim > 0 && p->seqlen > 0, "%s: empty tensor", name);
     MMU_CHECK(p->nslices >= 1 && p->nslices <= 64, "%s: 1..64 slices (got %d)", name, p->nslices);
     MMU_CHECK(p->seqlen % p->nslices == 0, "%s: seqlen %d must be divisible by nslices %d", name, p->seqlen, p->nslices);
@@ -443,23 +443,32 @@ int tg_check(const mmu_tri_gate_params *p, const char *name) {
 
 void tg_fill(const mmu_tri_gate_params *p, TgArgs &a) {
     a.batch = p->batch; a.dim = p->dim; a.L = p->seqlen; a.ns = p->nslices; a.Ls = p->seqlen / p->nslices;
-    a.z = (const float *)p->z; a.z_bs = p->z_bs; a.z_ds = p->z_ds;
-    a.y[0] = (const float *)p->y_f; a.y[1] = (const float *)p->y_b; a.y[2] = (const float *)p->y_s;
-    a.dy[0] = (float *)p->dy_f; a.dy[1] = (float *)p->dy_b; a.dy[2] = (float *)p->dy_s;
-    a.out = (float *)p->out; a.out_bs = p->out_bs; a.out_ds = p->out_ds;
-    a.dout = (const float *)p->dout; a.dout_bs = p->dout_bs; a.dout_ds = p->dout_ds;
-    a.dz = (float *)p->dz; a.dz_bs = p->dz_bs; a.dz_ds = p->dz_ds;
+    a.z = p->z; a.z_bs = p->z_bs; a.z_ds = p->z_ds;
+    a.y[0] = p->y_f; a.y[1] = p->y_b; a.y[2] = p->y_s;
+    a.dy[0] = p->dy_f; a.dy[1] = p->dy_b; a.dy[2] = p->dy_s;
+    a.out = p->out; a.out_bs = p->out_bs; a.out_ds = p->out_ds;
+    a.dout = p->dout; a.dout_bs = p->dout_bs; a.dout_ds = p->dout_ds;
+    a.dz = p->dz; a.dz_bs = p->dz_bs; a.dz_ds = p->dz_ds;
 }
 
-#define TRI_NS(ns, NS, ...)                              \
+#define TRI_NS_(ns, NS, ...)                             \
     switch (ns) {                                        \
     case 16: { constexpr int NS = 16; __VA_ARGS__; } break; \
     case 32: { constexpr int NS = 32; __VA_ARGS__; } break; \
     case 64: { constexpr int NS = 64; __VA_ARGS__; } break; \
     default: { constexpr int NS = 0; __VA_ARGS__; } break;  \
     }
+// (slice count, element type) -> template arguments NS, io_t
+#define TRI_NS(ns, NS, ...)                                               \
+    if (p->dtype == MMU_DTYPE_BF16) {                                     \
+        using io_t = bf16_t;                                              \
+        TRI_NS_(ns, NS, __VA_ARGS__)                                      \
+    } else {                                                              \
+        using io_t = float;                                               \
+        TRI_NS_(ns, NS, __VA_ARGS__)                                      \
+    }
 
-unsigned long long g_bwd_lds[4];
+unsigned long long g_bwd_lds[8];
 
 }  // namespace
 
@@ -470,7 +479,7 @@ extern "C" int mmu_tri_conv_fwd(const mmu_tri_conv_params *p, void *stream) {
     tc_fill(p, a);
     const int lds = a.ns * TP * 4;
     dim3 grid(a.ntiles, p->batch * p->dim);
-    TRI_NS(a.ns, NS, tri_conv_fwd_kernel<NS><<<grid, 256, lds, (hipStream_t)stream>>>(a));
+    TRI_NS(a.ns, NS, tri_conv_fwd_kernel<NS, io_t><<<grid, 256, lds, (hipStream_t)stream>>>(a));
     MMU_HIP_LAUNCH_CHECK("tri_conv_fwd");
     return 0;
 }
@@ -497,8 +506,8 @@ extern "C" int mmu_tri_conv_bwd(const mmu_tri_conv_params *p, void *stream) {
     int slot = a.ns == 16 ? 1 : a.ns == 32 ? 2 : a.ns == 64 ? 3 : 0;
     hipError_t e = hipSuccess;
     TRI_NS(a.ns, NS, {
-        if (lds > 64 * 1024) e = mmu_set_lds_once(tri_conv_bwd_kernel<NS>, lds, g_bwd_lds[slot]);
-        if (e == hipSuccess) tri_conv_bwd_kernel<NS><<<grid, 256, lds, st>>>(a);
+        if (lds > 64 * 1024) e = mmu_set_lds_once(tri_conv_bwd_kernel<NS, io_t>, lds, g_bwd_lds[slot + (p->dtype == MMU_DTYPE_BF16 ? 4 : 0)]);
+        if (e == hipSuccess) tri_conv_bwd_kernel<NS, io_t><<<grid, 256, lds, st>>>(a);
     });
     MMU_CHECK(e == hipSuccess, "tri_conv_bwd: %s", hipGetErrorString(e));
     MMU_HIP_LAUNCH_CHECK("tri_conv_bwd");
@@ -527,7 +536,7 @@ extern "C" int mmu_tri_gate_fwd(const mmu_tri_gate_params *p, void *stream) {
     TgArgs a = {};
     tg_fill(p, a);
     dim3 grid((a.Ls + TI - 1) / TI, p->batch * p->dim);
-    TRI_NS(a.ns, NS, tri_gate_fwd_kernel<NS><<<grid, 256, 0, (hipStream_t)stream>>>(a));
+    TRI_NS(a.ns, NS, tri_gate_fwd_kernel<NS, io_t><<<grid, 256, 0, (hipStream_t)stream>>>(a));
     MMU_HIP_LAUNCH_CHECK("tri_gate_fwd");
     return 0;
 }
@@ -538,7 +547,7 @@ extern "C" int mmu_tri_gate_bwd(const mmu_tri_gate_params *p, void *stream) {
     TgArgs a = {};
     tg_fill(p, a);
     dim3 grid((a.Ls + TI - 1) / TI, p->batch * p->dim);
-    TRI_NS(a.ns, NS, tri_gate_bwd_kernel<NS><<<grid, 256, 0, (hipStream_t)stream>>>(a));
+    TRI_NS(a.ns, NS, tri_gate_bwd_kernel<NS, io_t><<<grid, 256, 0, (hipStream_t)stream>>>(a));
     MMU_HIP_LAUNCH_CHECK("tri_gate_bwd");
     return 0;
 }

@@ -26,8 +26,12 @@ ENABLED = True   # False: Mamba._v3 keeps the three mamba_inner calls (fused_pat
 
 
 def supported(xz, nslices, conv_weights, params):
-    """float32 GPU tensors outside autocast, conv width 4, 4..64 slices dividing L, (batch, channel) rows of ``xz`` dense."""
-    if not ENABLED or xz.dim() != 3 or not xz.is_cuda or xz.dtype != torch.float32 or torch.is_autocast_enabled():
+    """float32 activations outside autocast, or bfloat16 activations (what the block's in_proj emits under bf16 autocast:
+    selective_scan_interface.py:158,169-171 -- x_proj / dt_proj are then cast to bfloat16 as the reference casts them);
+    float32 parameters, conv width 4, 4..64 slices dividing L, (batch, channel) rows of ``xz`` dense."""
+    if not ENABLED or xz.dim() != 3 or not xz.is_cuda or xz.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    if torch.is_autocast_enabled() and (torch.get_autocast_dtype("cuda") != torch.bfloat16 or xz.dtype != torch.bfloat16):
         return False
     B, C2, L = xz.shape
     if xz.stride(2) != 1 or C2 % 2 or not (4 <= nslices <= 64) or L % nslices or B * (C2 // 2) >= 65536:
@@ -38,14 +42,15 @@ def supported(xz, nslices, conv_weights, params):
 
 
 def _cbl(batch, dim, L, ref):
-    """(batch, dim, L) tensor laid out [dim][batch][L]: what the tokens-last projections want (a plain matrix view)."""
-    return torch.empty((dim, batch, L), device=ref.device, dtype=torch.float32).permute(1, 0, 2)
+    """(batch, dim, L) tensor of ``ref``'s type laid out [dim][batch][L]: what the tokens-last projections want (a plain
+    matrix view)."""
+    return torch.empty((dim, batch, L), device=ref.device, dtype=ref.dtype).permute(1, 0, 2)
 
 
 def _conv_params(x, ns, weights, biases):
     p = _lib.TriConvParams()
     p.batch, p.dim, p.seqlen, p.nslices = x.shape[0], x.shape[1], x.shape[2], ns
-    p.dtype = _lib.MMU_DTYPE_F32
+    p.dtype = _lib.dtype_code(x)
     p.x, p.x_bs, p.x_ds = x.data_ptr(), x.stride(0), x.stride(1)
     p.weight_f, p.weight_b, p.weight_s = (w.data_ptr() for w in weights)
     p.bias_f, p.bias_b, p.bias_s = (_lib.ptr(b) for b in biases)
@@ -87,7 +92,7 @@ def tri_conv_bwd(x, ns, weights, biases, douts, dx):
 def _gate_params(z, ns, ys):
     p = _lib.TriGateParams()
     p.batch, p.dim, p.seqlen, p.nslices = z.shape[0], z.shape[1], z.shape[2], ns
-    p.dtype = _lib.MMU_DTYPE_F32
+    p.dtype = _lib.dtype_code(z)
     p.z, p.z_bs, p.z_ds = z.data_ptr(), z.stride(0), z.stride(1)
     p.y_f, p.y_b, p.y_s = (y.data_ptr() for y in ys)
     return p
@@ -129,8 +134,16 @@ class TriMambaInnerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xz, ns, *params):
+        with torch.autocast("cuda", enabled=False):     # every cast below is explicit
+            return TriMambaInnerFn._forward(ctx, xz, ns, *params)
+
+    @staticmethod
+    def _forward(ctx, xz, ns, *params):
         assert len(params) == 3 * N_PER_DIR
         dirs = [params[k * N_PER_DIR:(k + 1) * N_PER_DIR] for k in range(3)]
+        ctx.proj_dtypes = [(d[2].dtype, d[3].dtype) for d in dirs]
+        if xz.dtype != torch.float32:    # bf16 activations: x_proj / dt_proj in bf16 too (selective_scan_interface.py:169-171)
+            dirs = [(d[0], d[1], d[2].to(xz.dtype), d[3].to(xz.dtype)) + tuple(d[4:]) for d in dirs]
         B, C2, L = xz.shape
         D_in = C2 // 2
         x, z = xz.chunk(2, dim=1)
@@ -167,8 +180,10 @@ class TriMambaInnerFn(torch.autograd.Function):
         per = [rest[k * 10:(k + 1) * 10] for k in range(3)]
         dxz = torch.empty_like(xz)
         dx, dz = dxz.chunk(2, dim=1)
-        if dtotal.stride(2) != 1 or dtotal.dtype != torch.float32:
-            dtotal = dtotal.float().contiguous()
+        if dtotal.dtype != xz.dtype:
+            dtotal = dtotal.to(xz.dtype)
+        if dtotal.stride(2) != 1:
+            dtotal = dtotal.contiguous()
         dys = tri_gate_bwd(z, ns, [p[4] for p in per], dtotal, dz)
         dconvs, grads = [], []
         for k, (conv, delta, x_dblT, inter, y, xw, dtw, A, Dc, dbias) in enumerate(per):
@@ -195,7 +210,8 @@ class TriMambaInnerFn(torch.autograd.Function):
                 t.copy_(dconv)
                 dconv = t
             dconvs.append(dconv)
-            grads.append([None, None, dxw, ddtw, dA, dD if Dc is not None else None, ddbias if dbias is not None else None])
+            grads.append([None, None, dxw.to(ctx.proj_dtypes[k][0]), ddtw.to(ctx.proj_dtypes[k][1]), dA,
+                          dD if Dc is not None else None, ddbias if dbias is not None else None])
         if ctx.conv_leaves:
             dws, dbs = tri_conv_bwd(x, ns, cws, cbs, dconvs, dx)
         else:

@@ -224,3 +224,85 @@ def test_stem7_mfma_vs_float64(B, H, W):
     out.backward(dout)
     e = float((conv.weight.grad.double() - wd.grad).abs().max())
     assert e < 5e-6 * float(wd.grad.abs().max()), e
+
+
+@pytest.mark.parametrize("B,D,L,ns", [(2, 6, 16 * 70, 16), (2, 4, 64 * 64, 64), (1, 3, 5 * 13, 5)])
+def test_tri_kernels_bfloat16_io(B, D, L, ns):
+    """bfloat16 activations (float32 arithmetic and weights): each kernel against the float64 composition of ITS bf16
+    inputs, within bf16 rounding of the outputs."""
+    from mm_unet_amd import tri_inner
+    gen = torch.Generator().manual_seed(L + ns)
+    bf = torch.bfloat16
+    xz = _cbl(torch.randn(B, 2 * D, L, generator=gen)).to(DEV).to(bf)
+    x, z = xz[:, :D], xz[:, D:]
+    ws = [(0.5 * torch.randn(D, 4, generator=gen)).to(DEV) for _ in range(3)]
+    bs = [(0.5 * torch.randn(D, generator=gen)).to(DEV) for _ in range(3)]
+    outs = tri_inner.tri_conv_fwd(x, ns, ws, bs)
+    xd = x.double().requires_grad_()
+    wd = [w.double().requires_grad_() for w in ws]
+    bd = [b.double().requires_grad_() for b in bs]
+    refs = [_conv_silu(xd, wd[0], bd[0]), _conv_silu(xd.flip(-1), wd[1], bd[1]), _conv_silu(_slice_order(xd, ns), wd[2], bd[2])]
+    rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max().clamp_min(1e-6))   # noqa: E731
+    for o, r in zip(outs, refs):
+        assert o.dtype == bf and rel(o, r) < 6e-3
+    douts = [_cbl(torch.randn(B, D, L, generator=gen)).to(DEV).to(bf) for _ in range(3)]
+    sum((r * g.double()).sum() for r, g in zip(refs, douts)).backward()
+    dxz = torch.zeros_like(xz)
+    dws, dbs = tri_inner.tri_conv_bwd(x, ns, ws, bs, douts, dxz[:, :D])
+    assert rel(dxz[:, :D], xd.grad) < 6e-3
+    for k in range(3):
+        assert dws[k].dtype == torch.float32 and rel(dws[k], wd[k].grad) < 1e-4 and rel(dbs[k], bd[k].grad) < 1e-4
+    ys = [_cbl(torch.randn(B, D, L, generator=gen)).to(DEV).to(bf) for _ in range(3)]
+    out = tri_inner.tri_gate_fwd(z, ns, ys)
+    zd = z.double().requires_grad_()
+    yd = [y.double().requires_grad_() for y in ys]
+    ref = F.silu(zd) * (yd[0] + yd[1].flip(-1) + _unslice(yd[2], ns))
+    assert out.dtype == bf and rel(out, ref) < 6e-3
+    dout = torch.randn(B, D, L, generator=gen).to(DEV).to(bf)
+    (ref * dout.double()).sum().backward()
+    dys = tri_inner.tri_gate_bwd(z, ns, ys, dout, dxz[:, D:])
+    assert rel(dxz[:, D:], zd.grad) < 8e-3
+    for k in range(3):
+        assert rel(dys[k], yd[k].grad) < 6e-3
+
+
+def test_fused_tri_block_under_bf16_autocast():
+    """Mamba(v3).forward_bcl under bf16 autocast: the fused route and the three-call route are both bf16 computations of
+    the float32 result; the fused one must not be further from it."""
+    from mm_unet_amd import tri_inner
+    from mm_unet_amd.mamba_simple import Mamba
+    torch.manual_seed(3)
+    m = Mamba(64, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nslices=32).to(DEV)
+    m.return_branch_outputs = False
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn(4, 64, 2048, generator=gen).to(DEV)
+    dout = torch.randn(x0.shape, generator=gen).to(DEV)
+
+    def run(autocast, fused):
+        tri_inner.ENABLED = fused
+        try:
+            for p in m.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                out = m.forward_bcl(x)[0]
+            out.float().backward(dout)
+            return out.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            tri_inner.ENABLED = True
+
+    calls = []
+    orig = tri_inner.tri_mamba_inner
+    tri_inner.tri_mamba_inner = lambda *a: (calls.append(a[0].dtype), orig(*a))[1]
+    try:
+        truth, fused, three = run(False, True), run(True, True), run(True, False)
+    finally:
+        tri_inner.tri_mamba_inner = orig
+    assert torch.bfloat16 in calls, "the fused route was not taken under autocast"
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12))   # noqa: E731
+    assert rms(fused[0], truth[0]) < 1.3 * rms(three[0], truth[0]) + 1e-3, (rms(fused[0], truth[0]), rms(three[0], truth[0]))
+    assert rms(fused[1], truth[1]) < 1.3 * rms(three[1], truth[1]) + 1e-3
+    assert set(fused[2]) == set(truth[2]) == set(three[2])
+    for n in truth[2]:
+        ef, et = rms(fused[2][n], truth[2][n]), rms(three[2][n], truth[2][n])
+        assert ef < 1.5 * et + 2e-2, (n, ef, et)
