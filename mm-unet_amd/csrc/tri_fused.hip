@@ -79,21 +79,23 @@ __device__ __forceinline__ void load_taps(const TcArgs &p, int d, Taps &t) {
 template <int KS, typename io_t>
 __device__ __forceinline__ void stage_x(const io_t *__restrict__ xr, float *xt, int ns, int Ls, int L, int i0, int tx, int ry) {
     for (int sb = ry; sb < ns; sb += 4 * KS) {
-        float a[KS], h[KS];
+        // (raw values in the registers, converted where they are consumed: a conversion next to its load is a wait on it)
+        io_t a[KS], h[KS];
+        const io_t zero = from_f32<io_t>(0.f);
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int sl = sb + 4 * k;
             const int t0 = sl * Ls + i0 - 3;
             const int t = t0 + tx, th = t0 + 64 + tx;
-            a[k] = (sl < ns && t >= 0 && t < L) ? to_f32(xr[t]) : 0.f;
-            h[k] = (sl < ns && tx < 6 && th >= 0 && th < L) ? to_f32(xr[th]) : 0.f;
+            a[k] = (sl < ns && t >= 0 && t < L) ? xr[t] : zero;
+            h[k] = (sl < ns && tx < 6 && th >= 0 && th < L) ? xr[th] : zero;
         }
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int sl = sb + 4 * k;
             if (sl < ns) {
-                xt[sl * TP + tx] = a[k];
-                if (tx < 6) xt[sl * TP + 64 + tx] = h[k];
+                xt[sl * TP + tx] = to_f32(a[k]);
+                if (tx < 6) xt[sl * TP + 64 + tx] = to_f32(h[k]);
             }
         }
     }
@@ -186,35 +188,37 @@ __global__ __launch_bounds__(256, NS > 0 ? 2 : 1) void tri_conv_bwd_kernel(TcArg
     // One tile's global loads (x with its halos, the three dout tiles) go into registers and are issued a whole tile
     // ahead: the loads of tile k+1 are in flight under the gradient phase of tile k (2 workgroups per CU at 64 slices:
     // nothing else hides a memory round trip).
-    float xa[KS], xh[2], gfa[KS], gba[KS], gfe = 0.f, gbe = 0.f, gsa[JP];
+    // (raw values in the registers, converted where they are consumed: a conversion next to its load is a wait on it)
+    const io_t zero = from_f32<io_t>(0.f);
+    io_t xa[KS], xh[2], gfa[KS], gba[KS], gfe = zero, gbe = zero, gsa[JP];
     const int esl = threadIdx.x / 3, ec = TI + (int)threadIdx.x - 3 * esl;   // the 3 extra columns of every slice
     auto issue = [&](int i0) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int sl = ry + 4 * k;
             const int tl = sl * Ls + i0 - 3 + tx;
-            xa[k] = (sl < ns && tl >= 0 && tl < L) ? to_f32(xr[tl]) : 0.f;
+            xa[k] = (sl < ns && tl >= 0 && tl < L) ? xr[tl] : zero;
             // natural order at positions i0 .. i0+TI+2, flipped order at the tokens i0-3 .. i0+TI-1: column c of df / db
             const int t = sl * Ls + i0 + tx, tb = t - 3;
-            gfa[k] = (sl < ns && t < L) ? to_f32(gf[t]) : 0.f;
-            gba[k] = (sl < ns && tb >= 0 && tb < L) ? to_f32(gb[L - 1 - tb]) : 0.f;
+            gfa[k] = (sl < ns && t < L) ? gf[t] : zero;
+            gba[k] = (sl < ns && tb >= 0 && tb < L) ? gb[L - 1 - tb] : zero;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {   // x columns 64..69 of every slice
             const int j = threadIdx.x + 256 * k, sl = j / 6;
             const int th = sl * Ls + i0 - 3 + 64 + (j - 6 * sl);
-            xh[k] = (j < 6 * ns && th >= 0 && th < L) ? to_f32(xr[th]) : 0.f;
+            xh[k] = (j < 6 * ns && th >= 0 && th < L) ? xr[th] : zero;
         }
         if (threadIdx.x < 3 * ns) {
             const int t = esl * Ls + i0 + ec, tb = t - 3;
-            gfe = t < L ? to_f32(gf[t]) : 0.f;
-            gbe = (tb >= 0 && tb < L) ? to_f32(gb[L - 1 - tb]) : 0.f;
+            gfe = t < L ? gf[t] : zero;
+            gbe = (tb >= 0 && tb < L) ? gb[L - 1 - tb] : zero;
         }
         // slice order at i0 .. i0+TI (column c of dsl)
 #pragma unroll
         for (int k = 0; k < JP; ++k) {
             const int j = threadIdx.x + 256 * k;
-            gsa[k] = (j < (TI + 1) * ns && (long)i0 * ns + j < L) ? to_f32(gs[(long)i0 * ns + j]) : 0.f;
+            gsa[k] = (j < (TI + 1) * ns && (long)i0 * ns + j < L) ? gs[(long)i0 * ns + j] : zero;
         }
     };
     issue((int)blockIdx.x * TI);
@@ -224,12 +228,12 @@ __global__ __launch_bounds__(256, NS > 0 ? 2 : 1) void tri_conv_bwd_kernel(TcArg
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int sl = ry + 4 * k;
-            if (sl < ns) xt[sl * TP + tx] = xa[k];
+            if (sl < ns) xt[sl * TP + tx] = to_f32(xa[k]);
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int j = threadIdx.x + 256 * k, sl = j / 6;
-            if (j < 6 * ns) xt[sl * TP + 64 + (j - 6 * sl)] = xh[k];
+            if (j < 6 * ns) xt[sl * TP + 64 + (j - 6 * sl)] = to_f32(xh[k]);
         }
         __syncthreads();
         // dp = dout * silu'(pre): both natural-order tiles read the same window x[c .. c+3] of the staged row
@@ -244,15 +248,15 @@ __global__ __launch_bounds__(256, NS > 0 ? 2 : 1) void tri_conv_bwd_kernel(TcArg
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int sl = ry + 4 * k;
-            if (sl < ns) dp_fb(sl, tx, gfa[k], gba[k]);
+            if (sl < ns) dp_fb(sl, tx, to_f32(gfa[k]), to_f32(gba[k]));
         }
-        if (threadIdx.x < 3 * ns) dp_fb(esl, ec, gfe, gbe);
+        if (threadIdx.x < 3 * ns) dp_fb(esl, ec, to_f32(gfe), to_f32(gbe));
 #pragma unroll
         for (int k = 0; k < JP; ++k) {
             const int j = threadIdx.x + 256 * k;
             if (j < (TI + 1) * ns) {
                 const int c = j / ns, s = j - c * ns;
-                dsl[s * TP + c] = gsa[k] * dsilu_(slice_pre(xt, tp.w[2], tp.b[2], ns, s, c, i0));
+                dsl[s * TP + c] = to_f32(gsa[k]) * dsilu_(slice_pre(xt, tp.w[2], tp.b[2], ns, s, c, i0));
             }
         }
         if (tile + (int)gridDim.x < p.ntiles) issue((tile + (int)gridDim.x) * TI);
