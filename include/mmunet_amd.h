@@ -519,8 +519,13 @@ int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream);
  * leading dimension) and is read transposed.  MMConv's dsc_conv_x on the sampler output (src/UM_Net/MMUNet.py:262):
  * forward = (Cout x 3Cin) . samples, input gradient = transposed weight . dout.
  * workspace: mmu_gemm_tokens_workspace_bytes() bytes, 16-byte aligned.
- * weight = NULL: the workspace ALREADY holds this weight's bf16 hi/lo image, written by mmu_gemm_tokens_prepare_batch
- * for the same (rows, inner, transposed_weight); the call then launches the product alone. */
+ * weight = NULL: the workspace ALREADY holds this weight's bf16 image, written by mmu_gemm_tokens_prepare_batch
+ * for the same (rows, inner, transposed_weight); the call then launches the product alone.
+ * Two kernels behind the entry point (ABI 7): products with >= 520 tiles of 64 rows x 512 tokens stream through the
+ * producer / consumer kernel (two-part bf16 split, 2^-16 products); smaller ones -- few tokens, deep inner dimension:
+ * the DSC products and projections of the maps <= 64 x 64 -- take a 64-row x 32/64-token kernel whose waves split the
+ * inner dimension, with THREE-part (float32-grade) products.  The image holds the hi | mid parts per chunk and the third
+ * parts behind them (1.5 x the ABI-6 size). */
 typedef struct {
     int32_t rows, inner, tokens, batch, transposed_weight;
     const float *weight;  int64_t w_ld;
