@@ -10,7 +10,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -munsafe-fp-atomics -Wall -Wno-unused-function ${MMU_EXTRA_FLAGS:-}"
 # left-overs of -save-temps runs (tools/kstats.sh and friends): never part of the library, 30 MB per gpurun push
 rm -f ./*-hip-amdgcn-amd-amdhsa-gfx950.* ./*-host-x86_64-unknown-linux-gnu.* 2>/dev/null || true
-SOURCES="mmu_abi.hip selective_scan.hip selective_scan_stream.hip selective_scan_bwd_w8.hip causal_conv1d.hip morph_sample.hip morph_coords.hip resize.hip conv3x3_small.hip tri_order.hip norm_fused.hip mamba_pre.hip conv3x3_mfma.hip conv3x3_wgrad_mfma.hip gemm_tokens_mfma.hip gemm_nt_splitk.hip pointwise_one.hip sum_parts.hip maxpool.hip conv7x7_small.hip gated_mul.hip cbam_stats.hip mamba_small_fused.hip conv_s2_mfma.hip morph_mix.hip adamw_multi.hip deferred_reduce.hip dice_bce.hip dt_proj.hip tri_fused.hip stem7_mfma.hip"
+SOURCES="mmu_abi.hip selective_scan.hip selective_scan_stream.hip selective_scan_bwd_w8.hip causal_conv1d.hip morph_sample.hip morph_coords.hip resize.hip conv3x3_small.hip tri_order.hip norm_fused.hip mamba_pre.hip conv3x3_mfma.hip conv3x3_wgrad_mfma.hip gemm_tokens_mfma.hip gemm_nt_splitk.hip pointwise_one.hip sum_parts.hip maxpool.hip conv7x7_small.hip gated_mul.hip cbam_stats.hip mamba_small_fused.hip conv_s2_mfma.hip morph_mix.hip adamw_multi.hip deferred_reduce.hip dice_bce.hip dt_proj.hip tri_fused.hip stem7_mfma.hip offset_conv_mfma.hip"
 objs=()
 compiled=0
 for f in $SOURCES; do

@@ -550,11 +550,16 @@ extern "C" size_t mmu_conv3x3_small_wgrad_workspace_floats(int batch, int in_cha
     return (size_t)nrb * batch * in_channels * ((out_channels * 10 + 3) & ~3);
 }
 
+int mmu_offset_dgrad_mfma_try(const mmu_conv3x3s_params *p, hipStream_t st);   // offset_conv_mfma.hip
+
 extern "C" int mmu_conv3x3_small_bwd(const mmu_conv3x3s_params *p, void *stream) {
     if (int r = check(p, "conv3x3_small_bwd")) return r;
     MMU_CHECK(p->dout && p->weight_t, "conv3x3_small_bwd: dout and weight_t are required");
     hipStream_t st = (hipStream_t)stream;
-    if (p->dinput) {
+    // the input gradient on the matrix cores where the shape allows (offset_conv_mfma.hip): 1 = done, 0 = not covered
+    const int on_mfma = p->dinput ? mmu_offset_dgrad_mfma_try(p, st) : 0;
+    if (on_mfma == 2) return 1;
+    if (p->dinput && on_mfma == 0) {
         static const bool four_off = []() { const char *e = getenv("MMU_CONV3X3S_BWD4"); return e && e[0] == '0'; }();
         const size_t esz = p->in_dtype == MMU_DTYPE_BF16 ? 2 : 4;
         const bool four = !four_off && p->width % 4 == 0 && ((uintptr_t)p->dout & 15) == 0 &&

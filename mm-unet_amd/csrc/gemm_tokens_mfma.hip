@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
 // NB = 32-token blocks per wave (tile = 64 rows x 32 NB tokens): the A fragments (three 16-byte loads per row tile and
 // chunk -- three quarters of the kernel's L1 traffic at NB = 1) serve NB token blocks.
 template <int NB>
-__global__ __launch_bounds__(256) void gemm_tokens_small_kernel(GemmArgs p, int per_xcd) {
+__global__ __launch_bounds__(256, NB == 1 ? 4 : 2) void gemm_tokens_small_kernel(GemmArgs p, int per_xcd) {
     __shared__ float red[4 * 32 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);

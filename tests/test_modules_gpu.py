@@ -648,7 +648,10 @@ def test_bilinear_resize_vs_interpolate(case):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 6, 32, 32), (1, 7, 6, 13, 10), (2, 5, 1, 9, 17), (1, 64, 8, 16, 16),
-                                  (3, 3, 2, 1, 5), (1, 12, 6, 64, 128)])
+                                  (3, 3, 2, 1, 5), (1, 12, 6, 64, 128),
+                                  # in_channels % 32 == 0 on >= 1,024 pixels: the input gradient on the matrix cores
+                                  # (csrc/offset_conv_mfma.hip): 4-row tiles, ragged tiles, 8-row tiles
+                                  (2, 64, 6, 32, 32), (1, 32, 6, 40, 72), (8, 32, 6, 128, 128), (1, 96, 8, 36, 33)])
 @pytest.mark.parametrize("native_wgrad", [False, True])
 def test_conv3x3_small_vs_conv2d(case, native_wgrad, monkeypatch):
     """conv3x3_small == F.conv2d(x, w, b, padding=1) evaluated on CPU: output and all three gradients
@@ -675,6 +678,16 @@ def test_conv3x3_small_vs_conv2d(case, native_wgrad, monkeypatch):
     close(bg.grad, br.grad, 1e-4, 1e-3, "d bias")
     # no bias
     close(conv3x3_small(x.to(DEV), w.to(DEV)), F.conv2d(x, w, None, padding=1), 1e-4, 1e-4, "no bias")
+    # a gradient another consumer of x parked in the hand-over slot is added in the same pass, in place
+    if W % 4 == 0:
+        slot = c3.grad_slot()
+        if slot is not None:
+            xs = x.to(DEV).requires_grad_()
+            out2 = conv3x3_small(xs, wg.detach(), bg.detach(), slot)
+            parked = torch.randn(x.shape, generator=gen).to(DEV)
+            slot.grad = parked.clone()
+            out2.backward(g.to(DEV))
+            close(xs.grad, xr.grad + parked.cpu(), 1e-4, 1e-4, "d input + parked gradient")
 
 
 @pytest.mark.parametrize("case", [(2, 6, 64, 4, "cb"), (1, 3, 96, 8, "bc"), (2, 4, 4096, 4, "cb"), (1, 2, 60, 3, "bc"),
