@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 8
+#define MMU_ABI_VERSION 9
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -529,10 +529,13 @@ int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream);
 typedef struct {
     int32_t rows, inner, tokens, batch, transposed_weight;
     const float *weight;  int64_t w_ld;
-    const float *x;       int64_t x_rs, x_bs;
-    float *out;           int64_t out_rs, out_bs;
+    const void *x;        int64_t x_rs, x_bs;
+    void *out;            int64_t out_rs, out_bs;
     void *workspace;
     int32_t accumulate;   /* ABI 6: non-zero: out += W . X (x_proj's input gradient lands on the scan's, selective_scan_interface.py:277) */
+    int32_t x_dtype, out_dtype;  /* ABI 9: MMU_DTYPE_F32 (0, a zeroed struct) or both MMU_DTYPE_BF16: bf16 activations
+                                  * under autocast (selective_scan_interface.py:169-171); x / out are then bf16 pointers,
+                                  * strides still in elements, the weight stays float32, accumulation float32 */
 } mmu_gemm_tokens_params;
 
 size_t mmu_gemm_tokens_workspace_bytes(int rows, int inner);

@@ -142,7 +142,8 @@ class AdamWParams(ctypes.Structure):
 class GemmTokensParams(ctypes.Structure):
     _fields_ = [("rows", _i32), ("inner", _i32), ("tokens", _i32), ("batch", _i32), ("transposed_weight", _i32),
                 ("weight", _vp), ("w_ld", _i64), ("x", _vp), ("x_rs", _i64), ("x_bs", _i64),
-                ("out", _vp), ("out_rs", _i64), ("out_bs", _i64), ("workspace", _vp), ("accumulate", _i32)]
+                ("out", _vp), ("out_rs", _i64), ("out_bs", _i64), ("workspace", _vp), ("accumulate", _i32),
+                ("x_dtype", _i32), ("out_dtype", _i32)]
 
 
 class DtProjParams(ctypes.Structure):
@@ -256,7 +257,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 8   # = MMU_ABI_VERSION of include/mmunet_amd.h
+ABI_VERSION = 9   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():

@@ -104,14 +104,18 @@ __global__ __launch_bounds__(256) void gemm_tokens_prep_batch_kernel(const long 
 }
 
 struct GemmArgs {
-    const float *x;
+    const void *x;            // float, or bf16_t for the XB instantiation of the 512-token kernel
     const unsigned short *wp;
-    float *out;
+    void *out;                // same type as x
     long x_rs, x_bs, o_rs, o_bs;
     int M, K, T, B, tiles_t, n_mt, total_tiles;   // M, K: padded to 64 / 16
     int Mv, Kv, acc;                              // the matrix' own rows / inner size; acc: out += W . X
 };
 
+// XB: X and out are bfloat16 (activations under autocast): a bf16 value IS its own hi part, so the producers pack
+// the loaded halves straight into the [token][8 k] image (v_perm_b32, no split), there is no lo image of X and a product
+// is two MFMAs (W lo x X, W hi x X); the result is rounded to bf16 where it is stored.
+template <bool XB>
 __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -141,18 +145,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
         // data: GEMM columns are independent and those outputs are never stored.
         const int ptid = tid - 256;
         const int half = (wv - 4) >> 1, grp = ptid & 127;   // wave-uniform: the row offset of the loads is scalar
-        v4u px[3][8], wr[3];
+        v4u px[3][8], wr[3];   // (XB: only .x / .y of a px entry are loaded -- four bf16 tokens)
         int l_tj = 0, l_ch = 0, l_b, l_mt, l_t0;
         decode(0, l_b, l_mt, l_t0);
+        constexpr unsigned ES = XB ? 2u : 4u;   // bytes per X element
         auto load = [&](v4u(&dst)[8], v4u &wdst) {
-            const rsrc_t rs = make_rsrc(p.x + (long)l_b * p.x_bs);
+            const rsrc_t rs = make_rsrc((const char *)p.x + (long)l_b * p.x_bs * ES);
             const int tok = l_t0 + 4 * grp;
-            const unsigned voff = (unsigned)(tok < p.T ? tok : 0) * 4u;
+            const unsigned voff = (unsigned)(tok < p.T ? tok : 0) * ES;
             const unsigned row0 = (unsigned)(l_ch * CK + half * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {   // rows past the matrix (inner padded to 16): a valid row again, its weights are zero
                 const unsigned rj = row0 + j < (unsigned)p.Kv ? row0 + j : (unsigned)p.Kv - 1u;
-                dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, rj * (unsigned)p.x_rs * 4u, 0);
+                if constexpr (XB) {
+                    typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+                    const v2u_ t2 = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, rj * (unsigned)p.x_rs * ES, 0);
+                    dst[j].x = t2.x;
+                    dst[j].y = t2.y;
+                } else {
+                    dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, rj * (unsigned)p.x_rs * ES, 0);
+                }
             }
             wdst = reinterpret_cast<const v4u *>(p.wp + ((long)l_mt * nch + l_ch) * (2 * 2 * 64 * 8))[ptid];
             if (l_ch + 1 < nch) {
@@ -167,13 +179,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 unsigned hw[4], lw[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    split2(__uint_as_float(src[2 * j][i]), __uint_as_float(src[2 * j + 1][i]), hw[j], lw[j]);
-                const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
                 const int off = (half * TT + 4 * grp + i) * 16;
-                *reinterpret_cast<v4u *>(buf + off) = h;
-                *reinterpret_cast<v4u *>(buf + XIMG + off) = l;
+                if constexpr (XB) {
+                    // token i of rows 2j, 2j+1: the low (i even) or high (i odd) halves of word i >> 1, packed (k even | k odd << 16)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        hw[j] = __builtin_amdgcn_perm(src[2 * j + 1][i >> 1], src[2 * j][i >> 1], (i & 1) ? 0x07060302u : 0x05040100u);
+                    const v4u h = {hw[0], hw[1], hw[2], hw[3]};
+                    *reinterpret_cast<v4u *>(buf + off) = h;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        split2(__uint_as_float(src[2 * j][i]), __uint_as_float(src[2 * j + 1][i]), hw[j], lw[j]);
+                    const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+                    *reinterpret_cast<v4u *>(buf + off) = h;
+                    *reinterpret_cast<v4u *>(buf + XIMG + off) = l;
+                }
             }
             *reinterpret_cast<v4u *>(buf + 2 * XIMG + ptid * 16) = wsrc;   // 256 x 16 B = hi and lo images of W
         };
@@ -225,14 +246,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             bh[n] = *reinterpret_cast<const bf16x8 *>(cur + n * (32 * 16) + b_lane);
-            bl[n] = *reinterpret_cast<const bf16x8 *>(cur + XIMG + n * (32 * 16) + b_lane);
+            if constexpr (!XB) bl[n] = *reinterpret_cast<const bf16x8 *>(cur + XIMG + n * (32 * 16) + b_lane);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                if constexpr (!XB) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
             }
         if (++c_ch == nch) {
@@ -245,7 +266,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tokens_mfma_kernel(GemmArgs p) {
                     const int tok = t0 + wv * 128 + n * 32 + (lane & 31);
                     if (tok < p.T) {
                         const int r0 = mt * 64 + m * 32 + 4 * (lane >> 5);
-                        float *op = p.out + (long)b * p.o_bs + (long)r0 * p.o_rs + tok;
+                        if constexpr (XB) {
+                            bf16_t *ob = (bf16_t *)p.out + (long)b * p.o_bs + (long)r0 * p.o_rs + tok;
+                            float old[16];
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int ro = (e & 3) + 8 * (e >> 2);
+                                old[e] = (p.acc && r0 + ro < p.Mv) ? to_f32(ob[(long)ro * p.o_rs]) : 0.f;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int ro = (e & 3) + 8 * (e >> 2);
+                                if (r0 + ro < p.Mv) ob[(long)ro * p.o_rs] = from_f32<bf16_t>(old[e] + acc[m][n][e]);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+                            continue;
+                        }
+                        float *op = (float *)p.out + (long)b * p.o_bs + (long)r0 * p.o_rs + tok;
                         if (r0 + 28 < p.Mv && !p.acc) {   // all 16 rows of this lane inside the matrix, plain store
 #pragma unroll
                             for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * p.o_rs] = acc[m][n][e];
@@ -306,7 +344,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 4 : 2) void gemm_tokens_small_kernel
     // X through a buffer resource: the row offset of a load is SCALAR ((chunk * 16 + j) rows), the lane's part (its k half
     // and its token) one VGPR that never changes -- as plain pointers every load cost seven vector instructions of 64-bit
     // address arithmetic, two of them quarter-rate multiplies (more issue time than the chunk's twelve MFMAs)
-    const rsrc_t xrs = make_rsrc(p.x + (long)b * p.x_bs);
+    const rsrc_t xrs = make_rsrc((const float *)p.x + (long)b * p.x_bs);
     unsigned xoff[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n)
@@ -413,7 +451,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 4 : 2) void gemm_tokens_small_kernel
         __syncthreads();
         const int tok = tok0 + 32 * n;
         if (tok < p.T) {
-            float *ob = p.out + (long)b * p.o_bs + tok;
+            float *ob = (float *)p.out + (long)b * p.o_bs + tok;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int v = 8 * wv + i;
@@ -460,8 +498,11 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     MMU_CHECK(p->rows > 0 && p->inner > 0, "gemm_tokens_mfma: rows and inner must be positive (got %d, %d)", p->rows, p->inner);
     const int Mp = (p->rows + 63) & ~63, Kp = (p->inner + CK - 1) & ~(CK - 1);
     MMU_CHECK(p->tokens > 0 && p->batch > 0, "gemm_tokens_mfma: empty problem");
-    MMU_CHECK(p->tokens % 4 == 0 && p->x_rs % 4 == 0 && p->x_bs % 4 == 0 && ((uintptr_t)p->x & 15) == 0,
-              "gemm_tokens_mfma: tokens, x_rs, x_bs must be multiples of 4 and x 16-byte aligned");
+    const bool xb = p->x_dtype == MMU_DTYPE_BF16;
+    MMU_CHECK(p->x_dtype == p->out_dtype && (p->x_dtype == MMU_DTYPE_F32 || xb),
+              "gemm_tokens_mfma: x and out both float32 or both bfloat16 (got dtypes %d, %d)", p->x_dtype, p->out_dtype);
+    MMU_CHECK(p->tokens % 4 == 0 && p->x_rs % 4 == 0 && p->x_bs % 4 == 0 && ((uintptr_t)p->x & (xb ? 7 : 15)) == 0,
+              "gemm_tokens_mfma: tokens, x_rs, x_bs must be multiples of 4 and x 16-byte (bfloat16: 8-byte) aligned");
     MMU_CHECK((long)p->inner * p->x_rs * 4 < (1L << 31), "gemm_tokens_mfma: x rows span more than 2 GB");
     MMU_CHECK(p->x && p->out && p->workspace, "gemm_tokens_mfma: x, out, workspace are required");
     MMU_CHECK(((uintptr_t)p->workspace & 15) == 0, "gemm_tokens_mfma: workspace must be 16-byte aligned");
@@ -479,7 +520,7 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
     a.Mv = p->rows; a.Kv = p->inner; a.acc = p->accumulate ? 1 : 0;
     a.tiles_t = (p->tokens + TT - 1) / TT;
     a.n_mt = Mp / 64;
-    if ((long)a.tiles_t * a.n_mt * p->batch < gemm_tokens_small_below()) {   // too few 512-token tiles to fill the chip
+    if (!xb && (long)a.tiles_t * a.n_mt * p->batch < gemm_tokens_small_below()) {   // too few 512-token tiles to fill the chip
         // two token blocks per wave when that still leaves two workgroups per CU
         const long items64 = (long)((p->tokens + 63) / 64) * a.n_mt * p->batch;
         const int nb = items64 >= 2L * mmu_cu_count() && gemm_tokens_small_nb() != 1 ? 2 : 1;
@@ -495,15 +536,20 @@ extern "C" int mmu_gemm_tokens_mfma(const mmu_gemm_tokens_params *p, void *strea
         MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma(small)");
         return 0;
     }
-    static unsigned long long attr_mask = 0;  // per device
-    if (hipError_t e = mmu_set_lds_once(gemm_tokens_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
+    static unsigned long long attr_mask = 0, attr_mask_b = 0;  // per device
+    if (hipError_t e = xb ? mmu_set_lds_once(gemm_tokens_mfma_kernel<true>, LDS_BYTES, attr_mask_b)
+                          : mmu_set_lds_once(gemm_tokens_mfma_kernel<false>, LDS_BYTES, attr_mask);
+        e != hipSuccess)
         return mmu_fail("gemm_tokens_mfma: LDS attribute: %s", hipGetErrorString(e));
     const long total = (long)a.tiles_t * a.n_mt * p->batch;
     MMU_CHECK(total < (1L << 30), "gemm_tokens_mfma: too many tiles");
     a.total_tiles = (int)total;
     const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;   // persistent: one workgroup per CU (register-bound: 2 waves/SIMD)
-    gemm_tokens_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
+    if (xb)
+        gemm_tokens_mfma_kernel<true><<<grid, 512, LDS_BYTES, st>>>(a);
+    else
+        gemm_tokens_mfma_kernel<false><<<grid, 512, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("gemm_tokens_mfma");
     return 0;
 }

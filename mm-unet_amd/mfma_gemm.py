@@ -96,8 +96,8 @@ def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, 
     ``x`` / ``out`` are float32 tensors whose storage holds the strided operands described by the element strides.
     ``prepared``: this weight's image from :class:`prepared_weights` (looked up by address when not given)."""
     _lib.require_gpu(weight, x, out)
-    if weight.dtype != torch.float32 or x.dtype != torch.float32 or out.dtype != torch.float32:
-        raise RuntimeError("gemm_tokens: float32 tensors required")
+    if weight.dtype != torch.float32 or x.dtype not in (torch.float32, torch.bfloat16) or out.dtype != x.dtype:
+        raise RuntimeError("gemm_tokens: a float32 weight and float32 or bfloat16 x / out of one type required")
     if weight.stride(-1) != 1 or weight.dim() != 2:
         raise RuntimeError("gemm_tokens: weight must be a 2-D matrix with unit column stride")
     want = (inner, rows) if transposed_weight else (rows, inner)
@@ -116,6 +116,7 @@ def gemm_tokens(weight, x, out, rows, inner, tokens, batch, x_rs, x_bs, out_rs, 
     p.out, p.out_rs, p.out_bs = out.data_ptr(), out_rs, out_bs
     p.workspace = ws.data_ptr()
     p.accumulate = int(bool(accumulate))   # out += W . X
+    p.x_dtype = p.out_dtype = _lib.dtype_code(x)   # (bf16 activations: the 512-token kernel's XB form, any tile count)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().mmu_gemm_tokens_mfma(p, _lib.stream_of(x)))
     return out
@@ -203,6 +204,17 @@ def x_proj_input_grad_add(weight, dx_dbl, dx):
     _lib.require_gpu(weight, dx_dbl, dx)
     _x_proj_call("mmu_x_proj_bwd", weight, dx, dx_dbl)
     return dx
+
+
+def tokens_lowp_supported(weight, *tensors):
+    """gemm_tokens with bfloat16 activations (csrc/gemm_tokens_mfma.hip, XB form): float32 2-D weight, bf16 operands /
+    results with unit token stride, 8-byte aligned, row / batch strides multiples of 4."""
+    return (ENABLED and LOWP and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_cuda
+            and all(t.is_cuda and t.dtype == torch.bfloat16 and t.data_ptr() % 8 == 0 and t.stride(-1) == 1
+                    and all(st % 4 == 0 for st in t.stride()[:-1]) and t.shape[-1] % 4 == 0 for t in tensors))
+
+
+LOWP = os.environ.get("MMUNET_GEMM_TOKENS_LOWP", "1") != "0"   # "0": bf16 projections stay library GEMMs (A/B)
 
 
 def tokens_supported(*tensors):

@@ -214,6 +214,19 @@ def _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, tokens):
             and mfma_gemm.tokens_supported(conv_m, x_proj_weight, delta_proj_weight))
 
 
+LOWP_PROJ = os.environ.get("MMUNET_LOWP_PROJ", "0") != "0"
+
+
+def _lowp_proj_ok(conv_m, x_proj_weight, delta_proj_weight):
+    """x_proj / dt_proj (and their input gradients) of bf16 activations on gemm_tokens' bf16 form: float32 contiguous
+    weights, a tokens-last bf16 conv matrix with unit token stride.  OFF by default (MMUNET_LOWP_PROJ=1): measured on
+    config 3, the 512-token kernel loses on these skinny products (36 / 4 rows, inner 4: 59.76 ms per step against 58.46
+    with the library) -- they want bf16 forms of csrc/dt_proj.hip's streaming kernels, which do not exist yet."""
+    return (LOWP_PROJ and conv_m.dtype == torch.bfloat16 and conv_m.dim() == 2 and conv_m.shape[1] % 4 == 0
+            and x_proj_weight.is_contiguous() and delta_proj_weight.is_contiguous()
+            and delta_proj_weight.dtype == torch.float32 and mfma_gemm.tokens_lowp_supported(x_proj_weight, conv_m))
+
+
 def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias):
     """delta, B, C from the conv output (selective_scan_interface.py:181-210), computed tokens-last:
     x_dblT = W_x @ conv (r+2N, B*L) -- the transpose of the reference's x_dbl -- so that delta, B and C
@@ -229,7 +242,19 @@ def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj
         x_dblT = torch.empty((x_proj_weight.shape[0], T), device=conv_m.device, dtype=torch.float32)
         mfma_gemm.gemm_tokens(x_proj_weight, conv_m, x_dblT, x_proj_weight.shape[0], dim, T, 1, conv_m.stride(0), 0, T, 0)
         delta = mfma_gemm.dt_proj(delta_proj_weight, x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
+    elif _lowp_proj_ok(conv_m, x_proj_weight, delta_proj_weight):
+        # bf16 activations (autocast), float32 weights: both projections on gemm_tokens' bf16 form -- one launch each
+        # instead of a cast of the weight + a library GEMM; products exact to the weight's 16 bits instead of its 8
+        T = batch * L
+        rows = x_proj_weight.shape[0]
+        x_dblT = torch.empty((rows, T), device=conv_m.device, dtype=torch.bfloat16)
+        mfma_gemm.gemm_tokens(x_proj_weight, conv_m, x_dblT, rows, dim, T, 1, conv_m.stride(0), 0, T, 0)
+        delta_m = torch.empty((dim, T), device=conv_m.device, dtype=torch.bfloat16)
+        mfma_gemm.gemm_tokens(delta_proj_weight, x_dblT[:r], delta_m, dim, r, T, 1, T, 0, T, 0)
+        delta = delta_m.view(dim, batch, L).permute(1, 0, 2)
     else:
+        if x_proj_weight.dtype != conv_m.dtype:      # (a caller that kept its float32 weights for the branch above)
+            x_proj_weight, delta_proj_weight = x_proj_weight.to(conv_m.dtype), delta_proj_weight.to(conv_m.dtype)
         x_dblT = x_proj_weight @ conv_m                                  # (r + 2N, B*L)
         delta = (delta_proj_weight @ x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
     if B is None:
@@ -258,18 +283,30 @@ def _project_backward(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_w
     ddelta_proj_weight = nt_splitk(ddelta_m, x_dblT[:r]).to(delta_proj_weight.dtype)  # (D, r)      (:273)
     conv_m = _dbl_view(conv1d_out)
     dconv_m = _dbl_view(dconv1d_out)                                        # (D, B*L)
-    own = (dconv_m.data_ptr() == dconv1d_out.data_ptr() and direct and dx_dblT.is_contiguous()
+    in_place = dconv_m.data_ptr() == dconv1d_out.data_ptr()
+    own = (in_place and direct and dx_dblT.is_contiguous()
            and _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, batch * L)
            and mfma_gemm.dt_proj_supported(delta_proj_weight, dx_dblT[:r], ddelta_m)
            and mfma_gemm.tokens_supported(dconv_m, dx_dblT) and dconv_m.stride(1) == 1 and dconv_m.stride(0) % 4 == 0)
+    lowp = (not own and in_place and dx_dblT.is_contiguous() and _lowp_proj_ok(conv_m, x_proj_weight, delta_proj_weight)
+            and mfma_gemm.tokens_lowp_supported(x_proj_weight, ddelta_m, dconv_m, dx_dblT))
+    T = batch * L
     if own:
         mfma_gemm.dt_proj_input_grad(delta_proj_weight, ddelta_m, dx_dblT[:r])  # (r, B*L)         (:274)
+    elif lowp:
+        mfma_gemm.gemm_tokens(delta_proj_weight, ddelta_m, dx_dblT[:r], r, dim, T, 1, ddelta_m.stride(0), 0, T, 0,
+                              transposed_weight=True)
     else:
+        if delta_proj_weight.dtype != ddelta_m.dtype:
+            x_proj_weight, delta_proj_weight = x_proj_weight.to(ddelta_m.dtype), delta_proj_weight.to(ddelta_m.dtype)
         torch.matmul(delta_proj_weight.t(), ddelta_m, out=dx_dblT[:r])     # (r, B*L)              (:274)
     dx_proj_weight = nt_splitk(dx_dblT, conv_m).to(x_proj_weight.dtype)    # (r+2N, D)             (:276)
     if own:
         mfma_gemm.x_proj_input_grad_add(x_proj_weight, dx_dblT, dconv_m)   # d conv += W_x^T d x_dbl, in place   (:277)
-    elif dconv_m.data_ptr() == dconv1d_out.data_ptr():
+    elif lowp:
+        mfma_gemm.gemm_tokens(x_proj_weight, dx_dblT, dconv_m, dim, x_proj_weight.shape[0], T, 1, T, 0, dconv_m.stride(0), 0,
+                              transposed_weight=True, accumulate=True)
+    elif in_place:
         dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
     else:  # dconv1d_out was not [D][B][L]; keep it correct anyway
         dconv_m = torch.addmm(dconv_m, x_proj_weight.t(), dx_dblT)

@@ -222,24 +222,32 @@ class _ProjBclFn(torch.autograd.Function):
 
 
 class _ProjBclLowpFn(torch.autograd.Function):
-    """``_ProjBclFn`` for bfloat16 activations (autocast): the same two layouts and no transposing copies -- each batch
-    item is one library GEMM whose strided operand / result is addressed in place -- with bf16 operands and float32
-    accumulation; the weight gradient is the split-K product over all tokens, summed in float32."""
+    """``_ProjBclFn`` for bfloat16 activations (autocast): the same two layouts and no transposing copies, bf16 operands
+    and results, float32 accumulation.  Round 4: ONE launch of ``gemm_tokens``' bf16 form over all batch items with the
+    FLOAT32 weight (its two-part image: products exact to 16 bits of the weight, where a weight cast to bf16 keeps 8) --
+    before: a cast of the weight and one library GEMM per batch item.  The weight gradient is the split-K product over
+    all tokens, summed in float32."""
 
     @staticmethod
     def forward(ctx, W, X, to_cb):
         with torch.autocast("cuda", enabled=False):
             B, I, L = X.shape
             O = W.shape[0]
-            Wc, Xc = W.to(torch.bfloat16), X.to(torch.bfloat16)
+            Xc = X.to(torch.bfloat16)
             if to_cb:
                 out = torch.empty((O, B, L), device=X.device, dtype=torch.bfloat16).permute(1, 0, 2)   # [O][B][L]
             else:
                 out = torch.empty((B, O, L), device=X.device, dtype=torch.bfloat16)
-            for b in range(B):
-                torch.mm(Wc, Xc[b], out=out[b])
+            own = W.is_contiguous() and mfma_gemm.tokens_lowp_supported(W, Xc, out)
+            if own:
+                mfma_gemm.gemm_tokens(W, Xc, out, O, I, L, B, Xc.stride(1), Xc.stride(0), out.stride(1), out.stride(0))
+                Wc = W
+            else:
+                Wc = W.to(torch.bfloat16)
+                for b in range(B):
+                    torch.mm(Wc, Xc[b], out=out[b])
         ctx.save_for_backward(Wc, Xc)
-        ctx.to_cb, ctx.w_dtype, ctx.x_dtype = to_cb, W.dtype, X.dtype
+        ctx.to_cb, ctx.w_dtype, ctx.x_dtype, ctx.own = to_cb, W.dtype, X.dtype, own
         return out
 
     @staticmethod
@@ -254,9 +262,13 @@ class _ProjBclLowpFn(torch.autograd.Function):
                     dX = torch.empty((B, I, L), device=G.device, dtype=torch.bfloat16)
                 else:
                     dX = torch.empty((I, B, L), device=G.device, dtype=torch.bfloat16).permute(1, 0, 2)
-                Wt = Wc.t()
-                for b in range(B):
-                    torch.mm(Wt, G[b], out=dX[b])
+                if ctx.own and G.stride(2) == 1 and mfma_gemm.tokens_lowp_supported(Wc, G, dX):
+                    mfma_gemm.gemm_tokens(Wc, G, dX, I, Wc.shape[0], L, B, G.stride(1), G.stride(0), dX.stride(1),
+                                          dX.stride(0), transposed_weight=True)
+                else:
+                    Wt = Wc.to(torch.bfloat16).t()
+                    for b in range(B):
+                        torch.mm(Wt, G[b], out=dX[b])
                 dX = dX.to(ctx.x_dtype)
             if ctx.needs_input_grad[0]:
                 dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(Xc)).to(ctx.w_dtype)

@@ -142,8 +142,8 @@ class TriMambaInnerFn(torch.autograd.Function):
         assert len(params) == 3 * N_PER_DIR
         dirs = [params[k * N_PER_DIR:(k + 1) * N_PER_DIR] for k in range(3)]
         ctx.proj_dtypes = [(d[2].dtype, d[3].dtype) for d in dirs]
-        if xz.dtype != torch.float32:    # bf16 activations: x_proj / dt_proj in bf16 too (selective_scan_interface.py:169-171)
-            dirs = [(d[0], d[1], d[2].to(xz.dtype), d[3].to(xz.dtype)) + tuple(d[4:]) for d in dirs]
+        # (bf16 activations: _project takes the float32 x_proj / dt_proj weights on gemm_tokens' bf16 form, or casts them
+        #  to bf16 for the library as selective_scan_interface.py:169-171 does)
         B, C2, L = xz.shape
         D_in = C2 // 2
         x, z = xz.chunk(2, dim=1)

@@ -952,6 +952,32 @@ def test_gemm_tokens_mfma_vs_fp64(case):
     close(out, ref.float(), 5e-5, 5e-5, "W @ X")   # three bf16 products per term: ~2^-16 relative each
 
 
+@pytest.mark.parametrize("case", [(64, 48, 700, 3, False), (256, 64, 4096, 2, False), (64, 128, 33000, 1, True),
+                                  (36, 128, 5000, 1, False), (128, 36, 2048, 1, True), (128, 4, 1024, 2, False)])
+def test_gemm_tokens_bfloat16_activations_vs_fp64(case):
+    """gemm_tokens with bfloat16 X / out (the 512-token kernel's XB form: a bf16 value is its own hi part, two MFMAs per
+    product, float32 accumulation, bf16 rounding at the store) == W @ X[b] in float64 on the SAME bf16 inputs."""
+    from mm_unet_amd.mfma_gemm import gemm_tokens
+    M, K, T, B, trans = case
+    gen = torch.Generator().manual_seed(M + K + T)
+    W = torch.randn(M, K, generator=gen) / K ** 0.5
+    X = torch.randn(K, B * T, generator=gen).to(torch.bfloat16)
+    ref = torch.stack([W.double() @ X[:, b * T:(b + 1) * T].double() for b in range(B)])      # (B, M, T)
+    Wd = (W.t().contiguous() if trans else W).to(DEV)
+    out = torch.full((B, M + 3, T), float("nan"), device=DEV, dtype=torch.bfloat16)          # guard rows behind each item
+    gemm_tokens(Wd, X.to(DEV), out, M, K, T, B, B * T, T, T, (M + 3) * T, transposed_weight=trans)
+    got = out[:, :M].float().cpu()
+    assert torch.isnan(out[:, M:].float()).all(), "rows past the matrix were written"
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert err < 6e-3, err
+    # accumulate: out += W . X in bf16
+    base = torch.randn(B, M, T, generator=gen).to(torch.bfloat16)
+    acc = base.clone().to(DEV)
+    gemm_tokens(Wd, X.to(DEV), acc, M, K, T, B, B * T, T, T, M * T, transposed_weight=trans, accumulate=True)
+    err = float((acc.float().cpu().double() - (ref + base.double())).abs().max() / ref.abs().max())
+    assert err < 1.2e-2, err
+
+
 def test_gemm_tokens_accumulates_and_leaves_masked_rows_alone():
     """accumulate=True: out += W^T . X on the rows of the matrix only (x_proj's input gradient added onto the scan's,
     selective_scan_interface.py:277); the padding rows of the 64-row tile are never written."""
