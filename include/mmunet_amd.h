@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 9
+#define MMU_ABI_VERSION 10
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -458,11 +458,14 @@ int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream);
  * workspace: mmu_conv3x3_mfma_workspace_bytes() bytes (prepared bf16 weights), 16-byte aligned. */
 typedef struct {
     int32_t batch, in_channels, out_channels, height, width, transposed;
-    const float *input;
+    const void *input;      /* io_dtype; for mmu_conv3x3_wgrad_mfma float32 */
     const float *weight;
     const float *bias;      /* [out_channels] or NULL */
-    float *out;
+    void *out;              /* io_dtype */
     void *workspace;
+    int32_t io_dtype;       /* ABI 10, mmu_conv3x3_mfma only: MMU_DTYPE_F32 (0, a zeroed struct) or MMU_DTYPE_BF16 -- bf16
+                             * activations under autocast: input and out bfloat16, weight and bias float32, two MFMAs per
+                             * product (a bf16 value is its own hi part), float32 accumulation */
 } mmu_conv3x3_mfma_params;
 
 size_t mmu_conv3x3_mfma_workspace_bytes(int in_channels, int out_channels);

@@ -125,7 +125,7 @@ class NormParams(ctypes.Structure):
 
 class Conv3x3MfmaParams(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "in_channels", "out_channels", "height", "width", "transposed")]
-                + [(n, _vp) for n in ("input", "weight", "bias", "out", "workspace")])
+                + [(n, _vp) for n in ("input", "weight", "bias", "out", "workspace")] + [("io_dtype", _i32)])
 
 
 class MorphMixParams(ctypes.Structure):
@@ -257,7 +257,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 9   # = MMU_ABI_VERSION of include/mmunet_amd.h
+ABI_VERSION = 10   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():

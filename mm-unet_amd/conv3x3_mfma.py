@@ -19,20 +19,31 @@ from . import _lib, conv_s2, deferred
 ENABLED = os.environ.get("MMUNET_CONV3X3_MFMA", "1") != "0"
 
 
+LOWP = os.environ.get("MMUNET_CONV3X3_MFMA_LOWP", "1") != "0"   # "0": under bf16 autocast the module call (MIOpen) stays
+
+
+def _lowp(x):
+    """bf16 activations under bf16 autocast: the kernel's XB form (bf16 in / out, float32 weights, two MFMAs per product)."""
+    return (LOWP and x.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
 def supported(x, weight):
-    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+    return (ENABLED and x.is_cuda and weight.dtype == torch.float32 and x.dim() == 4
             and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] == x.shape[1] and weight.shape[1] % 16 == 0
-            and weight.shape[0] % 64 == 0 and x.shape[3] % 4 == 0 and not torch.is_autocast_enabled())
+            and weight.shape[0] % 64 == 0 and x.shape[3] % 4 == 0
+            and ((x.dtype == torch.float32 and not torch.is_autocast_enabled()) or _lowp(x)))
 
 
 def _run(inp, weight, bias, cin, cout, transposed):
     B, _, H, W = inp.shape
-    out = torch.empty((B, cout, H, W), device=inp.device, dtype=torch.float32)
+    out = torch.empty((B, cout, H, W), device=inp.device, dtype=inp.dtype)
     ws = torch.empty(_lib.lib().mmu_conv3x3_mfma_workspace_bytes(cin, cout), device=inp.device, dtype=torch.uint8)
     p = _lib.Conv3x3MfmaParams()
     p.batch, p.in_channels, p.out_channels, p.height, p.width, p.transposed = B, cin, cout, H, W, int(transposed)
     p.input, p.weight, p.bias, p.out, p.workspace = inp.data_ptr(), weight.data_ptr(), _lib.ptr(bias), out.data_ptr(), \
         ws.data_ptr()
+    p.io_dtype = _lib.dtype_code(inp)
     with torch.cuda.device(inp.device):
         _lib.check(_lib.lib().mmu_conv3x3_mfma(p, _lib.stream_of(inp)))
     return out
@@ -75,12 +86,30 @@ class Conv3x3MfmaFn(torch.autograd.Function):
         out = _run(x, weight, bias, weight.shape[1], weight.shape[0], False)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.lowp = x.dtype != torch.float32
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, weight = ctx.saved_tensors
         cout, cin = weight.shape[0], weight.shape[1]
+        if ctx.lowp:   # bf16 activations: the input gradient on the kernel's bf16 form, the weight gradient in the library
+            g = dout.to(torch.bfloat16).contiguous()
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                if cin % 64 == 0 and cout % 16 == 0:
+                    dx = _run(g, weight, None, cout, cin, True)
+                else:
+                    dx = torch.ops.aten.convolution_backward(g, x, weight.to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
+                                                             False, [0, 0], 1, [True, False, False])[0]
+            need_b = ctx.has_bias and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1] or need_b:
+                _, dw, db = torch.ops.aten.convolution_backward(
+                    g, x, weight.to(torch.bfloat16), [cout] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                    [False, bool(ctx.needs_input_grad[1]), bool(need_b)])
+                dw = dw.float() if dw is not None else None
+                db = db.float() if db is not None else None
+            return dx, dw, db
         g = dout.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:

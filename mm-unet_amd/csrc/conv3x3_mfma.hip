@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_prep_kernel(const float *__r
 }
 
 struct ConvArgsM {
-    const float *x;
+    const void *x;            // float, or bf16_t in the XB instantiation
     const unsigned short *wp;
     const float *bias;
-    float *out;
+    void *out;                // same type as x
     int B, Cin, Cout, H, W, tiles_x, tiles_y, ncot, total_tiles;
 };
 
@@ -82,6 +82,9 @@ struct ConvArgsM {
 // so a tile's first loads, its staging and the previous tile's output stores all sit under MFMAs.  (One workgroup
 // per launch slot instead: every tile exposed a memory latency + staging + 64 stores per lane -- 32 % MFMA
 // utilisation at 64 -> 64 channels, where a tile has only 4 chunks.)
+// XB: input and output are bfloat16 (activations under autocast): a bf16 value is its own hi part -- the staged patch
+// has no lo image, a product is two MFMAs (W lo x X, W hi x X), the result is rounded to bf16 where it is stored.
+template <bool XB>
 __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
     };
 
     // ---- load stream (two chunks ahead of the MFMAs)
-    float px[3][8], pmask[3];
+    unsigned px[3][8], pmask[3];   // raw bits of the loaded values (converted where they are staged); 0 / ~0 masks
     v4u wr[5];
     int l_tj = 0, l_ch = 0, l_b, l_cot, l_y0, l_x0;
     decode(0, l_b, l_cot, l_y0, l_x0);
@@ -131,10 +134,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
         for (int k = 0; k < 3; ++k) {
             const int gy = l_y0 - 1 + ipr[k], gx = l_x0 - 1 + ipc[k];
             const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            pmask[k] = inb ? 1.f : 0.f;
-            const float *s = p.x + ((long)l_b * p.Cin + l_ch * CK + 8 * ihalf[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
+            pmask[k] = inb ? 0xffffffffu : 0u;
+            const long off = ((long)l_b * p.Cin + l_ch * CK + 8 * ihalf[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
+            if constexpr (XB) {
+                const unsigned short *s = (const unsigned short *)p.x + off;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) px[k][j] = s[j * HW];
+                for (int j = 0; j < 8; ++j) px[k][j] = s[j * HW];
+            } else {
+                const unsigned *s = (const unsigned *)p.x + off;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) px[k][j] = s[j * HW];
+            }
         }
         const v4u *ws = reinterpret_cast<const v4u *>(p.wp + ((long)l_cot * nch + l_ch) * (2 * 9 * 64 * 16));
 #pragma unroll
@@ -156,12 +166,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             unsigned hw[4], lw[4];
+            if constexpr (XB) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split2(px[k][2 * j] * pmask[k], px[k][2 * j + 1] * pmask[k], hw[j], lw[j]);
-            const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
-            if (ioff[k] >= 0) {
-                *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
-                *reinterpret_cast<v4u *>(patch_lo + ioff[k]) = l;
+                for (int j = 0; j < 4; ++j) hw[j] = (px[k][2 * j] | (px[k][2 * j + 1] << 16)) & pmask[k];
+                const v4u h = {hw[0], hw[1], hw[2], hw[3]};
+                if (ioff[k] >= 0) *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    split2(__uint_as_float(px[k][2 * j] & pmask[k]), __uint_as_float(px[k][2 * j + 1] & pmask[k]), hw[j], lw[j]);
+                const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+                if (ioff[k] >= 0) {
+                    *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
+                    *reinterpret_cast<v4u *>(patch_lo + ioff[k]) = l;
+                }
             }
         }
 #pragma unroll
@@ -223,14 +241,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
             for (int n = 0; n < 2; ++n) {
                 const int off = ((wv + kh) * PW + n * 32 + kw) * 16 + b_lane;
                 bh[n] = *reinterpret_cast<const bf16x8 *>(patch_hi + off);
-                bl[n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
+                if constexpr (!XB) bl[n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                    if constexpr (!XB) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
                 }
         }
@@ -264,9 +282,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
                 for (int n = 0; n < 2; ++n) {
                     const int ox = x0 + n * 32 + (lane & 31);
                     if (oy < p.H && ox < p.W) {
-                        float *op = p.out + ((long)b * p.Cout + cot * 64 + m * 32 + 4 * (lane >> 5)) * HW + (long)oy * p.W + ox;
+                        const long o0 = ((long)b * p.Cout + cot * 64 + m * 32 + 4 * (lane >> 5)) * HW + (long)oy * p.W + ox;
+                        if constexpr (XB) {
+                            bf16_t *op = (bf16_t *)p.out + o0;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * HW] = acc[m][n][e] + bv[m][e];
+                            for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * HW] = from_f32<bf16_t>(acc[m][n][e] + bv[m][e]);
+                        } else {
+                            float *op = (float *)p.out + o0;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * HW] = acc[m][n][e] + bv[m][e];
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
@@ -295,13 +320,17 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     MMU_CHECK(p->input && p->weight && p->out && p->workspace, "conv3x3_mfma: input, weight, out, workspace are required");
     MMU_CHECK(((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->workspace & 15) == 0,
               "conv3x3_mfma: input and workspace must be 16-byte aligned");
+    const bool xb = p->io_dtype == MMU_DTYPE_BF16;
+    MMU_CHECK(xb || p->io_dtype == MMU_DTYPE_F32, "conv3x3_mfma: io_dtype must be float32 or bfloat16 (got %d)", p->io_dtype);
     hipStream_t st = (hipStream_t)stream;
     const long nw = (long)p->in_channels * p->out_channels * 9;
     conv3x3_mfma_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(
         p->weight, (unsigned short *)p->workspace, p->in_channels, p->out_channels, p->transposed ? 1 : 0);
     MMU_HIP_LAUNCH_CHECK("conv3x3_mfma(prep)");
-    static unsigned long long attr_mask = 0;  // per device
-    if (hipError_t e = mmu_set_lds_once(conv3x3_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
+    static unsigned long long attr_mask = 0, attr_mask_b = 0;  // per device
+    if (hipError_t e = xb ? mmu_set_lds_once(conv3x3_mfma_kernel<true>, LDS_BYTES, attr_mask_b)
+                          : mmu_set_lds_once(conv3x3_mfma_kernel<false>, LDS_BYTES, attr_mask);
+        e != hipSuccess)
         return mmu_fail("conv3x3_mfma: LDS attribute: %s", hipGetErrorString(e));
     ConvArgsM a;
     a.x = p->input; a.wp = (const unsigned short *)p->workspace; a.bias = p->bias; a.out = p->out;
@@ -314,7 +343,10 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     a.total_tiles = (int)total;
     const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;   // one workgroup (158 KB of LDS) per CU
-    conv3x3_mfma_kernel<<<grid, 512, LDS_BYTES, st>>>(a);
+    if (xb)
+        conv3x3_mfma_kernel<true><<<grid, 512, LDS_BYTES, st>>>(a);
+    else
+        conv3x3_mfma_kernel<false><<<grid, 512, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("conv3x3_mfma");
     return 0;
 }

@@ -256,7 +256,7 @@ extern "C" int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *st
     if (hipError_t e = mmu_set_lds_once(conv3x3_wgrad_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
         return mmu_fail("conv3x3_wgrad_mfma: LDS attribute: %s", hipGetErrorString(e));
     WgArgs a;
-    a.x = p->input; a.g = p->weight; a.ws = (float *)p->workspace;
+    a.x = (const float *)p->input; a.g = p->weight; a.ws = (float *)p->workspace;
     a.B = p->batch; a.Cin = p->in_channels; a.Cout = p->out_channels; a.H = p->height; a.W = p->width;
     a.tiles_x = (p->width + TW - 1) / TW; a.tiles_y = (p->height + TH - 1) / TH;
     a.n_cic = p->in_channels / CI; a.n_cot = p->out_channels / CO;
@@ -270,7 +270,7 @@ extern "C" int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *st
                              a.wg_per_cc, (long)CO | ((long)CI << 32)};
         if (mmu_defer_job(job)) return 0;
     }
-    conv3x3_wgrad_sum_kernel<<<(unsigned)((n + 15) / 16), 256, 0, st>>>(a.ws, p->out, p->in_channels, p->out_channels,
+    conv3x3_wgrad_sum_kernel<<<(unsigned)((n + 15) / 16), 256, 0, st>>>(a.ws, (float *)p->out, p->in_channels, p->out_channels,
                                                                          a.n_cic, a.wg_per_cc);
     MMU_HIP_LAUNCH_CHECK("conv3x3_wgrad_mfma(sum)");
     return 0;

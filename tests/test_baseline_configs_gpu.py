@@ -121,8 +121,13 @@ def test_config3_bf16_autocast_train_step_bs16_512():
     assert all(torch.isfinite(g).all() for g in grads.values())
     assert sum(g.numel() for g in grads.values()) == 9562699  # the live set of BASELINE.md (38.25 MB fp32)
     step.optimizer.step()
-    moved = sum(int((p.detach() != before[k]).any()) for k, p in m.named_parameters() if k in grads)
-    assert moved == len(grads)
+    # every live parameter moves -- except a convolution bias in front of a BatchNorm: its gradient is analytically zero
+    # (BatchNorm removes any per-channel shift).  Since round 4 CBAM's 3 x 3 convolutions run on conv3x3_mfma's bf16 form
+    # with the bias folded into the fused normalisation, and that gradient comes out as ~1e-21 instead of the library
+    # route's bf16 noise of ~1e-5: AdamW leaves such a parameter where it is.
+    still = [k for k, p in m.named_parameters() if k in grads and not (p.detach() != before[k]).any()]
+    assert all(k.endswith(".bias") and float(grads[k].abs().max()) < 1e-12 for k in still), still
+    assert len(still) <= 2, still
 
 
 def test_config5_dstate64_vs_oracle_and_1024_bf16_step():

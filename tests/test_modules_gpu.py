@@ -952,6 +952,36 @@ def test_gemm_tokens_mfma_vs_fp64(case):
     close(out, ref.float(), 5e-5, 5e-5, "W @ X")   # three bf16 products per term: ~2^-16 relative each
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 24, 36), (1, 32, 128, 17, 64), (2, 64, 128, 40, 132)])
+def test_conv3x3_mfma_bfloat16_activations_vs_fp64(case):
+    """conv3x3_mfma under bf16 autocast (the kernel's XB form: bf16 input / output, float32 weights): output and input
+    gradient against float64 F.conv2d on the SAME bf16 inputs, within bf16 rounding of the results; the weight gradient
+    (library, bf16) within bf16 accuracy."""
+    import torch.nn.functional as F
+    from mm_unet_amd.conv3x3_mfma import conv3x3_mfma, supported
+    B, Cin, Cout, H, W = case
+    gen = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=gen)
+    g = torch.randn(B, Cout, H, W, generator=gen).to(torch.bfloat16)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    ref = F.conv2d(xr, wr, b.double(), padding=1)
+    ref.backward(g.double())
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert supported(xg, wg)
+        out = conv3x3_mfma(xg, wg, bg)
+    assert out.dtype == torch.bfloat16
+    out.backward(g.to(DEV))
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / r.abs().max())   # noqa: E731
+    assert rel(out, ref.detach()) < 6e-3, rel(out, ref.detach())
+    if Cin % 64 == 0:
+        assert xg.grad.dtype == torch.bfloat16
+    assert rel(xg.grad, xr.grad) < 8e-3, rel(xg.grad, xr.grad)
+    assert rel(wg.grad, wr.grad) < 2e-2 and wg.grad.dtype == torch.float32
+
+
 @pytest.mark.parametrize("case", [(64, 48, 700, 3, False), (256, 64, 4096, 2, False), (64, 128, 33000, 1, True),
                                   (36, 128, 5000, 1, False), (128, 36, 2048, 1, True), (128, 4, 1024, 2, False)])
 def test_gemm_tokens_bfloat16_activations_vs_fp64(case):
