@@ -458,14 +458,15 @@ int mmu_norm_fused_bwd(const mmu_norm_params *p, void *stream);
  * workspace: mmu_conv3x3_mfma_workspace_bytes() bytes (prepared bf16 weights), 16-byte aligned. */
 typedef struct {
     int32_t batch, in_channels, out_channels, height, width, transposed;
-    const void *input;      /* io_dtype; for mmu_conv3x3_wgrad_mfma float32 */
+    const void *input;      /* io_dtype */
     const float *weight;
     const float *bias;      /* [out_channels] or NULL */
     void *out;              /* io_dtype */
     void *workspace;
-    int32_t io_dtype;       /* ABI 10, mmu_conv3x3_mfma only: MMU_DTYPE_F32 (0, a zeroed struct) or MMU_DTYPE_BF16 -- bf16
-                             * activations under autocast: input and out bfloat16, weight and bias float32, two MFMAs per
-                             * product (a bf16 value is its own hi part), float32 accumulation */
+    int32_t io_dtype;       /* ABI 10: MMU_DTYPE_F32 (0, a zeroed struct) or MMU_DTYPE_BF16 -- bf16 activations under
+                             * autocast: input and out bfloat16, weight and bias float32, two MFMAs per product (a bf16
+                             * value is its own hi part), float32 accumulation.  mmu_conv3x3_wgrad_mfma: x AND dout
+                             * bfloat16 (dout 8-byte aligned), one MFMA per product, dweight float32 */
 } mmu_conv3x3_mfma_params;
 
 size_t mmu_conv3x3_mfma_workspace_bytes(int in_channels, int out_channels);

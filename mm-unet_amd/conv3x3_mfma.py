@@ -49,6 +49,7 @@ def _run(inp, weight, bias, cin, cout, transposed):
     return out
 
 
+LOWP_WGRAD = os.environ.get("MMUNET_CONV3X3_WGRAD_LOWP", "1") != "0"   # "0": bf16 weight gradients from the library
 WGRAD_MFMA = True   # False: the weight gradient comes from ATen / MIOpen (tests compare the two)
 
 
@@ -66,6 +67,7 @@ def _wgrad(x, g, cout):
     p = _lib.Conv3x3MfmaParams()
     p.batch, p.in_channels, p.out_channels, p.height, p.width, p.transposed = B, cin, cout, H, W, 0
     p.input, p.weight, p.out, p.workspace = x.data_ptr(), g.data_ptr(), dw.data_ptr(), ws.data_ptr()
+    p.io_dtype = _lib.dtype_code(x)      # bf16: x and g are exact bf16 values, one MFMA per product; dW stays float32
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().mmu_conv3x3_wgrad_mfma(p, _lib.stream_of(x)))
     deferred.keep(ws)    # (inside a deferred.Scope the sum over the workgroups' partials runs later)
@@ -93,7 +95,7 @@ class Conv3x3MfmaFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight = ctx.saved_tensors
         cout, cin = weight.shape[0], weight.shape[1]
-        if ctx.lowp:   # bf16 activations: the input gradient on the kernel's bf16 form, the weight gradient in the library
+        if ctx.lowp:   # bf16 activations: input and weight gradient on the kernels' bf16 forms
             g = dout.to(torch.bfloat16).contiguous()
             dx = dw = db = None
             if ctx.needs_input_grad[0]:
@@ -103,7 +105,10 @@ class Conv3x3MfmaFn(torch.autograd.Function):
                     dx = torch.ops.aten.convolution_backward(g, x, weight.to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
                                                              False, [0, 0], 1, [True, False, False])[0]
             need_b = ctx.has_bias and ctx.needs_input_grad[2]
-            if ctx.needs_input_grad[1] or need_b:
+            if ctx.needs_input_grad[1] and LOWP_WGRAD and wgrad_supported(x, cout) and g.data_ptr() % 8 == 0:
+                dw = _wgrad(x, g, cout)
+                db = g.sum(dim=(0, 2, 3), dtype=torch.float32) if need_b else None
+            elif ctx.needs_input_grad[1] or need_b:
                 _, dw, db = torch.ops.aten.convolution_backward(
                     g, x, weight.to(torch.bfloat16), [cout] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                     [False, bool(ctx.needs_input_grad[1]), bool(need_b)])

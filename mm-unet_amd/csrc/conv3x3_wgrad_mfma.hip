@@ -45,12 +45,15 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 }
 
 struct WgArgs {
-    const float *x, *g;
+    const void *x, *g;        // float32, or (XB) bfloat16: both operands are then exact bf16 values -- one MFMA per product
     float *ws;
     int B, Cin, Cout, H, W, tiles_x, tiles_y, n_cic, n_cot, wg_per_cc;
 };
 
+template <bool XB>
 __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
+    using px_t = typename std::conditional<XB, unsigned short, float>::type;   // raw activations as loaded
+    using dv_t = typename std::conditional<XB, v2u, float4>::type;            // four dout pixels as loaded
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *patch_hi = lds, *patch_lo = lds + PATCH_IMG;
     unsigned char *dout_hi = lds + 2 * PATCH_IMG, *dout_lo = dout_hi + DOUT_IMG;
@@ -87,8 +90,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
         d_off[k] = live ? d_co[k] * DROW + d_px[k] * 2 : -1;
     }
 
-    float px[3][8], pm[3];
-    float4 dv[8];
+    px_t px[3][8];
+    float pm[3];
+    dv_t dv[8];
     auto prefetch = [&](int t) {
         t = t < ntiles ? t : ntiles - 1;              // past the end: re-read the last tile (nobody stages it)
         const int b = t / tiles_img, r = t - b * tiles_img;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
             const int gy = y0 - 1 + p_pr[k], gx = x0 - 1 + p_pc[k];
             const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             pm[k] = inb ? 1.f : 0.f;  // (selects below: 0 * a non-finite pixel (0, 0) would poison every padded tap)
-            const float *s = p.x + ((long)b * p.Cin + cic * CI + 8 * p_cg[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
+            const px_t *s = (const px_t *)p.x + ((long)b * p.Cin + cic * CI + 8 * p_cg[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) px[k][j] = s[j * HW];
         }
@@ -107,10 +111,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
         for (int k = 0; k < 8; ++k) {
             const int gy = y0 + (d_px[k] >> 6), gx = x0 + (d_px[k] & 63);
             const bool inb = gy < p.H && gx < p.W;     // W % 4 == 0: a group of 4 is in or out as a whole
-            const float4 v = *reinterpret_cast<const float4 *>(
-                p.g + ((long)b * p.Cout + cot * CO + d_co[k]) * HW + (inb ? (long)gy * p.W + gx : 0));
-            const float m = inb ? 1.f : 0.f;
-            dv[k] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+            const long go = ((long)b * p.Cout + cot * CO + d_co[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
+            if constexpr (XB) {
+                const v2u v = *reinterpret_cast<const v2u *>((const unsigned short *)p.g + go);
+                dv[k] = inb ? v : v2u{0u, 0u};
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>((const float *)p.g + go);
+                const float m = inb ? 1.f : 0.f;
+                dv[k] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+            }
         }
     };
     auto stage = [&]() {
@@ -118,21 +127,29 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
         for (int k = 0; k < 3; ++k) {
             unsigned hw[4], lw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                split2(pm[k] != 0.f ? px[k][2 * j] : 0.f, pm[k] != 0.f ? px[k][2 * j + 1] : 0.f, hw[j], lw[j]);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (XB)
+                    hw[j] = pm[k] != 0.f ? (unsigned)px[k][2 * j] | ((unsigned)px[k][2 * j + 1] << 16) : 0u;
+                else
+                    split2(pm[k] != 0.f ? px[k][2 * j] : 0.f, pm[k] != 0.f ? px[k][2 * j + 1] : 0.f, hw[j], lw[j]);
+            }
             if (p_off[k] >= 0) {
                 *reinterpret_cast<v4u *>(patch_hi + p_off[k]) = v4u{hw[0], hw[1], hw[2], hw[3]};
-                *reinterpret_cast<v4u *>(patch_lo + p_off[k]) = v4u{lw[0], lw[1], lw[2], lw[3]};
+                if constexpr (!XB) *reinterpret_cast<v4u *>(patch_lo + p_off[k]) = v4u{lw[0], lw[1], lw[2], lw[3]};
             }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            unsigned h0, l0, h1, l1;
-            split2(dv[k].x, dv[k].y, h0, l0);
-            split2(dv[k].z, dv[k].w, h1, l1);
-            if (d_off[k] >= 0) {
-                *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = v2u{h0, h1};
-                *reinterpret_cast<v2u *>(dout_lo + d_off[k]) = v2u{l0, l1};
+            if constexpr (XB) {
+                if (d_off[k] >= 0) *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = dv[k];
+            } else {
+                unsigned h0, l0, h1, l1;
+                split2(dv[k].x, dv[k].y, h0, l0);
+                split2(dv[k].z, dv[k].w, h1, l1);
+                if (d_off[k] >= 0) {
+                    *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = v2u{h0, h1};
+                    *reinterpret_cast<v2u *>(dout_lo + d_off[k]) = v2u{l0, l1};
+                }
             }
         }
     };
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
             for (int m = 0; m < 2; ++m) {
                 const int off = m * 32 * DROW + (row * TW + xk) * 2 + a_lane;
                 ah[m] = *reinterpret_cast<const bf16x8 *>(dout_hi + off);
-                al[m] = *reinterpret_cast<const bf16x8 *>(dout_lo + off);
+                if constexpr (!XB) al[m] = *reinterpret_cast<const bf16x8 *>(dout_lo + off);
             }
             const int poff = ((row + kh) * PW + xk + kw) * (CI * 2) + b_lane;
             auto tr = [&](const unsigned char *img, int o) {
@@ -175,14 +192,19 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
                     (__attribute__((address_space(3))) s4 *)(uintptr_t)(unsigned)(uintptr_t)(img + o));
             };
             const s4 h0 = tr(patch_hi, poff), h1 = tr(patch_hi, poff + 4 * (CI * 2));
-            const s4 l0 = tr(patch_lo, poff), l1 = tr(patch_lo, poff + 4 * (CI * 2));
             const bf16x8 bh = __builtin_bit_cast(bf16x8, s8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, s8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+            if constexpr (XB) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+            } else {
+                const s4 l0 = tr(patch_lo, poff), l1 = tr(patch_lo, poff + 4 * (CI * 2));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, s8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+                }
             }
         }
     }
@@ -250,19 +272,26 @@ extern "C" int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *st
     MMU_CHECK(p->width % 4 == 0, "conv3x3_wgrad_mfma: width must be a multiple of 4 (got %d)", p->width);
     // input = x [B, Cin, H, W]; weight field = dout [B, Cout, H, W]; out = dW [Cout, Cin, 3, 3]
     MMU_CHECK(p->input && p->weight && p->out && p->workspace, "conv3x3_wgrad_mfma: input, dout, dweight, workspace required");
-    MMU_CHECK(((uintptr_t)p->weight & 15) == 0, "conv3x3_wgrad_mfma: dout must be 16-byte aligned");
+    MMU_CHECK(p->io_dtype == MMU_DTYPE_F32 || p->io_dtype == MMU_DTYPE_BF16, "conv3x3_wgrad_mfma: io_dtype must be float32 or bfloat16");
+    const bool xb = p->io_dtype == MMU_DTYPE_BF16;
+    MMU_CHECK(((uintptr_t)p->weight & (xb ? 7 : 15)) == 0, "conv3x3_wgrad_mfma: dout must be %d-byte aligned", xb ? 8 : 16);
     hipStream_t st = (hipStream_t)stream;
-    static unsigned long long attr_mask = 0;  // per device
-    if (hipError_t e = mmu_set_lds_once(conv3x3_wgrad_mfma_kernel, LDS_BYTES, attr_mask); e != hipSuccess)
+    static unsigned long long attr_mask = 0, attr_mask_xb = 0;  // per device
+    if (hipError_t e = xb ? mmu_set_lds_once(conv3x3_wgrad_mfma_kernel<true>, LDS_BYTES, attr_mask_xb)
+                          : mmu_set_lds_once(conv3x3_wgrad_mfma_kernel<false>, LDS_BYTES, attr_mask);
+        e != hipSuccess)
         return mmu_fail("conv3x3_wgrad_mfma: LDS attribute: %s", hipGetErrorString(e));
     WgArgs a;
-    a.x = (const float *)p->input; a.g = p->weight; a.ws = (float *)p->workspace;
+    a.x = p->input; a.g = p->weight; a.ws = (float *)p->workspace;
     a.B = p->batch; a.Cin = p->in_channels; a.Cout = p->out_channels; a.H = p->height; a.W = p->width;
     a.tiles_x = (p->width + TW - 1) / TW; a.tiles_y = (p->height + TH - 1) / TH;
     a.n_cic = p->in_channels / CI; a.n_cot = p->out_channels / CO;
     a.wg_per_cc = wg_per_cc_for(p->batch, p->in_channels, p->out_channels, p->height, p->width);
     const int grid = a.wg_per_cc * a.n_cic * a.n_cot;
-    conv3x3_wgrad_mfma_kernel<<<grid, NT, LDS_BYTES, st>>>(a);
+    if (xb)
+        conv3x3_wgrad_mfma_kernel<true><<<grid, NT, LDS_BYTES, st>>>(a);
+    else
+        conv3x3_wgrad_mfma_kernel<false><<<grid, NT, LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("conv3x3_wgrad_mfma");
     const long n = (long)p->out_channels * p->in_channels * 9;
     {   // inside a deferred scope: with the other weight-gradient sums of the pass (deferred_reduce.hip, kind 6)
