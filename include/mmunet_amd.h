@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 10
+#define MMU_ABI_VERSION 11
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -599,10 +599,13 @@ typedef struct {
     int32_t m, n, batch, seqlen;
     int32_t exact_products;   /* 1: exact float32 products on the fp32 matrix pipe */
     int32_t narrow_steps;     /* 1: always the 32-token-step kernel (default: 128-token steps when seqlen % 128 == 0) */
-    const float *a;  int64_t a_rs, a_bs;
-    const float *b;  int64_t b_rs, b_bs;
+    const void *a;   int64_t a_rs, a_bs;   /* ab_dtype; strides in elements */
+    const void *b;   int64_t b_rs, b_bs;
     float *c;        /* [m][n] contiguous */
     float *workspace;
+    int32_t ab_dtype;         /* ABI 11: MMU_DTYPE_F32 (0, a zeroed struct) or MMU_DTYPE_BF16 -- both operands bfloat16
+                               * (autocast): exact products, ONE MFMA each; seqlen % 128 == 0, a / b 8-byte aligned,
+                               * exact_products = narrow_steps = 0 */
 } mmu_gemm_nt_params;
 
 size_t mmu_gemm_nt_splitk_workspace_floats(int m, int n, int batch, int seqlen);

@@ -159,7 +159,7 @@ class XProjParams(ctypes.Structure):
 class GemmNtParams(ctypes.Structure):
     _fields_ = [("m", _i32), ("n", _i32), ("batch", _i32), ("seqlen", _i32), ("exact_products", _i32), ("narrow_steps", _i32),
                 ("a", _vp), ("a_rs", _i64), ("a_bs", _i64), ("b", _vp), ("b_rs", _i64), ("b_bs", _i64),
-                ("c", _vp), ("workspace", _vp)]
+                ("c", _vp), ("workspace", _vp), ("ab_dtype", _i32)]
 
 
 class CbamStatsParams(ctypes.Structure):
@@ -257,7 +257,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 10   # = MMU_ABI_VERSION of include/mmunet_amd.h
+ABI_VERSION = 11   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():

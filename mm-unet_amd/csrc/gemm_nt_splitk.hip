@@ -47,7 +47,7 @@ constexpr int NT_A_FLOATS = NT_TM * NT_LD, NT_B_FLOATS = NT_TN * NT_LD;
 constexpr int NT_STAGE = NT_A_FLOATS + NT_B_FLOATS;             // 6,912 floats = 27 KB per buffer
 
 struct NtArgs {
-    const float *a, *b;
+    const void *a, *b;      // float32 (bfloat16 for gemm_nt_wide_kernel<true>)
     float *part;            // [slabs][M][N]
     long a_rs, a_bs, b_rs, b_bs;
     int M, N, L, batch;     // tokens = batch * L, L % 32 == 0
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(NtArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = min(m0 + row_a + 32 * j, p.M - 1);   // (never dereferenced beyond M)
-        ap[j] = p.a + (long)r * p.a_rs + 4 * colg;
+        ap[j] = (const float *)p.a + (long)r * p.a_rs + 4 * colg;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = min(n0 + row_a + 32 * j, p.N - 1);
-        bp[j] = p.b + (long)r * p.b_rs + 4 * colg;
+        bp[j] = (const float *)p.b + (long)r * p.b_rs + 4 * colg;
     }
     const int cpb = p.L / NT_TK;              // chunks per batch item
     // rows beyond M / N are never loaded: their LDS rows stay zero-fed from registers
@@ -220,7 +220,12 @@ constexpr int NW_ROWS = NT_TM + NT_TN;                  // 192
 constexpr int NW_LDS_BYTES = NW_ROWS * NW_LD * 4;       // 101,376
 constexpr int NW_LOADS = NW_ROWS / 16;                  // 12 row passes of 16 rows (512 threads = 16 rows x 32 pieces)
 
+// XB: bfloat16 operands (autocast) -- a row's 128 tokens are 256 bytes, a thread's piece 8 bytes written straight into
+// the hi image; both operands are exact bf16 values: ONE MFMA per product.
+template <bool XB>
 __global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(NtArgs p) {
+    using el_t = typename std::conditional<XB, unsigned short, float>::type;
+    using ld_t = typename std::conditional<XB, uint2, float4>::type;
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,39 +233,43 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(NtArgs p) {
     const int c_lo = slab * p.slab_chunks;                       // in steps of 128 tokens
     const int c_hi = min(c_lo + p.slab_chunks, p.n_chunks);
     const int piece = tid & 31, row_p = tid >> 5;                // 16-byte piece of the 512-byte row segment; row of the pass
-    const float *src[NW_LOADS];
+    const el_t *src[NW_LOADS];
     bool valid[NW_LOADS];
 #pragma unroll
     for (int j = 0; j < NW_LOADS; ++j) {
         const int r = row_p + 16 * j;                            // tile row: 0..127 = A, 128..191 = B
         if (r < NT_TM) {
             valid[j] = m0 + r < p.M;
-            src[j] = p.a + (long)min(m0 + r, p.M - 1) * p.a_rs + 4 * piece;
+            src[j] = (const el_t *)p.a + (long)min(m0 + r, p.M - 1) * p.a_rs + 4 * piece;
         } else {
             valid[j] = n0 + r - NT_TM < p.N;
-            src[j] = p.b + (long)min(n0 + r - NT_TM, p.N - 1) * p.b_rs + 4 * piece;
+            src[j] = (const el_t *)p.b + (long)min(n0 + r - NT_TM, p.N - 1) * p.b_rs + 4 * piece;
         }
     }
     const int cpb = p.L / NW_TK;
-    float4 regs[NW_LOADS];
+    ld_t regs[NW_LOADS];
 #pragma unroll
-    for (int j = 0; j < NW_LOADS; ++j) regs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NW_LOADS; ++j) regs[j] = ld_t{};
     auto load = [&](int c) {
         const int bi = c / cpb, l0 = (c - bi * cpb) * NW_TK;
         const long oa = (long)bi * p.a_bs + l0, ob = (long)bi * p.b_bs + l0;
 #pragma unroll
         for (int j = 0; j < NW_LOADS; ++j)
-            if (valid[j]) regs[j] = *reinterpret_cast<const float4 *>(src[j] + (j < NT_TM / 16 ? oa : ob));
+            if (valid[j]) regs[j] = *reinterpret_cast<const ld_t *>(src[j] + (j < NT_TM / 16 ? oa : ob));
     };
     auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < NW_LOADS; ++j) {
             float *row = wlds + (row_p + 16 * j) * NW_LD;
-            uint2 hi, lo;
-            nt_split2(regs[j].x, regs[j].y, hi.x, lo.x);
-            nt_split2(regs[j].z, regs[j].w, hi.y, lo.y);
-            *reinterpret_cast<uint2 *>(row + 2 * piece) = hi;
-            *reinterpret_cast<uint2 *>(row + 64 + 2 * piece) = lo;
+            if constexpr (XB) {
+                *reinterpret_cast<uint2 *>(row + 2 * piece) = regs[j];
+            } else {
+                uint2 hi, lo;
+                nt_split2(regs[j].x, regs[j].y, hi.x, lo.x);
+                nt_split2(regs[j].z, regs[j].w, hi.y, lo.y);
+                *reinterpret_cast<uint2 *>(row + 2 * piece) = hi;
+                *reinterpret_cast<uint2 *>(row + 64 + 2 * piece) = lo;
+            }
         }
     };
     // wave w: rows 32 (w & 3) .. + 31 of A against columns 32 (w >> 2) .. + 31 of B
@@ -278,11 +287,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(NtArgs p) {
 #pragma unroll
             for (int s = 0; s < NW_TK / 16; ++s) {     // lane (r, h): tokens 16 s + 8 h .. + 7 of its row
                 const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wlds + a_off + 8 * s);
-                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(wlds + a_off + 64 + 8 * s);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(wlds + b_off + 8 * s);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(wlds + b_off + 64 + 8 * s);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                if constexpr (!XB) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(wlds + a_off + 64 + 8 * s);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(wlds + b_off + 64 + 8 * s);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             }
             MMU_LDS_BARRIER();                         // everyone is done reading before the next step is staged
@@ -375,9 +386,14 @@ extern "C" int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream) {
     MMU_CHECK(p->m > 0 && p->n > 0 && p->batch > 0 && p->seqlen > 0, "gemm_nt_splitk: empty problem");
     MMU_CHECK(p->seqlen % NT_TK == 0, "gemm_nt_splitk: seqlen must be a multiple of %d (got %d)", NT_TK, p->seqlen);
     MMU_CHECK(p->a && p->b && p->c && p->workspace, "gemm_nt_splitk: a, b, c, workspace are required");
-    MMU_CHECK(((uintptr_t)p->a & 15) == 0 && ((uintptr_t)p->b & 15) == 0 && p->a_rs % 4 == 0 && p->a_bs % 4 == 0 &&
+    MMU_CHECK(p->ab_dtype == MMU_DTYPE_F32 || p->ab_dtype == MMU_DTYPE_BF16, "gemm_nt_splitk: ab_dtype must be float32 or bfloat16");
+    const bool xb = p->ab_dtype == MMU_DTYPE_BF16;
+    const uintptr_t amask = xb ? 7 : 15;
+    MMU_CHECK(((uintptr_t)p->a & amask) == 0 && ((uintptr_t)p->b & amask) == 0 && p->a_rs % 4 == 0 && p->a_bs % 4 == 0 &&
                   p->b_rs % 4 == 0 && p->b_bs % 4 == 0,
-              "gemm_nt_splitk: operands must be 16-byte aligned with row / batch strides that are multiples of 4");
+              "gemm_nt_splitk: operands must be %d-byte aligned with row / batch strides that are multiples of 4", (int)amask + 1);
+    MMU_CHECK(!xb || (p->seqlen % NW_TK == 0 && !p->exact_products && !p->narrow_steps),
+              "gemm_nt_splitk: bfloat16 operands need seqlen %% %d == 0 (128-token steps) and no exact / narrow request", NW_TK);
     hipStream_t st = (hipStream_t)stream;
     const bool swap = nt_rows_loaded(p->n, p->m) < nt_rows_loaded(p->m, p->n);   // compute C^T, transpose in the reduce
     NtArgs a;
@@ -393,15 +409,20 @@ extern "C" int mmu_gemm_nt_splitk(const mmu_gemm_nt_params *p, void *stream) {
     const long tokens = (long)p->batch * p->seqlen;
     static const bool exact_env = []() { const char *e = getenv("MMU_GEMM_NT_EXACT"); return e && e[0] == '1'; }();
     const bool exact = exact_env || p->exact_products;
-    const bool wide = !p->narrow_steps && nt_wide(p->seqlen, exact);
+    const bool wide = xb || (!p->narrow_steps && nt_wide(p->seqlen, exact));
     a.n_chunks = (int)(tokens / (wide ? NW_TK : NT_TK));
     const int slabs = nt_plan(a.M, a.N, tokens, a.slab_chunks, wide);
     dim3 grid((a.M + NT_TM - 1) / NT_TM, (a.N + NT_TN - 1) / NT_TN, slabs);
     if (wide) {
-        static unsigned long long attr_mask = 0;  // per device
-        if (hipError_t e = mmu_set_lds_once(gemm_nt_wide_kernel, NW_LDS_BYTES, attr_mask); e != hipSuccess)
+        static unsigned long long attr_mask = 0, attr_mask_xb = 0;  // per device
+        if (hipError_t e = xb ? mmu_set_lds_once(gemm_nt_wide_kernel<true>, NW_LDS_BYTES, attr_mask_xb)
+                              : mmu_set_lds_once(gemm_nt_wide_kernel<false>, NW_LDS_BYTES, attr_mask);
+            e != hipSuccess)
             return mmu_fail("gemm_nt_splitk: LDS attribute: %s", hipGetErrorString(e));
-        gemm_nt_wide_kernel<<<grid, 512, NW_LDS_BYTES, st>>>(a);
+        if (xb)
+            gemm_nt_wide_kernel<true><<<grid, 512, NW_LDS_BYTES, st>>>(a);
+        else
+            gemm_nt_wide_kernel<false><<<grid, 512, NW_LDS_BYTES, st>>>(a);
     } else if (exact) {
         gemm_nt_splitk_kernel<false><<<grid, 256, 0, st>>>(a);
     } else {

@@ -225,24 +225,30 @@ def tokens_supported(*tensors):
 
 # False (or MMUNET_GEMM_NT=0): callers keep their batched-GEMM split-K (tests compare the two)
 NT_ENABLED = os.environ.get("MMUNET_GEMM_NT", "1") != "0"
+NT_LOWP = os.environ.get("MMUNET_GEMM_NT_LOWP", "1") != "0"   # "0": bf16 weight gradients stay on the slab-batched library GEMM
 
 
 def nt_supported(a, b, seqlen):
-    """Token-contraction product on the fp32 matrix cores (csrc/gemm_nt_splitk.hip): float32 operands with unit token
-    stride, 16-byte aligned, seqlen a multiple of 32."""
-    return (NT_ENABLED and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and seqlen % 32 == 0
-            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+    """Token-contraction product on the matrix cores (csrc/gemm_nt_splitk.hip): float32 operands with unit token
+    stride, 16-byte aligned, seqlen a multiple of 32 -- or bfloat16 operands (autocast), 8-byte aligned, seqlen a
+    multiple of 128."""
+    if not (NT_ENABLED and a.is_cuda and a.dtype == b.dtype):
+        return False
+    if a.dtype == torch.bfloat16:
+        return NT_LOWP and seqlen % 128 == 0 and a.data_ptr() % 8 == 0 and b.data_ptr() % 8 == 0
+    return a.dtype == torch.float32 and seqlen % 32 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
 
 
 def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False, narrow=False):
     """C (m, n) = sum over the batch * seqlen tokens of A[i][t] * B[j][t]; token (bi, l) of row i of ``a`` lies at
     element offset i * a_rs + bi * a_bs + l of its storage (same for ``b``): channel-major and batch-major operands are
-    both read in place.  float32, deterministic."""
+    both read in place.  float32 operands, or both bfloat16 (exact products, one MFMA each); float32 result,
+    deterministic."""
     _lib.require_gpu(a, b)
-    if a.dtype != torch.float32 or b.dtype != torch.float32:
-        raise RuntimeError("gemm_nt: float32 tensors required")
-    if seqlen % 32 != 0 or any(v % 4 != 0 for v in (a_rs, a_bs, b_rs, b_bs)):
-        raise RuntimeError("gemm_nt: seqlen must be a multiple of 32 and the strides multiples of 4")
+    if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("gemm_nt: two float32 or two bfloat16 tensors required")
+    if seqlen % (128 if a.dtype == torch.bfloat16 else 32) != 0 or any(v % 4 != 0 for v in (a_rs, a_bs, b_rs, b_bs)):
+        raise RuntimeError("gemm_nt: seqlen must be a multiple of 32 (bfloat16: 128) and the strides multiples of 4")
     L = _lib.lib()
     c = torch.empty((m, n), device=a.device, dtype=torch.float32)
     with torch.cuda.device(a.device):   # the slab count follows the CU count of the device that runs the kernel
@@ -253,6 +259,7 @@ def gemm_nt(a, b, m, n, batch, seqlen, a_rs, a_bs, b_rs, b_bs, exact=False, narr
     p.a, p.a_rs, p.a_bs = a.data_ptr(), a_rs, a_bs
     p.b, p.b_rs, p.b_bs = b.data_ptr(), b_rs, b_bs
     p.c, p.workspace = c.data_ptr(), ws.data_ptr()
+    p.ab_dtype = _lib.dtype_code(a)
     with torch.cuda.device(a.device):
         _lib.check(L.mmu_gemm_nt_splitk(p, _lib.stream_of(a)))
     # inside a deferred.Scope the slab sums run later: the partials must outlive this call.  (NOT the result: an extra

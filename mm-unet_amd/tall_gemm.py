@@ -25,7 +25,11 @@ def nt_splitk(X, Y):
     if T < _NT_MIN:
         return X @ Y.t()
     if X.dtype == Y.dtype and mfma_gemm.nt_supported(X, Y, T) and X.stride(0) % 4 == 0 and Y.stride(0) % 4 == 0:
-        return mfma_gemm.gemm_nt(X, Y, I, J, 1, T, X.stride(0), 0, Y.stride(0), 0)   # one kernel + its slab sum
+        # one kernel + its slab sum.  bf16 operands (autocast): the callers cast the float32 result to the dtype of a
+        # weight that may itself be a bf16 COPY of the parameter -- the result is then a temporary, which a deferred sum
+        # must never write to (deferred.py: the leaf-parameter contract): summed on the spot
+        with (contextlib.nullcontext() if X.dtype == torch.float32 else deferred.paused()):
+            return mfma_gemm.gemm_nt(X, Y, I, J, 1, T, X.stride(0), 0, Y.stride(0), 0)
     S = T // _SLAB
     Tm = S * _SLAB
     Xs = X[:, :Tm].reshape(I, S, _SLAB).transpose(0, 1)          # (S, I, slab) view
@@ -238,6 +242,9 @@ class _ProjBclLowpFn(torch.autograd.Function):
                 out = torch.empty((O, B, L), device=X.device, dtype=torch.bfloat16).permute(1, 0, 2)   # [O][B][L]
             else:
                 out = torch.empty((B, O, L), device=X.device, dtype=torch.bfloat16)
+            base = W._base if W._is_view() else None   # (the leaf-parameter contract of deferred sums: _ProjBclFn)
+            ctx.defer_dw = bool(W.dtype == torch.float32 and
+                                (W.is_leaf or (base is not None and base.is_leaf and W.is_contiguous())))
             own = W.is_contiguous() and mfma_gemm.tokens_lowp_supported(W, Xc, out)
             if own:
                 mfma_gemm.gemm_tokens(W, Xc, out, O, I, L, B, Xc.stride(1), Xc.stride(0), out.stride(1), out.stride(0))
@@ -271,7 +278,15 @@ class _ProjBclLowpFn(torch.autograd.Function):
                         torch.mm(Wt, G[b], out=dX[b])
                 dX = dX.to(ctx.x_dtype)
             if ctx.needs_input_grad[0]:
-                dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(Xc)).to(ctx.w_dtype)
+                if (G.stride(2) == 1 and Xc.stride(2) == 1 and mfma_gemm.nt_supported(G, Xc, L) and B * L >= _NT_MIN
+                        and all(t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 for t in (G, Xc))):
+                    # both layouts read in place by the token-contraction kernel's bf16 form (exact products)
+                    with (contextlib.nullcontext() if ctx.defer_dw else deferred.paused()):
+                        dW = mfma_gemm.gemm_nt(G, Xc, Wc.shape[0], I, B, L, G.stride(1), G.stride(0), Xc.stride(1),
+                                               Xc.stride(0)).to(ctx.w_dtype)
+                else:
+                    with deferred.paused():
+                        dW = nt_splitk(_channel_major_2d(G), _channel_major_2d(Xc)).to(ctx.w_dtype)
         return dW, dX, None
 
 

@@ -771,6 +771,34 @@ def test_gemm_nt_splitk_vs_float64(case):
         assert err <= tol * (b * l) ** 0.5, f"exact={exact} narrow={narrow}: max abs err {err:.3e}"
 
 
+@pytest.mark.parametrize("case", [(256, 64, 2, 1024, "cm", "bm"), (64, 128, 3, 512, "bm", "cm"), (36, 128, 2, 2048, "cm", "cm"),
+                                  (128, 4, 2, 1024, "cm", "cm"), (130, 65, 3, 384, "cm", "bm")])
+def test_gemm_nt_bfloat16_operands_vs_float64(case):
+    """gemm_nt with bfloat16 operands (autocast: gemm_nt_wide_kernel<true>, both operands exact bf16 values, ONE MFMA
+    per product, float32 sums) against a float64 einsum of the SAME bf16 values: float32-grade, and reproducible."""
+    from mm_unet_amd import mfma_gemm
+    m, n, b, l, la, lb = case
+    gen = torch.Generator().manual_seed(23)
+
+    def make(rows, layout):
+        t = torch.randn(b, rows, l, generator=gen).to(torch.bfloat16)
+        if layout == "cm":
+            return t, t.permute(1, 0, 2).contiguous().to(DEV), b * l, l
+        return t, t.to(DEV), l, rows * l
+
+    a_ref, a_dev, a_rs, a_bs = make(m, la)
+    b_ref, b_dev, b_rs, b_bs = make(n, lb)
+    assert mfma_gemm.nt_supported(a_dev, b_dev, l)
+    ref = torch.einsum("bil,bjl->ij", a_ref.double(), b_ref.double())
+    c1 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs)
+    c2 = mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, l, a_rs, a_bs, b_rs, b_bs)
+    assert c1.dtype == torch.float32 and torch.equal(c1, c2)
+    err = float((c1.double().cpu() - ref).abs().max())
+    assert err <= 4e-6 * (b * l) ** 0.5, err       # exact products: only the float32 accumulation rounds
+    with pytest.raises(RuntimeError):              # 32-token steps have no bf16 form
+        mfma_gemm.gemm_nt(a_dev, b_dev, m, n, b, 96, a_rs, a_bs, b_rs, b_bs)
+
+
 @pytest.mark.parametrize("shape", [(256, 64), (36, 128), (64, 192)])
 def test_gemm_nt_full_size_properties(shape):
     """csrc/gemm_nt_splitk.hip at the headline token count (B * L = 8 * 65,536, the slab plans of the real calls): against

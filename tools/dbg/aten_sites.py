@@ -1,5 +1,5 @@
 """Which call sites still launch plain ATen kernels (fills, copies, adds, cats, ...) in one training step
-(float32, 8 x 3 x 512 x 512)?  Logs every aten op outside a small allow-list with its shapes and the innermost
+(float32, 8 x 3 x 512 x 512; DT=bf16: under bf16 autocast, batch 16)?  Logs every aten op outside a small allow-list with its shapes and the innermost
 mm-unet_amd frame (autograd-engine calls have none: '?')."""
 import collections, os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -27,12 +27,18 @@ class Log(TorchDispatchMode):
         return func(*args, **(kwargs or {}))
 
 torch.manual_seed(50)
+BF = os.environ.get("DT") == "bf16"
+NB = 16 if BF else 8
 m = MM_Net(num_classes=1).cuda().train()
-x = torch.randn(8, 3, 512, 512, device="cuda"); t = (torch.rand(8, 1, 512, 512, device="cuda") > 0.88).float()
-DICE_BCE_Loss()(m(x), t).backward()   # warm
+x = torch.randn(NB, 3, 512, 512, device="cuda"); t = (torch.rand(NB, 1, 512, 512, device="cuda") > 0.88).float()
+def step():
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=BF):
+        out = m(x)
+    DICE_BCE_Loss()(out.float(), t).backward()   # (the loss outside autocast, as train_step.py runs it)
+step()   # warm
 m.zero_grad(set_to_none=True)
 with Log():
-    DICE_BCE_Loss()(m(x), t).backward()
+    step()
 agg = collections.Counter()
 for (name, shapes, site), n in seen.items():
     agg[(name, site)] += n
