@@ -561,9 +561,11 @@ int mmu_gemm_tokens_prepare_batch(const int64_t *table, int n_items, int64_t max
 typedef struct {
     int32_t rank, dim;
     int64_t tokens;
-    const float *dt;      int64_t dt_rs;      /* written by mmu_dt_proj_bwd */
+    const void *dt;       int64_t dt_rs;      /* io_dtype; written by mmu_dt_proj_bwd */
     const float *weight;  int64_t w_ld;
-    float *delta;         int64_t delta_rs;   /* read by mmu_dt_proj_bwd */
+    void *delta;          int64_t delta_rs;   /* io_dtype; read by mmu_dt_proj_bwd */
+    int32_t io_dtype;     /* ABI 11: MMU_DTYPE_F32 (0, a zeroed struct) or MMU_DTYPE_BF16 -- bfloat16 token rows (8-byte
+                           * aligned), float32 weights and arithmetic, results rounded to nearest even */
 } mmu_dt_proj_params;
 int mmu_dt_proj_fwd(const mmu_dt_proj_params *p, void *stream);
 int mmu_dt_proj_bwd(const mmu_dt_proj_params *p, void *stream);
@@ -578,9 +580,10 @@ int mmu_dt_proj_bwd(const mmu_dt_proj_params *p, void *stream);
 typedef struct {
     int32_t rows, dim;
     int64_t tokens;
-    const float *x;       int64_t x_rs;       /* updated by mmu_x_proj_bwd */
+    const void *x;        int64_t x_rs;       /* io_dtype; updated by mmu_x_proj_bwd */
     const float *weight;  int64_t w_ld;
-    float *x_dbl;         int64_t x_dbl_rs;   /* read by mmu_x_proj_bwd */
+    void *x_dbl;          int64_t x_dbl_rs;   /* io_dtype; read by mmu_x_proj_bwd */
+    int32_t io_dtype;     /* ABI 11: as mmu_dt_proj_params.io_dtype */
 } mmu_x_proj_params;
 int mmu_x_proj_fwd(const mmu_x_proj_params *p, void *stream);
 int mmu_x_proj_bwd(const mmu_x_proj_params *p, void *stream);

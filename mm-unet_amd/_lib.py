@@ -148,12 +148,12 @@ class GemmTokensParams(ctypes.Structure):
 
 class DtProjParams(ctypes.Structure):
     _fields_ = [("rank", _i32), ("dim", _i32), ("tokens", _i64), ("dt", _vp), ("dt_rs", _i64), ("weight", _vp), ("w_ld", _i64),
-                ("delta", _vp), ("delta_rs", _i64)]
+                ("delta", _vp), ("delta_rs", _i64), ("io_dtype", _i32)]
 
 
 class XProjParams(ctypes.Structure):
     _fields_ = [("rows", _i32), ("dim", _i32), ("tokens", _i64), ("x", _vp), ("x_rs", _i64), ("weight", _vp), ("w_ld", _i64),
-                ("x_dbl", _vp), ("x_dbl_rs", _i64)]
+                ("x_dbl", _vp), ("x_dbl_rs", _i64), ("io_dtype", _i32)]
 
 
 class GemmNtParams(ctypes.Structure):

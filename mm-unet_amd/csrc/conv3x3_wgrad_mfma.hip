@@ -79,16 +79,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
         p_pc[k] = pxi - p_pr[k] * PW;
         p_off[k] = live ? pxi * (CI * 2) + p_cg[k] * 16 : -1;
     }
-    int d_co[8], d_px[8], d_off[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int q = tid + NT * k;
-        const bool live = q < CO * 64;
-        q = live ? q : CO * 64 - 1;
-        d_co[k] = q >> 6;
-        d_px[k] = (q & 63) * 4;                       // pixel index inside the 4 x 64 tile (row-major)
-        d_off[k] = live ? d_co[k] * DROW + d_px[k] * 2 : -1;
-    }
+    // (NT = 9 x 64: item tid + NT k is channel row wv + 9 k, pixel group tid & 63 -- one pixel offset for all eight
+    // rounds, nothing per round kept in registers)
+    const int d_px = (tid & 63) * 4;                  // pixel index inside the 4 x 64 tile (row-major)
+    const int d_co0 = tid >> 6;
+    auto d_live = [&](int k) { return d_co0 + 9 * k < CO; };
+    auto d_co = [&](int k) { return d_live(k) ? d_co0 + 9 * k : CO - 1; };
 
     px_t px[3][8];
     float pm[3];
@@ -109,9 +105,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int gy = y0 + (d_px[k] >> 6), gx = x0 + (d_px[k] & 63);
+            const int gy = y0 + (d_px >> 6), gx = x0 + (d_px & 63);
             const bool inb = gy < p.H && gx < p.W;     // W % 4 == 0: a group of 4 is in or out as a whole
-            const long go = ((long)b * p.Cout + cot * CO + d_co[k]) * HW + (inb ? (long)gy * p.W + gx : 0);
+            const long go = ((long)b * p.Cout + cot * CO + d_co(k)) * HW + (inb ? (long)gy * p.W + gx : 0);
             if constexpr (XB) {
                 const v2u v = *reinterpret_cast<const v2u *>((const unsigned short *)p.g + go);
                 dv[k] = inb ? v : v2u{0u, 0u};
@@ -141,14 +137,14 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if constexpr (XB) {
-                if (d_off[k] >= 0) *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = dv[k];
+                if (d_live(k)) *reinterpret_cast<v2u *>(dout_hi + d_co(k) * DROW + d_px * 2) = dv[k];
             } else {
                 unsigned h0, l0, h1, l1;
                 split2(dv[k].x, dv[k].y, h0, l0);
                 split2(dv[k].z, dv[k].w, h1, l1);
-                if (d_off[k] >= 0) {
-                    *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = v2u{h0, h1};
-                    *reinterpret_cast<v2u *>(dout_lo + d_off[k]) = v2u{l0, l1};
+                if (d_live(k)) {
+                    *reinterpret_cast<v2u *>(dout_hi + d_co(k) * DROW + d_px * 2) = v2u{h0, h1};
+                    *reinterpret_cast<v2u *>(dout_lo + d_co(k) * DROW + d_px * 2) = v2u{l0, l1};
                 }
             }
         }

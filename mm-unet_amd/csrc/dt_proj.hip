@@ -6,20 +6,44 @@
 // and 128 channels.  A GEMM library pads them to its tile sizes and ran them at 3.6-4 TB/s (68 us for 276 MB); they are
 // pure streaming: every thread owns four tokens, keeps the R dt values (forward) or R sums (backward) of its tokens in
 // registers and walks the D rows, whose weights are wave-uniform (scalar loads).  float32; rows 16-byte aligned.
+// Under bf16 autocast (io_t = bf16_t) the token rows are bfloat16 -- read and written natively, half the bytes of a
+// memory-bound kernel --, the weights and all arithmetic stay float32, results round to nearest even at the store.
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
 
 namespace {
 
-template <int R>
-__global__ __launch_bounds__(256) void dt_proj_fwd_kernel(const float *__restrict__ dt, long dt_rs, const float *__restrict__ W,
-                                                          long w_ld, float *__restrict__ out, long out_rs, int D, long T4,
+// four consecutive tokens of a row: float32 (16 bytes) or bfloat16 (8 bytes; autocast) -- float32 in registers either way
+template <typename io_t>
+__device__ __forceinline__ float4 ld4(const io_t *row, long i) {
+    if constexpr (sizeof(io_t) == 4) {
+        return reinterpret_cast<const float4 *>(row)[i];
+    } else {
+        const uint2 v = reinterpret_cast<const uint2 *>(row)[i];
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xffff0000u));
+    }
+}
+template <typename io_t>
+__device__ __forceinline__ void st4(io_t *row, long i, float4 v) {
+    if constexpr (sizeof(io_t) == 4) {
+        reinterpret_cast<float4 *>(row)[i] = v;
+    } else {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+        const bf2 a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};   // round to nearest even
+        reinterpret_cast<uint2 *>(row)[i] = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    }
+}
+
+template <int R, typename io_t>
+__global__ __launch_bounds__(256) void dt_proj_fwd_kernel(const io_t *__restrict__ dt, long dt_rs, const float *__restrict__ W,
+                                                          long w_ld, io_t *__restrict__ out, long out_rs, int D, long T4,
                                                           int d_per_block) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T4) return;
     float4 v[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = reinterpret_cast<const float4 *>(dt + r * dt_rs)[i];
+    for (int r = 0; r < R; ++r) v[r] = ld4(dt + r * dt_rs, i);
     const int d0 = blockIdx.y * d_per_block, d1 = min(d0 + d_per_block, D);
     for (int d = d0; d < d1; ++d) {
         const float *w = W + (long)d * w_ld;   // uniform: scalar loads
@@ -29,13 +53,13 @@ __global__ __launch_bounds__(256) void dt_proj_fwd_kernel(const float *__restric
             const float c = w[r];
             o.x = fmaf(c, v[r].x, o.x); o.y = fmaf(c, v[r].y, o.y); o.z = fmaf(c, v[r].z, o.z); o.w = fmaf(c, v[r].w, o.w);
         }
-        reinterpret_cast<float4 *>(out + (long)d * out_rs)[i] = o;
+        st4(out + (long)d * out_rs, i, o);
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void dt_proj_bwd_kernel(const float *__restrict__ g, long g_rs, const float *__restrict__ W,
-                                                          long w_ld, float *__restrict__ ddt, long ddt_rs, int D, long T4) {
+template <int R, typename io_t>
+__global__ __launch_bounds__(256) void dt_proj_bwd_kernel(const io_t *__restrict__ g, long g_rs, const float *__restrict__ W,
+                                                          long w_ld, io_t *__restrict__ ddt, long ddt_rs, int D, long T4) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T4) return;
     float4 acc[R];
@@ -45,7 +69,7 @@ __global__ __launch_bounds__(256) void dt_proj_bwd_kernel(const float *__restric
     for (; d + 8 <= D; d += 8) {   // eight rows in flight per thread
         float4 x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = reinterpret_cast<const float4 *>(g + (long)(d + j) * g_rs)[i];
+        for (int j = 0; j < 8; ++j) x[j] = ld4(g + (long)(d + j) * g_rs, i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float *w = W + (long)(d + j) * w_ld;
@@ -58,7 +82,7 @@ __global__ __launch_bounds__(256) void dt_proj_bwd_kernel(const float *__restric
         }
     }
     for (; d < D; ++d) {
-        const float4 x = reinterpret_cast<const float4 *>(g + (long)d * g_rs)[i];
+        const float4 x = ld4(g + (long)d * g_rs, i);
         const float *w = W + (long)d * w_ld;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -68,7 +92,7 @@ __global__ __launch_bounds__(256) void dt_proj_bwd_kernel(const float *__restric
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) reinterpret_cast<float4 *>(ddt + r * ddt_rs)[i] = acc[r];
+    for (int r = 0; r < R; ++r) st4(ddt + r * ddt_rs, i, acc[r]);
 }
 
 // ---- x_proj on tokens-last operands: x_dbl (RW x T) = W_x (RW x D) . conv (D x T), and d conv += W_x^T . d x_dbl -------
@@ -80,9 +104,9 @@ __global__ __launch_bounds__(256) void dt_proj_bwd_kernel(const float *__restric
 // backward spends its time in the read-modify-write epilogue (97 / 250 us; the library: 97 / 157 us).
 constexpr int XP_MAXR = 40;
 
-template <int RW>
-__global__ __launch_bounds__(256) void x_proj_fwd_kernel(const float *__restrict__ x, long x_rs, const float *__restrict__ W,
-                                                         long w_ld, float *__restrict__ out, long out_rs, int D, long T4) {
+template <int RW, typename io_t>
+__global__ __launch_bounds__(256) void x_proj_fwd_kernel(const io_t *__restrict__ x, long x_rs, const float *__restrict__ W,
+                                                         long w_ld, io_t *__restrict__ out, long out_rs, int D, long T4) {
     extern __shared__ __attribute__((aligned(16))) float sW[];   // [D][RWP]: W transposed, rows padded to a multiple of 4
     constexpr int RWP = (RW + 3) & ~3;
     for (int i = threadIdx.x; i < D * RWP; i += 256) {   // coalesced reads of W's rows, transposed into LDS
@@ -97,7 +121,7 @@ __global__ __launch_bounds__(256) void x_proj_fwd_kernel(const float *__restrict
     for (int d0 = 0; d0 < D; d0 += 4) {   // four rows in flight
         float4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const float4 *>(x + (long)(d0 + j) * x_rs)[i];
+        for (int j = 0; j < 4; ++j) v[j] = ld4(x + (long)(d0 + j) * x_rs, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 *w4 = reinterpret_cast<const float4 *>(sW + (d0 + j) * RWP);
@@ -117,14 +141,14 @@ __global__ __launch_bounds__(256) void x_proj_fwd_kernel(const float *__restrict
         }
     }
 #pragma unroll
-    for (int r = 0; r < RW; ++r) reinterpret_cast<float4 *>(out + (long)r * out_rs)[i] = acc[r];
+    for (int r = 0; r < RW; ++r) st4(out + (long)r * out_rs, i, acc[r]);
     }
 }
 
 // d conv[d][t] += sum_r W[r][d] * g[r][t]
-template <int RW>
-__global__ __launch_bounds__(256) void x_proj_bwd_kernel(const float *__restrict__ g, long g_rs, const float *__restrict__ W,
-                                                         long w_ld, float *__restrict__ dx, long dx_rs, int D, long T4) {
+template <int RW, typename io_t>
+__global__ __launch_bounds__(256) void x_proj_bwd_kernel(const io_t *__restrict__ g, long g_rs, const float *__restrict__ W,
+                                                         long w_ld, io_t *__restrict__ dx, long dx_rs, int D, long T4) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
     constexpr int RWP = (RW + 3) & ~3;
     for (int i = threadIdx.x; i < D * RWP; i += 256) {   // coalesced reads of W's rows, transposed into LDS
@@ -135,11 +159,11 @@ __global__ __launch_bounds__(256) void x_proj_bwd_kernel(const float *__restrict
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < T4; i += (long)gridDim.x * 256) {
     float4 v[RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) v[r] = reinterpret_cast<const float4 *>(g + (long)r * g_rs)[i];
+    for (int r = 0; r < RW; ++r) v[r] = ld4(g + (long)r * g_rs, i);
     for (int d0 = 0; d0 < D; d0 += 4) {
         float4 o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = reinterpret_cast<const float4 *>(dx + (long)(d0 + j) * dx_rs)[i];
+        for (int j = 0; j < 4; ++j) o[j] = ld4(dx + (long)(d0 + j) * dx_rs, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 *w4 = reinterpret_cast<const float4 *>(sW + (d0 + j) * RWP);
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(256) void x_proj_bwd_kernel(const float *__restrict
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) reinterpret_cast<float4 *>(dx + (long)(d0 + j) * dx_rs)[i] = o[j];
+        for (int j = 0; j < 4; ++j) st4(dx + (long)(d0 + j) * dx_rs, i, o[j]);
     }
     }
 }
@@ -169,9 +193,11 @@ int check_xp(const mmu_x_proj_params *p, const char *who) {
               "%s: rows must be 1..%d, dim a multiple of 4 up to 1024, tokens positive (got %d, %d, %ld)", who, XP_MAXR,
               p->rows, p->dim, (long)p->tokens);
     MMU_CHECK(p->x && p->weight && p->x_dbl, "%s: x, weight, x_dbl are required", who);
-    MMU_CHECK(p->tokens % 4 == 0 && p->x_rs % 4 == 0 && p->x_dbl_rs % 4 == 0 && ((uintptr_t)p->x & 15) == 0 &&
-                  ((uintptr_t)p->x_dbl & 15) == 0,
-              "%s: tokens and the row strides must be multiples of 4, x and x_dbl 16-byte aligned", who);
+    MMU_CHECK(p->io_dtype == MMU_DTYPE_F32 || p->io_dtype == MMU_DTYPE_BF16, "%s: io_dtype must be float32 or bfloat16", who);
+    const uintptr_t am = p->io_dtype == MMU_DTYPE_BF16 ? 7 : 15;
+    MMU_CHECK(p->tokens % 4 == 0 && p->x_rs % 4 == 0 && p->x_dbl_rs % 4 == 0 && ((uintptr_t)p->x & am) == 0 &&
+                  ((uintptr_t)p->x_dbl & am) == 0,
+              "%s: tokens and the row strides must be multiples of 4, x and x_dbl %d-byte aligned", who, (int)am + 1);
     return 0;
 }
 
@@ -180,9 +206,11 @@ int check(const mmu_dt_proj_params *p, const char *who) {
     MMU_CHECK(p->rank >= 1 && p->rank <= 8 && p->dim > 0 && p->tokens > 0,
               "%s: rank must be 1..8, dim and tokens positive (got %d, %d, %ld)", who, p->rank, p->dim, (long)p->tokens);
     MMU_CHECK(p->dt && p->weight && p->delta, "%s: dt, weight, delta are required", who);
-    MMU_CHECK(p->tokens % 4 == 0 && p->dt_rs % 4 == 0 && p->delta_rs % 4 == 0 && ((uintptr_t)p->dt & 15) == 0 &&
-                  ((uintptr_t)p->delta & 15) == 0,
-              "%s: tokens and the row strides must be multiples of 4, dt and delta 16-byte aligned", who);
+    MMU_CHECK(p->io_dtype == MMU_DTYPE_F32 || p->io_dtype == MMU_DTYPE_BF16, "%s: io_dtype must be float32 or bfloat16", who);
+    const uintptr_t am = p->io_dtype == MMU_DTYPE_BF16 ? 7 : 15;
+    MMU_CHECK(p->tokens % 4 == 0 && p->dt_rs % 4 == 0 && p->delta_rs % 4 == 0 && ((uintptr_t)p->dt & am) == 0 &&
+                  ((uintptr_t)p->delta & am) == 0,
+              "%s: tokens and the row strides must be multiples of 4, dt and delta %d-byte aligned", who, (int)am + 1);
     MMU_CHECK(p->tokens / 4 / 256 < (1L << 31), "%s: too many tokens", who);
     return 0;
 }
@@ -210,8 +238,13 @@ extern "C" int mmu_dt_proj_fwd(const mmu_dt_proj_params *p, void *stream) {
     while (ny < 8 && (long)bx * ny < 2 * mmu_cu_count() && p->dim / (ny * 2) >= 8) ny *= 2;
     const int dpb = (p->dim + ny - 1) / ny;
     dim3 grid(bx, (unsigned)((p->dim + dpb - 1) / dpb));
-    DT_DISPATCH(p->rank, dt_proj_fwd_kernel<R><<<grid, 256, 0, (hipStream_t)stream>>>(p->dt, p->dt_rs, p->weight, p->w_ld, p->delta,
-                                                                                       p->delta_rs, p->dim, T4, dpb););
+    if (p->io_dtype == MMU_DTYPE_BF16) {
+        DT_DISPATCH(p->rank, dt_proj_fwd_kernel<R, bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(
+            (const bf16_t *)p->dt, p->dt_rs, p->weight, p->w_ld, (bf16_t *)p->delta, p->delta_rs, p->dim, T4, dpb););
+    } else {
+        DT_DISPATCH(p->rank, dt_proj_fwd_kernel<R, float><<<grid, 256, 0, (hipStream_t)stream>>>(
+            (const float *)p->dt, p->dt_rs, p->weight, p->w_ld, (float *)p->delta, p->delta_rs, p->dim, T4, dpb););
+    }
     MMU_HIP_LAUNCH_CHECK("dt_proj_fwd");
     return 0;
 }
@@ -221,8 +254,13 @@ extern "C" int mmu_dt_proj_bwd(const mmu_dt_proj_params *p, void *stream) {
     const long T4 = p->tokens / 4;
     const unsigned bx = (unsigned)((T4 + 255) / 256);
     // here `delta` is the incoming gradient d delta (read) and `dt` receives d dt (written)
-    DT_DISPATCH(p->rank, dt_proj_bwd_kernel<R><<<bx, 256, 0, (hipStream_t)stream>>>(p->delta, p->delta_rs, p->weight, p->w_ld,
-                                                                                     const_cast<float *>(p->dt), p->dt_rs, p->dim, T4););
+    if (p->io_dtype == MMU_DTYPE_BF16) {
+        DT_DISPATCH(p->rank, dt_proj_bwd_kernel<R, bf16_t><<<bx, 256, 0, (hipStream_t)stream>>>(
+            (const bf16_t *)p->delta, p->delta_rs, p->weight, p->w_ld, (bf16_t *)const_cast<void *>(p->dt), p->dt_rs, p->dim, T4););
+    } else {
+        DT_DISPATCH(p->rank, dt_proj_bwd_kernel<R, float><<<bx, 256, 0, (hipStream_t)stream>>>(
+            (const float *)p->delta, p->delta_rs, p->weight, p->w_ld, (float *)const_cast<void *>(p->dt), p->dt_rs, p->dim, T4););
+    }
     MMU_HIP_LAUNCH_CHECK("dt_proj_bwd");
     return 0;
 }
@@ -244,8 +282,13 @@ extern "C" int mmu_x_proj_fwd(const mmu_x_proj_params *p, void *stream) {
     const unsigned bx = (unsigned)(nb < cap ? nb : cap);
     const size_t lds = sizeof(float) * (size_t)p->dim * ((p->rows + 3) & ~3);
     MMU_CHECK(lds <= 64 * 1024, "x_proj_fwd: the weight does not fit 64 KiB of LDS");
-    XP_DISPATCH(p->rows, x_proj_fwd_kernel<RW><<<bx, 256, lds, (hipStream_t)stream>>>(p->x, p->x_rs, p->weight, p->w_ld, p->x_dbl,
-                                                                                       p->x_dbl_rs, p->dim, T4););
+    if (p->io_dtype == MMU_DTYPE_BF16) {
+        XP_DISPATCH(p->rows, x_proj_fwd_kernel<RW, bf16_t><<<bx, 256, lds, (hipStream_t)stream>>>(
+            (const bf16_t *)p->x, p->x_rs, p->weight, p->w_ld, (bf16_t *)p->x_dbl, p->x_dbl_rs, p->dim, T4););
+    } else {
+        XP_DISPATCH(p->rows, x_proj_fwd_kernel<RW, float><<<bx, 256, lds, (hipStream_t)stream>>>(
+            (const float *)p->x, p->x_rs, p->weight, p->w_ld, (float *)p->x_dbl, p->x_dbl_rs, p->dim, T4););
+    }
     MMU_HIP_LAUNCH_CHECK("x_proj_fwd");
     return 0;
 }
@@ -259,8 +302,13 @@ extern "C" int mmu_x_proj_bwd(const mmu_x_proj_params *p, void *stream) {
     const unsigned bx = (unsigned)(nb < cap ? nb : cap);
     const size_t lds = sizeof(float) * (size_t)p->dim * ((p->rows + 3) & ~3);
     MMU_CHECK(lds <= 64 * 1024, "x_proj_bwd: the weight does not fit 64 KiB of LDS");
-    XP_DISPATCH(p->rows, x_proj_bwd_kernel<RW><<<bx, 256, lds, (hipStream_t)stream>>>(p->x_dbl, p->x_dbl_rs, p->weight, p->w_ld,
-                                                                                       const_cast<float *>(p->x), p->x_rs, p->dim, T4););
+    if (p->io_dtype == MMU_DTYPE_BF16) {
+        XP_DISPATCH(p->rows, x_proj_bwd_kernel<RW, bf16_t><<<bx, 256, lds, (hipStream_t)stream>>>(
+            (const bf16_t *)p->x_dbl, p->x_dbl_rs, p->weight, p->w_ld, (bf16_t *)const_cast<void *>(p->x), p->x_rs, p->dim, T4););
+    } else {
+        XP_DISPATCH(p->rows, x_proj_bwd_kernel<RW, float><<<bx, 256, lds, (hipStream_t)stream>>>(
+            (const float *)p->x_dbl, p->x_dbl_rs, p->weight, p->w_ld, (float *)const_cast<void *>(p->x), p->x_rs, p->dim, T4););
+    }
     MMU_HIP_LAUNCH_CHECK("x_proj_bwd");
     return 0;
 }

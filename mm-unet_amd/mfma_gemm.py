@@ -129,7 +129,7 @@ def dt_proj(weight, dt_rows, delta=None):
     dim, rank = weight.shape
     T = dt_rows.shape[1]
     if delta is None:
-        delta = torch.empty((dim, T), device=dt_rows.device, dtype=torch.float32)
+        delta = torch.empty((dim, T), device=dt_rows.device, dtype=dt_rows.dtype)
     _dt_proj_call("mmu_dt_proj_fwd", weight, dt_rows, delta)
     return delta
 
@@ -142,24 +142,34 @@ def dt_proj_input_grad(weight, ddelta, ddt_rows):
     return ddt_rows
 
 
+def _io_rows_ok(a, b):
+    """Token rows of csrc/dt_proj.hip's streaming kernels: two 2-D matrices of ONE dtype with unit token stride -- float32
+    (outside autocast; 16-byte aligned) or bfloat16 (8-byte aligned; read and written natively, float32 arithmetic)."""
+    if a.dtype != b.dtype or not all(t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 for t in (a, b)):
+        return False
+    if a.dtype == torch.bfloat16:
+        return LOWP and a.data_ptr() % 8 == 0 and b.data_ptr() % 8 == 0
+    return (a.dtype == torch.float32 and not torch.is_autocast_enabled() and a.data_ptr() % 16 == 0
+            and b.data_ptr() % 16 == 0)
+
+
 def dt_proj_supported(weight, dt_rows, delta):
     return (ENABLED and weight.dim() == 2 and 1 <= weight.shape[1] <= 8 and weight.stride(1) == 1
-            and not torch.is_autocast_enabled()
-            and all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in (weight, dt_rows, delta))
-            and all(t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
-                    for t in (dt_rows, delta))
+            and all(t is not None and t.is_cuda for t in (weight, dt_rows, delta)) and weight.dtype == torch.float32
+            and _io_rows_ok(dt_rows, delta)
             and dt_rows.shape[1] % 4 == 0 and dt_rows.shape[1] == delta.shape[1]
             and dt_rows.shape[0] == weight.shape[1] and delta.shape[0] == weight.shape[0])
 
 
 def _dt_proj_call(name, weight, dt_rows, delta):
     if not dt_proj_supported(weight, dt_rows, delta):
-        raise RuntimeError(f"{name}: float32 tokens-last matrices with unit token stride, rank <= 8, tokens % 4 == 0 required")
+        raise RuntimeError(f"{name}: float32 (or, both, bfloat16) tokens-last matrices with unit token stride, float32 weight, rank <= 8, tokens % 4 == 0 required")
     p = _lib.DtProjParams()
     p.rank, p.dim, p.tokens = weight.shape[1], weight.shape[0], dt_rows.shape[1]
     p.dt, p.dt_rs = dt_rows.data_ptr(), dt_rows.stride(0)
     p.weight, p.w_ld = weight.data_ptr(), weight.stride(0)
     p.delta, p.delta_rs = delta.data_ptr(), delta.stride(0)
+    p.io_dtype = _lib.dtype_code(delta)
     with torch.cuda.device(delta.device):
         _lib.check(getattr(_lib.lib(), name)(p, _lib.stream_of(delta)))
 
@@ -170,21 +180,21 @@ X_PROJ_ROWS = (33, 34, 36, 40)   # dt_rank + 2 * d_state the streaming x_proj ke
 def x_proj_supported(weight, x, x_dbl):
     return (ENABLED and weight.dim() == 2 and weight.shape[0] in X_PROJ_ROWS and weight.stride(1) == 1
             and weight.shape[1] % 4 == 0 and weight.shape[1] <= 1024 and weight.shape[1] * ((weight.shape[0] + 3) // 4 * 4) * 4 <= 65536
-            and not torch.is_autocast_enabled()
-            and all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in (weight, x, x_dbl))
-            and all(t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (x, x_dbl))
+            and all(t is not None and t.is_cuda for t in (weight, x, x_dbl)) and weight.dtype == torch.float32
+            and _io_rows_ok(x, x_dbl)
             and x.shape[1] % 4 == 0 and x.shape[1] == x_dbl.shape[1] and x.shape[0] == weight.shape[1]
             and x_dbl.shape[0] == weight.shape[0])
 
 
 def _x_proj_call(name, weight, x, x_dbl):
     if not x_proj_supported(weight, x, x_dbl):
-        raise RuntimeError(f"{name}: float32 tokens-last matrices with unit token stride, rows in {X_PROJ_ROWS}, dim % 4 == 0 required")
+        raise RuntimeError(f"{name}: float32 (or, both, bfloat16) tokens-last matrices with unit token stride, float32 weight, rows in {X_PROJ_ROWS}, dim % 4 == 0 required")
     p = _lib.XProjParams()
     p.rows, p.dim, p.tokens = weight.shape[0], weight.shape[1], x.shape[1]
     p.x, p.x_rs = x.data_ptr(), x.stride(0)
     p.weight, p.w_ld = weight.data_ptr(), weight.stride(0)
     p.x_dbl, p.x_dbl_rs = x_dbl.data_ptr(), x_dbl.stride(0)
+    p.io_dtype = _lib.dtype_code(x)
     with torch.cuda.device(x.device):
         _lib.check(getattr(_lib.lib(), name)(p, _lib.stream_of(x)))
 
@@ -194,7 +204,7 @@ def x_proj(weight, x, x_dbl=None):
     selective_scan_interface.py:181)."""
     _lib.require_gpu(weight, x)
     if x_dbl is None:
-        x_dbl = torch.empty((weight.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
+        x_dbl = torch.empty((weight.shape[0], x.shape[1]), device=x.device, dtype=x.dtype)
     _x_proj_call("mmu_x_proj_fwd", weight, x, x_dbl)
     return x_dbl
 

@@ -214,17 +214,23 @@ def _own_proj_ok(conv_m, x_proj_weight, delta_proj_weight, tokens):
             and mfma_gemm.tokens_supported(conv_m, x_proj_weight, delta_proj_weight))
 
 
-LOWP_PROJ = os.environ.get("MMUNET_LOWP_PROJ", "0") != "0"
+# bf16 activations (autocast): 0 = x_proj / dt_proj and their input gradients as library GEMMs on bf16 casts of the
+# weights; 1 = x_proj on gemm_tokens' bf16 form, the rest on csrc/dt_proj.hip's streaming kernels (bf16 rows, float32
+# weights and arithmetic); 2 = x_proj on the streaming kernel too
+LOWP_PROJ = int(os.environ.get("MMUNET_LOWP_PROJ", "1"))
 
 
 def _lowp_proj_ok(conv_m, x_proj_weight, delta_proj_weight):
-    """x_proj / dt_proj (and their input gradients) of bf16 activations on gemm_tokens' bf16 form: float32 contiguous
-    weights, a tokens-last bf16 conv matrix with unit token stride.  OFF by default (MMUNET_LOWP_PROJ=1): measured on
-    config 3, the 512-token kernel loses on these skinny products (36 / 4 rows, inner 4: 59.76 ms per step against 58.46
-    with the library) -- they want bf16 forms of csrc/dt_proj.hip's streaming kernels, which do not exist yet."""
-    return (LOWP_PROJ and conv_m.dtype == torch.bfloat16 and conv_m.dim() == 2 and conv_m.shape[1] % 4 == 0
-            and x_proj_weight.is_contiguous() and delta_proj_weight.is_contiguous()
-            and delta_proj_weight.dtype == torch.float32 and mfma_gemm.tokens_lowp_supported(x_proj_weight, conv_m))
+    """x_proj / dt_proj (and their input gradients) of bf16 activations on this library's kernels: float32 contiguous
+    weights, a tokens-last bf16 conv matrix with unit token stride.  (With all four products on gemm_tokens' 512-token
+    kernel this lost to the library -- 59.76 against 58.46 ms per step of config 3: the products with 4 rows / inner 4
+    pad to its tiles; they are streaming kernels now.)"""
+    return (LOWP_PROJ > 0 and conv_m.dtype == torch.bfloat16 and conv_m.dim() == 2 and conv_m.shape[1] % 4 == 0
+            and conv_m.stride(0) % 4 == 0 and conv_m.data_ptr() % 8 == 0
+            and x_proj_weight.is_contiguous() and delta_proj_weight.is_contiguous() and 1 <= delta_proj_weight.shape[1] <= 8
+            and delta_proj_weight.dtype == torch.float32 and mfma_gemm.tokens_lowp_supported(x_proj_weight, conv_m)
+            and x_proj_weight.shape[0] in mfma_gemm.X_PROJ_ROWS and x_proj_weight.shape[1] % 4 == 0
+            and x_proj_weight.shape[1] * 4 * ((x_proj_weight.shape[0] + 3) // 4 * 4) <= 65536)
 
 
 def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj_bias, C_proj_bias):
@@ -243,15 +249,17 @@ def _project(conv1d_out, x_proj_weight, delta_proj_weight, d_state, B, C, B_proj
         mfma_gemm.gemm_tokens(x_proj_weight, conv_m, x_dblT, x_proj_weight.shape[0], dim, T, 1, conv_m.stride(0), 0, T, 0)
         delta = mfma_gemm.dt_proj(delta_proj_weight, x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
     elif _lowp_proj_ok(conv_m, x_proj_weight, delta_proj_weight):
-        # bf16 activations (autocast), float32 weights: both projections on gemm_tokens' bf16 form -- one launch each
-        # instead of a cast of the weight + a library GEMM; products exact to the weight's 16 bits instead of its 8
+        # bf16 activations (autocast), float32 weights: x_proj on gemm_tokens' bf16 form, dt_proj (inner dimension 4) as
+        # a streaming kernel -- one launch each instead of a cast of the weight + a library GEMM; products exact to the
+        # weight's 16 / 24 bits instead of its 8
         T = batch * L
         rows = x_proj_weight.shape[0]
         x_dblT = torch.empty((rows, T), device=conv_m.device, dtype=torch.bfloat16)
-        mfma_gemm.gemm_tokens(x_proj_weight, conv_m, x_dblT, rows, dim, T, 1, conv_m.stride(0), 0, T, 0)
-        delta_m = torch.empty((dim, T), device=conv_m.device, dtype=torch.bfloat16)
-        mfma_gemm.gemm_tokens(delta_proj_weight, x_dblT[:r], delta_m, dim, r, T, 1, T, 0, T, 0)
-        delta = delta_m.view(dim, batch, L).permute(1, 0, 2)
+        if LOWP_PROJ == 2:
+            mfma_gemm.x_proj(x_proj_weight, conv_m, x_dblT)
+        else:
+            mfma_gemm.gemm_tokens(x_proj_weight, conv_m, x_dblT, rows, dim, T, 1, conv_m.stride(0), 0, T, 0)
+        delta = mfma_gemm.dt_proj(delta_proj_weight, x_dblT[:r]).view(dim, batch, L).permute(1, 0, 2)
     else:
         if x_proj_weight.dtype != conv_m.dtype:      # (a caller that kept its float32 weights for the branch above)
             x_proj_weight, delta_proj_weight = x_proj_weight.to(conv_m.dtype), delta_proj_weight.to(conv_m.dtype)
@@ -289,13 +297,14 @@ def _project_backward(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_w
            and mfma_gemm.dt_proj_supported(delta_proj_weight, dx_dblT[:r], ddelta_m)
            and mfma_gemm.tokens_supported(dconv_m, dx_dblT) and dconv_m.stride(1) == 1 and dconv_m.stride(0) % 4 == 0)
     lowp = (not own and in_place and dx_dblT.is_contiguous() and _lowp_proj_ok(conv_m, x_proj_weight, delta_proj_weight)
-            and mfma_gemm.tokens_lowp_supported(x_proj_weight, ddelta_m, dconv_m, dx_dblT))
+            and mfma_gemm.tokens_lowp_supported(x_proj_weight, ddelta_m, dconv_m, dx_dblT)
+            and mfma_gemm.dt_proj_supported(delta_proj_weight, dx_dblT[:r], ddelta_m)
+            and mfma_gemm.x_proj_supported(x_proj_weight, dconv_m, dx_dblT))
     T = batch * L
     if own:
         mfma_gemm.dt_proj_input_grad(delta_proj_weight, ddelta_m, dx_dblT[:r])  # (r, B*L)         (:274)
     elif lowp:
-        mfma_gemm.gemm_tokens(delta_proj_weight, ddelta_m, dx_dblT[:r], r, dim, T, 1, ddelta_m.stride(0), 0, T, 0,
-                              transposed_weight=True)
+        mfma_gemm.dt_proj_input_grad(delta_proj_weight, ddelta_m, dx_dblT[:r])
     else:
         if delta_proj_weight.dtype != ddelta_m.dtype:
             x_proj_weight, delta_proj_weight = x_proj_weight.to(ddelta_m.dtype), delta_proj_weight.to(ddelta_m.dtype)
@@ -304,8 +313,7 @@ def _project_backward(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_w
     if own:
         mfma_gemm.x_proj_input_grad_add(x_proj_weight, dx_dblT, dconv_m)   # d conv += W_x^T d x_dbl, in place   (:277)
     elif lowp:
-        mfma_gemm.gemm_tokens(x_proj_weight, dx_dblT, dconv_m, dim, x_proj_weight.shape[0], T, 1, T, 0, dconv_m.stride(0), 0,
-                              transposed_weight=True, accumulate=True)
+        mfma_gemm.x_proj_input_grad_add(x_proj_weight, dx_dblT, dconv_m)   # (bf16 rows, float32 sums, one rounding)
     elif in_place:
         dconv_m.addmm_(x_proj_weight.t(), dx_dblT)                          # in place              (:277)
     else:  # dconv1d_out was not [D][B][L]; keep it correct anyway

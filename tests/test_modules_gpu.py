@@ -1067,6 +1067,39 @@ def test_x_proj_stream_kernels_vs_fp64(case):
     close(dx, (base.double() + W.double().t() @ g.double()).float(), 1e-5, 2e-5, "d conv")
 
 
+@pytest.mark.parametrize("case", [(4, 128, 36, 4096 + 512), (1, 8, 33, 1028), (8, 64, 40, 2048)])
+def test_dt_and_x_proj_stream_kernels_bfloat16_rows_vs_fp64(case):
+    """csrc/dt_proj.hip with bfloat16 token rows (autocast: read / written natively, float32 weights and arithmetic):
+    all four kernels against float64 on the SAME bf16 inputs, within ONE bf16 rounding of the result; rows past the
+    operands stay untouched."""
+    from mm_unet_amd.mfma_gemm import dt_proj, dt_proj_input_grad, x_proj, x_proj_input_grad_add
+    R, D, RW, T = case
+    gen = torch.Generator().manual_seed(R + D + T)
+    bf = lambda t: t.to(torch.bfloat16)   # noqa: E731
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / r.abs().max())   # noqa: E731
+    Wdt = torch.randn(D, R, generator=gen)
+    xdbl = bf(torch.randn(R + 32, T, generator=gen))
+    delta = dt_proj(Wdt.to(DEV), xdbl.to(DEV)[:R])
+    assert delta.dtype == torch.bfloat16
+    assert rel(delta, Wdt.double() @ xdbl[:R].double()) < 4e-3
+    g = bf(torch.randn(D, T, generator=gen))
+    dx = torch.full((R + 32, T), 7.0, device=DEV, dtype=torch.bfloat16)
+    dt_proj_input_grad(Wdt.to(DEV), g.to(DEV), dx[:R])
+    assert rel(dx[:R], Wdt.double().t() @ g.double()) < 4e-3
+    assert bool((dx[R:] == 7.0).all()), "rows past dt_rank were written"
+    Wx = torch.randn(RW, D, generator=gen) / D ** 0.5
+    x = bf(torch.randn(D, T, generator=gen))
+    out = x_proj(Wx.to(DEV), x.to(DEV))
+    assert out.dtype == torch.bfloat16 and rel(out, Wx.double() @ x.double()) < 4e-3
+    gx = bf(torch.randn(RW, T, generator=gen))
+    base = bf(torch.randn(D, T, generator=gen))
+    dc = base.clone().to(DEV)
+    x_proj_input_grad_add(Wx.to(DEV), gx.to(DEV), dc)
+    assert rel(dc, base.double() + Wx.double().t() @ gx.double()) < 4e-3
+    with pytest.raises(RuntimeError):      # mixed row dtypes are refused, not converted
+        dt_proj(Wdt.to(DEV), xdbl.to(DEV)[:R], torch.empty(D, T, device=DEV))
+
+
 def test_mamba_inner_own_projections_match_library_route(monkeypatch):
     """x_proj / dt_proj and their input gradients on the build's kernels (gemm_tokens with a zero-padded 36-row image,
     dt_proj.hip) against the same mamba_inner with library GEMMs (MMUNET_OWN_PROJ off): output and every gradient."""
