@@ -22,6 +22,7 @@
 // The input gradient is the same kernel on flipped / transposed weights (prepared by the same small kernel).
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,7 +44,12 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
     hi = pack_bf16(a, b);
     const float ah = __builtin_bit_cast(float, hi << 16), bh = __builtin_bit_cast(float, hi & 0xffff0000u);
-    lo = pack_bf16(a - ah, b - bh);
+    // two plain v_sub_f32: left to the compiler the pair becomes ONE v_pk_add_f32, which beside MFMAs costs more than
+    // the two it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+    float la, lb;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(ah));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(bh));
+    lo = pack_bf16(la, lb);
 }
 
 // weights [Cout][Cin][3][3] f32 (flip = 0) or, for the input gradient, the ORIGINAL weight [Cin_eff][Cout_eff][3][3]
@@ -220,37 +226,54 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
     for (int it = 0; it < niter; ++it) {
         const unsigned char *cur = lds + (it & 1) * STAGE_BYTES;
         const unsigned char *patch_hi = cur, *patch_lo = cur + PATCH_BYTES, *w_hi = cur + 2 * PATCH_BYTES;
-        if (!late) {
+        // MMU_CONV3_EXP (timing experiments only, results are wrong): 1 = no staging and no loads inside the loop,
+        // 2 = no MFMAs / fragment reads, 3 = staging but no global loads
+#ifndef MMU_CONV3_EXP
+#define MMU_CONV3_EXP 0
+#endif
+        if (!late && MMU_CONV3_EXP != 1) {
             stage(lds + ((it + 1) & 1) * STAGE_BYTES);
-            prefetch();
+            if (MMU_CONV3_EXP != 3) prefetch();
         }
         // keep the loads ahead of the MFMAs: left alone, the scheduler sinks them behind the last MFMA (their
         // destination registers then double as fragment registers) and every chunk waits out a full memory latency
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
+        // fragments of shift s + 1 are read while the MFMAs of shift s run (two register sets; left to itself the compiler
+        // keeps ONE set and issues the next shift's reads behind the last MFMA: an exposed LDS round trip per shift)
+        bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+        auto frags = [&](int s, int set) {
             const int kh = s / 3, kw = s - 3 * kh;
-            bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int off = s * (2 * 64 * 16) + m * (32 * 16) + a_lane;
-                ah[m] = *reinterpret_cast<const bf16x8 *>(w_hi + off);
-                al[m] = *reinterpret_cast<const bf16x8 *>(w_hi + WCH_BYTES + off);
+                ah[set][m] = *reinterpret_cast<const bf16x8 *>(w_hi + off);
+                al[set][m] = *reinterpret_cast<const bf16x8 *>(w_hi + WCH_BYTES + off);
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int off = ((wv + kh) * PW + n * 32 + kw) * 16 + b_lane;
-                bh[n] = *reinterpret_cast<const bf16x8 *>(patch_hi + off);
-                if constexpr (!XB) bl[n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
+                bh[set][n] = *reinterpret_cast<const bf16x8 *>(patch_hi + off);
+                if constexpr (!XB) bl[set][n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
+            }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < (MMU_CONV3_EXP == 2 ? 0 : 9); ++s) {
+            const int c = s & 1;
+            if (s + 1 < 9) {
+                frags(s + 1, c ^ 1);
+                __builtin_amdgcn_sched_barrier(0);   // the reads are issued BEFORE this shift's MFMAs
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                    if constexpr (!XB) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c][m], bh[c][n], acc[m][n], 0, 0, 0);
+                    if constexpr (!XB) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][m], bl[c][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][m], bh[c][n], acc[m][n], 0, 0, 0);
                 }
+            // pin the order: this shift's MFMAs stay behind the reads of the next one
+            if (s + 1 < 9) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (late) {
@@ -303,6 +326,242 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_kernel(ConvArgsM p) {
     }
 }
 
+
+// ---- the same convolution with the staging and the matrix work on DIFFERENT waves (round 4) ---------------------------
+// Measured on the kernel above (tools/ab_conv3.sh; [8, 256, 64, 64] -> 256, no HBM influence): 110 us in all = 76 us
+// with the staging and loads removed + 38 us with the MFMAs removed -- the two phases add up, nothing overlaps: the two
+// waves of a SIMD run the same program between the same barriers, so both convert / store the next chunk, then both queue
+// on the matrix pipe.  (Staggering one of them behind its MFMAs put a branch around the loads -- a vmcnt(0) at each
+// merge -- and gained nothing.)  Here waves 0-3 (one per SIMD) are PRODUCERS: global loads two chunks ahead, hi/lo
+// split, LDS stores of the next chunk; waves 4-7 (one per SIMD) are CONSUMERS: two tile rows each, 128 accumulator
+// registers, 24 MFMAs per 3x3 shift on 12 fragment reads (the weights' fragments serve both rows), the next step's
+// fragments read while the current MFMAs run.  Two separate loops with the same number of barriers: a SIMD's vector
+// issue slots between the consumer's MFMAs (24 of every 32 cycles) carry the producer's instructions.
+template <bool XB>
+__global__ __launch_bounds__(512, 2) void conv3x3_mfma_ws_kernel(ConvArgsM p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch = p.Cin / CK;
+    const long HW = (long)p.H * p.W;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, each with its own L2.  XCD k takes the k-th
+    // contiguous eighth of the tile list (x fastest, then y: at 256 x 256 one whole image), so the halo rows and the
+    // 128-byte lines that neighbouring tiles share are fetched from HBM once, not once per XCD.
+    const int G = gridDim.x;
+    const bool xcd_map = (G & 7) == 0;
+    const int per_xcd = (p.total_tiles + 7) >> 3;
+    const int t_first = xcd_map ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t_step = xcd_map ? G >> 3 : G;
+    const int t_end = xcd_map ? min((((int)blockIdx.x & 7) + 1) * per_xcd, p.total_tiles) : p.total_tiles;
+    const int ntl = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;   // tiles of this workgroup
+    const int niter = ntl * nch;
+    constexpr int NPX = PH * PW, NITEM = 2 * NPX;
+    auto decode = [&](int tj, int &b, int &cot, int &y0, int &x0) {
+        int t = t_first + tj * t_step;
+        t = t < p.total_tiles ? t : p.total_tiles - 1;   // (a workgroup without tiles decodes the last one and loads it once)
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        t /= p.tiles_y;
+        cot = t % p.ncot;
+        b = t / p.ncot;
+        y0 = ty * TH;
+        x0 = tx * TW;
+    };
+    if (wv < 4) {
+        // ================= producers: 256 threads stage a chunk (1,320 patch items: 6 rounds; 2,304 weight pieces: 9)
+        constexpr int PR = (NITEM + 255) / 256, WR = 2304 / 256;
+        int ipr[PR], ipc[PR], ihalf[PR], ioff[PR];
+#pragma unroll
+        for (int k = 0; k < PR; ++k) {
+            int q = tid + 256 * k;
+            const bool live = q < NITEM;
+            q = live ? q : NITEM - 1;
+            ihalf[k] = q / NPX;
+            const int pxi = q - ihalf[k] * NPX;
+            ipr[k] = pxi / PW;
+            ipc[k] = pxi - ipr[k] * PW;
+            ioff[k] = live ? ihalf[k] * (NPX * 16) + pxi * 16 : -1;
+        }
+        unsigned px[PR][8];
+        v4u wr[WR];
+        int l_tj = 0, l_ch = 0, l_b, l_cot, l_y0, l_x0;
+        decode(0, l_b, l_cot, l_y0, l_x0);
+        // Patch loads through a buffer resource: base = (batch item, chunk) in SGPRs, the channel row j as a scalar
+        // offset, ONE per-lane byte offset per item (non-negative by construction) -- no 64-bit address arithmetic per
+        // load -- and padded pixels ask for offset 2^31 >= num_records, which the hardware answers with 0: no mask
+        // instructions either.  (The host checks 9 H W elements < 2^31 bytes.)
+        constexpr unsigned ES = XB ? 2 : 4, OOB = 0x80000000u;
+        auto prefetch = [&]() {
+            const char *base = (const char *)p.x + ((long)l_b * p.Cin + l_ch * CK) * HW * ES;
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, (int)OOB, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < PR; ++k) {
+                const int gy = l_y0 - 1 + ipr[k], gx = l_x0 - 1 + ipc[k];
+                const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const unsigned voff = inb ? ((unsigned)(8 * ihalf[k]) * (unsigned)HW + (unsigned)(gy * p.W + gx)) * ES : OOB;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (XB)
+                        px[k][j] = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, (unsigned)(j * HW) * ES, 0);
+                    else
+                        px[k][j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)(j * HW) * ES, 0);
+                }
+            }
+            const v4u *ws = reinterpret_cast<const v4u *>(p.wp + ((long)l_cot * nch + l_ch) * (2 * 9 * 64 * 16));
+#pragma unroll
+            for (int j = 0; j < WR; ++j) wr[j] = ws[tid + 256 * j];
+            if (l_ch + 1 < nch) {           // past the end the stream re-reads the last chunk (nothing consumes it)
+                ++l_ch;
+            } else if (l_tj + 1 < ntl) {
+                l_ch = 0;
+                ++l_tj;
+                decode(l_tj, l_b, l_cot, l_y0, l_x0);
+            }
+        };
+        auto stage = [&](unsigned char *buf) {
+            unsigned char *patch_hi = buf, *patch_lo = buf + PATCH_BYTES, *w_hi = buf + 2 * PATCH_BYTES;
+#pragma unroll
+            for (int k = 0; k < PR; ++k) {
+                unsigned hw[4], lw[4];
+                if constexpr (XB) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hw[j] = px[k][2 * j] | (px[k][2 * j + 1] << 16);
+                    const v4u h = {hw[0], hw[1], hw[2], hw[3]};
+                    if (ioff[k] >= 0) *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        split2(__uint_as_float(px[k][2 * j]), __uint_as_float(px[k][2 * j + 1]), hw[j], lw[j]);
+                    const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+                    if (ioff[k] >= 0) {
+                        *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
+                        *reinterpret_cast<v4u *>(patch_lo + ioff[k]) = l;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WR; ++j) *reinterpret_cast<v4u *>(w_hi + (tid + 256 * j) * 16) = wr[j];
+        };
+        prefetch();
+        stage(lds);
+        prefetch();
+        MMU_LDS_BARRIER();
+        for (int it = 0; it < niter; ++it) {
+            if (MMU_CONV3_EXP != 1) {        // (timing experiments: see the kernel above)
+                stage(lds + ((it + 1) & 1) * STAGE_BYTES);
+                if (MMU_CONV3_EXP != 3) prefetch();
+            }
+            MMU_LDS_BARRIER();
+        }
+    } else {
+        // ================= consumers: wave cw owns tile rows 2 cw, 2 cw + 1
+        const int cw = wv - 4;
+        f32x16 acc[2][2][2];   // [row][m][n]
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
+        const int a_lane = (lane >> 5) * (64 * 16) + (lane & 31) * 16;        // weights: [shift][plane][64 co][8 ci]
+        const int b_lane = (lane >> 5) * (NPX * 16) + (lane & 31) * 16;       // patch:   [plane][pixel][8 ci]
+        MMU_LDS_BARRIER();
+        int c_tj = 0, c_ch = 0;
+        for (int it = 0; it < niter; ++it) {
+            const unsigned char *cur = lds + (it & 1) * STAGE_BYTES;
+            const unsigned char *patch_hi = cur, *patch_lo = cur + PATCH_BYTES, *w_hi = cur + 2 * PATCH_BYTES;
+            bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];   // [register set][m or n]
+            auto frag_a = [&](int s, int set) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int off = s * (2 * 64 * 16) + m * (32 * 16) + a_lane;
+                    ah[set][m] = *reinterpret_cast<const bf16x8 *>(w_hi + off);
+                    al[set][m] = *reinterpret_cast<const bf16x8 *>(w_hi + WCH_BYTES + off);
+                }
+            };
+            auto frag_b = [&](int s, int r, int set) {
+                const int kh = s / 3, kw = s - 3 * kh;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int off = ((2 * cw + r + kh) * PW + n * 32 + kw) * 16 + b_lane;
+                    bh[set][n] = *reinterpret_cast<const bf16x8 *>(patch_hi + off);
+                    if constexpr (!XB) bl[set][n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
+                }
+            };
+            frag_a(0, 0);
+            frag_b(0, 0, 0);
+#pragma unroll
+            for (int step = 0; step < (MMU_CONV3_EXP == 2 ? 0 : 18); ++step) {      // step = (shift, row)
+                const int s = step >> 1, r = step & 1, ca = s & 1, cb = step & 1;
+                if (step + 1 < 18) {
+                    const int ns = (step + 1) >> 1, nr = (step + 1) & 1;
+                    frag_b(ns, nr, cb ^ 1);
+                    if (nr == 0) frag_a(ns, ca ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);   // the next step's reads are issued before this step's MFMAs
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ca][m], bh[cb][n], acc[r][m][n], 0, 0, 0);
+                        if constexpr (!XB)
+                            acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][m], bl[cb][n], acc[r][m][n], 0, 0, 0);
+                        acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][m], bh[cb][n], acc[r][m][n], 0, 0, 0);
+                    }
+                if (step + 1 < 18) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++c_ch == nch) {
+                // ---- tile done: C layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+                int b, cot, y0, x0;
+                decode(c_tj, b, cot, y0, x0);
+                float bv[2][16];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) bv[m][e] = 0.f;
+                if (p.bias != nullptr) {
+                    const float *bp = p.bias + cot * 64 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) bv[m][e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int oy = y0 + 2 * cw + r;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const int ox = x0 + n * 32 + (lane & 31);
+                            if (oy < p.H && ox < p.W) {
+                                const long o0 = ((long)b * p.Cout + cot * 64 + m * 32 + 4 * (lane >> 5)) * HW + (long)oy * p.W + ox;
+                                if constexpr (XB) {
+                                    bf16_t *op = (bf16_t *)p.out + o0;
+#pragma unroll
+                                    for (int e = 0; e < 16; ++e)
+                                        op[((e & 3) + 8 * (e >> 2)) * HW] = from_f32<bf16_t>(acc[r][m][n][e] + bv[m][e]);
+                                } else {
+                                    float *op = (float *)p.out + o0;
+#pragma unroll
+                                    for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * HW] = acc[r][m][n][e] + bv[m][e];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
+                        }
+                }
+                c_ch = 0;
+                ++c_tj;
+            }
+            MMU_LDS_BARRIER();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t mmu_conv3x3_mfma_workspace_bytes(int in_channels, int out_channels) {
@@ -327,11 +586,17 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     conv3x3_mfma_prep_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(
         p->weight, (unsigned short *)p->workspace, p->in_channels, p->out_channels, p->transposed ? 1 : 0);
     MMU_HIP_LAUNCH_CHECK("conv3x3_mfma(prep)");
-    static unsigned long long attr_mask = 0, attr_mask_b = 0;  // per device
-    if (hipError_t e = xb ? mmu_set_lds_once(conv3x3_mfma_kernel<true>, LDS_BYTES, attr_mask_b)
-                          : mmu_set_lds_once(conv3x3_mfma_kernel<false>, LDS_BYTES, attr_mask);
-        e != hipSuccess)
-        return mmu_fail("conv3x3_mfma: LDS attribute: %s", hipGetErrorString(e));
+    // MMU_CONV3_WS=0: the kernel whose eight waves all stage and multiply (A/B; default: producer / consumer waves)
+    static const bool ws = []() { const char *e = getenv("MMU_CONV3_WS"); return !e || e[0] != '0'; }();
+    static unsigned long long attr_mask = 0, attr_mask_b = 0, attr_mask_ws = 0, attr_mask_ws_b = 0;  // per device
+    hipError_t e;
+    if (ws)
+        e = xb ? mmu_set_lds_once(conv3x3_mfma_ws_kernel<true>, LDS_BYTES, attr_mask_ws_b)
+               : mmu_set_lds_once(conv3x3_mfma_ws_kernel<false>, LDS_BYTES, attr_mask_ws);
+    else
+        e = xb ? mmu_set_lds_once(conv3x3_mfma_kernel<true>, LDS_BYTES, attr_mask_b)
+               : mmu_set_lds_once(conv3x3_mfma_kernel<false>, LDS_BYTES, attr_mask);
+    if (e != hipSuccess) return mmu_fail("conv3x3_mfma: LDS attribute: %s", hipGetErrorString(e));
     ConvArgsM a;
     a.x = p->input; a.wp = (const unsigned short *)p->workspace; a.bias = p->bias; a.out = p->out;
     a.B = p->batch; a.Cin = p->in_channels; a.Cout = p->out_channels; a.H = p->height; a.W = p->width;
@@ -340,10 +605,15 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     a.ncot = p->out_channels / 64;
     const long total = (long)a.tiles_x * a.tiles_y * a.ncot * p->batch;
     MMU_CHECK(total < (1L << 30), "conv3x3_mfma: too many tiles");
+    MMU_CHECK(9L * p->height * p->width * (xb ? 2 : 4) < (1L << 31), "conv3x3_mfma: 9 * height * width elements must stay below 2 GiB");
     a.total_tiles = (int)total;
     const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;   // one workgroup (158 KB of LDS) per CU
-    if (xb)
+    if (ws && xb)
+        conv3x3_mfma_ws_kernel<true><<<grid, 512, LDS_BYTES, st>>>(a);
+    else if (ws)
+        conv3x3_mfma_ws_kernel<false><<<grid, 512, LDS_BYTES, st>>>(a);
+    else if (xb)
         conv3x3_mfma_kernel<true><<<grid, 512, LDS_BYTES, st>>>(a);
     else
         conv3x3_mfma_kernel<false><<<grid, 512, LDS_BYTES, st>>>(a);
