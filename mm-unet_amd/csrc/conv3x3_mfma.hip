@@ -529,30 +529,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_ws_kernel(ConvArgsM p) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) bv[m][e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
                 }
+                // stores through a buffer resource too: base = (batch item, channel tile) in SGPRs, the channel row as a
+                // scalar offset, one byte offset per lane and pixel; lanes outside the image store to offset 2^31 (dropped)
+                constexpr unsigned ES = XB ? 2 : 4, OOB = 0x80000000u;
+                char *obase = (char *)p.out + ((long)b * p.Cout + cot * 64) * HW * ES;
+                const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)OOB, 0x00020000);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int oy = y0 + 2 * cw + r;
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int n = 0; n < 2; ++n) {
+                        const int ox = x0 + n * 32 + (lane & 31);
+                        const unsigned voff = (oy < p.H && ox < p.W)
+                                                  ? ((unsigned)(4 * (lane >> 5)) * (unsigned)HW + (unsigned)(oy * p.W + ox)) * ES
+                                                  : OOB;
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            const int ox = x0 + n * 32 + (lane & 31);
-                            if (oy < p.H && ox < p.W) {
-                                const long o0 = ((long)b * p.Cout + cot * 64 + m * 32 + 4 * (lane >> 5)) * HW + (long)oy * p.W + ox;
-                                if constexpr (XB) {
-                                    bf16_t *op = (bf16_t *)p.out + o0;
+                        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-                                    for (int e = 0; e < 16; ++e)
-                                        op[((e & 3) + 8 * (e >> 2)) * HW] = from_f32<bf16_t>(acc[r][m][n][e] + bv[m][e]);
-                                } else {
-                                    float *op = (float *)p.out + o0;
-#pragma unroll
-                                    for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * HW] = acc[r][m][n][e] + bv[m][e];
-                                }
+                            for (int e = 0; e < 16; ++e) {
+                                const unsigned soff = (unsigned)((m * 32 + (e & 3) + 8 * (e >> 2)) * HW) * ES;
+                                const float v = acc[r][m][n][e] + bv[m][e];
+                                if constexpr (XB)
+                                    __builtin_amdgcn_raw_buffer_store_b16(from_f32<bf16_t>(v).bits, ors, voff, soff, 0);
+                                else
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, voff, soff, 0);
+                                acc[r][m][n][e] = 0.f;
                             }
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
                         }
+                    }
                 }
                 c_ch = 0;
                 ++c_tj;
@@ -587,7 +591,9 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
         p->weight, (unsigned short *)p->workspace, p->in_channels, p->out_channels, p->transposed ? 1 : 0);
     MMU_HIP_LAUNCH_CHECK("conv3x3_mfma(prep)");
     // MMU_CONV3_WS=0: the kernel whose eight waves all stage and multiply (A/B; default: producer / consumer waves)
-    static const bool ws = []() { const char *e = getenv("MMU_CONV3_WS"); return !e || e[0] != '0'; }();
+    static const bool ws_on = []() { const char *e = getenv("MMU_CONV3_WS"); return !e || e[0] != '0'; }();
+    // (its buffer-resource addressing keeps a channel tile of one batch item within 32-bit byte offsets)
+    const bool ws = ws_on && 64L * p->height * p->width * (xb ? 2 : 4) < (1L << 31);
     static unsigned long long attr_mask = 0, attr_mask_b = 0, attr_mask_ws = 0, attr_mask_ws_b = 0;  // per device
     hipError_t e;
     if (ws)
@@ -605,7 +611,6 @@ extern "C" int mmu_conv3x3_mfma(const mmu_conv3x3_mfma_params *p, void *stream) 
     a.ncot = p->out_channels / 64;
     const long total = (long)a.tiles_x * a.tiles_y * a.ncot * p->batch;
     MMU_CHECK(total < (1L << 30), "conv3x3_mfma: too many tiles");
-    MMU_CHECK(9L * p->height * p->width * (xb ? 2 : 4) < (1L << 31), "conv3x3_mfma: 9 * height * width elements must stay below 2 GiB");
     a.total_tiles = (int)total;
     const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;   // one workgroup (158 KB of LDS) per CU
