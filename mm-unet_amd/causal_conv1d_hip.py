@@ -86,7 +86,8 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
     p.workspace = ws.data_ptr()
     # inside a deferred.Scope the ordered sum of the per-block partials runs with all the others of the backward pass --
     # unless the result is converted (read) right here
-    same = weight.dtype == torch.float32 and (bias_ is None or bias_.dtype == torch.float32)
+    same = (weight.dtype == torch.float32 and (bias_ is None or bias_.dtype == torch.float32)
+            and deferred.may_defer(weight, bias_))   # (parameters, or contiguous views of them: deferred.py's contract)
     with torch.cuda.device(x.device):
         if same:
             _lib.check(_lib.lib().mmu_causal_conv1d_bwd(p, _lib.stream_of(x)))

@@ -88,6 +88,7 @@ class Conv3x3MfmaFn(torch.autograd.Function):
         out = _run(x, weight, bias, weight.shape[1], weight.shape[0], False)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.may_defer = deferred.may_defer(weight, bias)
         ctx.lowp = x.dtype != torch.float32
         return out
 
@@ -106,7 +107,8 @@ class Conv3x3MfmaFn(torch.autograd.Function):
                                                              False, [0, 0], 1, [True, False, False])[0]
             need_b = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1] and LOWP_WGRAD and wgrad_supported(x, cout) and g.data_ptr() % 8 == 0:
-                dw = _wgrad(x, g, cout)
+                with deferred.guard(ctx.may_defer):
+                    dw = _wgrad(x, g, cout)
                 db = g.sum(dim=(0, 2, 3), dtype=torch.float32) if need_b else None
             elif ctx.needs_input_grad[1] or need_b:
                 _, dw, db = torch.ops.aten.convolution_backward(
@@ -125,8 +127,9 @@ class Conv3x3MfmaFn(torch.autograd.Function):
                                                          [True, False, False])[0]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and wgrad_supported(x, cout) and g.data_ptr() % 16 == 0:
-            dw = _wgrad(x, g, cout)
-            db = conv_s2._bias_grad(g) if need_b else None   # (streaming channel sums, csrc/sum_parts.hip)
+            with deferred.guard(ctx.may_defer):
+                dw = _wgrad(x, g, cout)
+                db = conv_s2._bias_grad(g) if need_b else None   # (streaming channel sums, csrc/sum_parts.hip)
         elif ctx.needs_input_grad[1] or need_b:
             _, dw, db = torch.ops.aten.convolution_backward(
                 g, x, weight, [cout] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,

@@ -153,6 +153,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_conv3x3_small_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, wt)
         ctx.has_bias = bias is not None
+        ctx.may_defer = deferred.may_defer(weight, bias)
         ctx.wshape = tuple(weight.shape)
         ctx.slot = slot
         if isinstance(slot, SharedGrad):
@@ -209,7 +210,7 @@ class Conv3x3SmallFn(torch.autograd.Function):
                 nws = _lib.lib().mmu_conv3x3_small_wgrad_workspace_floats(B, Cin, CO, H, W)
                 ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
                 p.workspace = _lib.ptr(ws)
-                with torch.cuda.device(x.device):
+                with torch.cuda.device(x.device), deferred.guard(ctx.may_defer):
                     _lib.check(_lib.lib().mmu_conv3x3_small_bwd(p, _lib.stream_of(x)))
                 deferred.keep(ws)   # (deferred.Scope: the sum over the row blocks runs later)
             else:

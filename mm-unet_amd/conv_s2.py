@@ -106,6 +106,7 @@ class ConvS2Fn(torch.autograd.Function):
         out = _run(False, x, weight, bias, cin, cout, k, (ho, wo))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.may_defer = deferred.may_defer(weight, bias)
         return out
 
     @staticmethod
@@ -123,12 +124,14 @@ class ConvS2Fn(torch.autograd.Function):
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             if _wgrad_ok(cin, cout, g.shape[3], g):
-                dw = _wgrad(x, g, k)
+                with deferred.guard(ctx.may_defer):
+                    dw = _wgrad(x, g, k)
             else:
                 dw = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
         if need_b:
-            db = _bias_grad(g)
+            with deferred.guard(ctx.may_defer):
+                db = _bias_grad(g)
         return dx, dw, db
 
 
@@ -148,6 +151,7 @@ class ConvT2Fn(torch.autograd.Function):
         out = _run(True, x, weight, bias, cin, cout, 4, (2 * x.shape[2], 2 * x.shape[3]))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.may_defer = deferred.may_defer(weight, bias)
         return out
 
     @staticmethod
@@ -163,12 +167,14 @@ class ConvT2Fn(torch.autograd.Function):
                 dx = torch.nn.functional.conv2d(g, weight, None, stride=2, padding=1)
         if ctx.needs_input_grad[1]:
             if _wgrad_ok(cout, cin, x.shape[3], x):
-                dw = _wgrad(g, x, 4)                # [C_low = Cin_T][C_high = Cout_T][4][4]
+                with deferred.guard(ctx.may_defer):
+                    dw = _wgrad(g, x, 4)            # [C_low = Cin_T][C_high = Cout_T][4][4]
             else:
                 dw = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1,
                                                          [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _bias_grad(g)
+            with deferred.guard(ctx.may_defer):
+                db = _bias_grad(g)
         return dx, dw, db
 
 

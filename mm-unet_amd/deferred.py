@@ -17,6 +17,8 @@ Eagerly ``launch()`` binds by itself.  Contract: the weight gradients are leaves
 pass it captures and CHECKS the contract there (``Scope.verify_destinations``: every result address inside exactly one
 ``param.grad``, none twice).  Process-wide: one scope at a time.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -54,6 +56,45 @@ def take_prescaled(t):
 
 def clear_prescaled():
     _PRESCALED.clear()
+
+
+_GUARD = os.environ.get("MMUNET_DEFER_GUARD", "1") != "0"   # "0": every wrapper defers unconditionally (A/B only)
+
+
+def may_defer(*weights):
+    """The leaf-parameter contract, checked where a wrapper is called: every tensor whose gradient the call produces is a
+    float32 LEAF (a parameter) or a contiguous view of one -- its gradient then goes into ``param.grad`` untouched (view
+    backward ops move no data).  A copy, a cast, a permuted or re-parametrised weight has its gradient READ by autograd on
+    the spot (clone / permute / add): such a call must sum at once -- wrap it in ``guard(False)``."""
+    if not _GUARD:
+        return True
+    for w in weights:
+        if w is None:
+            continue
+        if w.dtype != torch.float32:
+            return False
+        if w.is_leaf:
+            continue
+        base = w._base
+        if base is None or not base.is_leaf or not w.is_contiguous():
+            return False
+    return True
+
+
+class guard:
+    """``with guard(ok):`` -- defers inside an open scope only when ``ok`` (= :func:`may_defer` at forward time)."""
+
+    def __init__(self, ok):
+        self._p = None if ok else paused()
+
+    def __enter__(self):
+        if self._p is not None:
+            self._p.__enter__()
+
+    def __exit__(self, *exc):
+        if self._p is not None:
+            self._p.__exit__(*exc)
+        return False
 
 
 class paused:

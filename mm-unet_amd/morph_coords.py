@@ -79,6 +79,7 @@ class ZigzagInProjFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_zigzag_inproj_fwd(p, _lib.stream_of(offset)))
         ctx.save_for_backward(offset, w)
         ctx.w_dtype = w_in.dtype
+        ctx.may_defer = deferred.may_defer(w)
         ctx.slot = slot
         if slot is not None:
             slot.armed = bool(ctx.needs_input_grad[0]) and ctx.off_dtype == torch.float32
@@ -104,7 +105,7 @@ class ZigzagInProjFn(torch.autograd.Function):
         p.accumulate_doffset = int(parked is not None)
         ws = _bwd_workspace(offset, K)     # per-block partials: ordered sums (no atomics, no zero fill), deferrable
         p.workspace = ws.data_ptr()
-        with torch.cuda.device(offset.device):
+        with torch.cuda.device(offset.device), deferred.guard(ctx.may_defer):
             _lib.check(_lib.lib().mmu_zigzag_inproj_bwd(p, _lib.stream_of(offset)))
         deferred.keep(ws)
         return doff.to(ctx.off_dtype), dw.to(ctx.w_dtype), None
@@ -130,6 +131,7 @@ class CoordsOutProjFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_coords_outproj_fwd(p, _lib.stream_of(offset)))
         ctx.save_for_backward(offset, oz, w, al)
         ctx.scope, ctx.w_dtype, ctx.a_shape, ctx.a_dtype = scope, w_out.dtype, altho.shape, altho.dtype
+        ctx.may_defer = deferred.may_defer(w, al)
         ctx.slot = slot
         return y
 
@@ -150,7 +152,7 @@ class CoordsOutProjFn(torch.autograd.Function):
             da.data_ptr()
         ws = _bwd_workspace(offset, K)
         p.workspace = ws.data_ptr()
-        with torch.cuda.device(offset.device):
+        with torch.cuda.device(offset.device), deferred.guard(ctx.may_defer):
             _lib.check(_lib.lib().mmu_coords_outproj_bwd(p, _lib.stream_of(offset)))
         deferred.keep(ws)
         doff = doff.to(ctx.off_dtype)

@@ -46,6 +46,7 @@ class Conv1x1OneFn(torch.autograd.Function):
             _lib.check(_lib.lib().mmu_conv1x1_one_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, weight, scale)
         ctx.has_bias = bias is not None
+        ctx.may_defer = deferred.may_defer(weight, bias)
         return out
 
     @staticmethod
@@ -67,7 +68,7 @@ class Conv1x1OneFn(torch.autograd.Function):
         p.input, p.weight, p.dout = x.data_ptr(), weight.data_ptr(), g.data_ptr()
         p.dinput, p.dweight, p.dbias, p.workspace = _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), ws.data_ptr()
         p.scale = _lib.ptr(scale)
-        with torch.cuda.device(x.device):
+        with torch.cuda.device(x.device), deferred.guard(ctx.may_defer):
             _lib.check(L.mmu_conv1x1_one_bwd(p, _lib.stream_of(x)))
         deferred.keep(ws)    # (inside a deferred.Scope the sum over the workgroups' partials runs later)
         return dx, dw, db, None
@@ -115,6 +116,7 @@ class Conv7x7SmallFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().mmu_conv7x7_2to1_fwd(p, _lib.stream_of(x)))
         ctx.save_for_backward(x, weight)
+        ctx.may_defer = deferred.may_defer(weight)
         return out
 
     @staticmethod
@@ -131,7 +133,7 @@ class Conv7x7SmallFn(torch.autograd.Function):
         p.batch, p.height, p.width = B, H, W
         p.input, p.weight, p.dout = x.data_ptr(), weight.data_ptr(), g.data_ptr()
         p.dinput, p.dweight, p.workspace = _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(ws)
-        with torch.cuda.device(x.device):
+        with torch.cuda.device(x.device), deferred.guard(ctx.may_defer):
             _lib.check(L.mmu_conv7x7_2to1_bwd(p, _lib.stream_of(x)))
         deferred.keep(ws)    # (inside a deferred.Scope the sum over the blocks' partials runs later)
         return dx, dw

@@ -195,7 +195,7 @@ def _post_small(ddelta, x_dblT, dx_dblT, conv1d_out, dconv1d_out, x_proj_weight,
     p.conv_out, p.dconv_out = conv1d_out.data_ptr(), dconv1d_out.data_ptr()
     p.x_proj_weight, p.dt_proj_weight = wx.data_ptr(), wdt.data_ptr()
     p.dx_proj_weight, p.ddt_proj_weight, p.workspace = dwx.data_ptr(), dwdt.data_ptr(), ws.data_ptr()
-    with torch.cuda.device(ddelta.device):
+    with torch.cuda.device(ddelta.device), deferred.guard(deferred.may_defer(x_proj_weight, delta_proj_weight)):
         _lib.check(_lib.lib().mmu_mamba_post_small(p, _lib.stream_of(ddelta)))
     deferred.keep(ws)    # (inside a deferred.Scope the sum over the workgroups' partials runs later)
     return dwx, dwdt

@@ -2126,6 +2126,49 @@ def test_deferred_scope_verification_catches_a_weight_used_twice():
         run(True)
 
 
+def test_deferred_guard_sums_at_once_for_weights_that_are_not_parameters():
+    """deferred.may_defer / deferred.guard: inside an open scope a wrapper whose weight is NOT a leaf parameter (here a
+    scaled copy, as a re-parametrisation or a cast would be) must run its final sum at once -- autograd reads that
+    gradient right away (MulBackward) -- while the same call on the parameter itself records a deferred job.  Checked on
+    three wrappers (3 x 3 / 6-channel, stride-2 matrix-core, 1 x 1 -> 1) against the same graph without a scope."""
+    import torch.nn.functional as F
+    from mm_unet_amd import conv3x3_small, conv_s2, deferred, pointwise
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    x6 = torch.randn(2, 6, 32, 32, device=DEV, generator=gen)
+    x64 = torch.randn(2, 64, 32, 32, device=DEV, generator=gen)
+    x16 = torch.randn(2, 16, 32, 32, device=DEV, generator=gen)
+    c3 = torch.nn.Conv2d(6, 6, 3, padding=1).to(DEV)
+    cs = torch.nn.Conv2d(64, 64, 3, stride=2, padding=1).to(DEV)
+    c1 = torch.nn.Conv2d(16, 1, 1).to(DEV)
+    assert deferred.may_defer(c3.weight, c3.bias) and deferred.may_defer(c3.weight.view(6, 54), None)
+    assert not deferred.may_defer(c3.weight * 1.0) and not deferred.may_defer(c3.weight.permute(1, 0, 2, 3))
+    assert not deferred.may_defer(c3.weight.to(torch.bfloat16))
+
+    def loss(scale):
+        w3, ws, w1 = (c.weight * scale if scale is not None else c.weight for c in (c3, cs, c1))
+        return (conv3x3_small.conv3x3_small(x6, w3, c3.bias).square().mean()
+                + conv_s2.conv_s2(x64, ws, cs.bias).square().mean()
+                + pointwise.conv1x1_one(x16, w1, c1.bias).square().mean())
+
+    params = [q for c in (c3, cs, c1) for q in c.parameters()]
+    for scale in (None, 1.5):
+        for q in params:
+            q.grad = None
+        loss(scale).backward()
+        want = [q.grad.clone() for q in params]
+        for q in params:
+            q.grad = None
+        scope = deferred.Scope(DEV)
+        with scope:
+            loss(scale).backward()
+            scope.launch()
+        torch.cuda.synchronize()
+        for q, w in zip(params, want):
+            assert torch.equal(q.grad, w), f"scale {scale}: a gradient differs inside the scope"
+        if scale is not None:   # the weight gradients were summed on the spot; only the (leaf) biases may have deferred
+            assert scope.n_jobs <= 3, scope.n_jobs
+
+
 def test_deferred_conv_weight_gradient_sums_are_bit_identical():
     """deferred.Scope, the matrix-core convolutions: weight gradients of the 3 x 3 convolution, of the stride-2 convolution
     and its transpose (tile partials, kind 6), their bias gradients (batch partials, kind 3) and the 7 x 7 two-channel
