@@ -226,6 +226,7 @@ void mmu_deferred_begin(void);
 void mmu_deferred_pause(int paused);   /* 1: launchers reduce at once again (scope stays open); 0: record again */
 void mmu_deferred_end(void);
 int mmu_deferred_jobs(int64_t *rows_out, int max_jobs);
+int mmu_deferred_job_workgroups(const int64_t *row);   /* workgroups of mmu_deferred_launch one recorded row (8 x int64) needs */
 int mmu_deferred_launch(const int64_t *table, const int32_t *work, int n_work, void *stream);
 
 /* ---- AdamW over many tensors in one launch (csrc/adamw_multi.hip) -------------------------------------------------------

@@ -246,7 +246,7 @@ EXPORTS = (
     "mmu_tri_split", "mmu_tri_combine", "mmu_tri_conv_fwd", "mmu_tri_conv_bwd", "mmu_tri_conv_bwd_workspace_floats",
     "mmu_tri_gate_fwd", "mmu_tri_gate_bwd", "mmu_stem7_workspace_bytes", "mmu_stem7_fwd", "mmu_stem7_wgrad", "mmu_conv3x3_mfma", "mmu_conv3x3_mfma_workspace_bytes", "mmu_conv3x3_wgrad_mfma",
     "mmu_conv3x3_wgrad_mfma_workspace_floats", "mmu_gemm_tokens_mfma", "mmu_dt_proj_fwd", "mmu_dt_proj_bwd", "mmu_x_proj_fwd", "mmu_x_proj_bwd",
-    "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_adamw_multi", "mmu_coords_bwd_workspace_floats", "mmu_channel_sum", "mmu_scatter_stride2", "mmu_dice_bce_fwd", "mmu_dice_bce_bwd", "mmu_dice_bce_workspace_floats", "mmu_gated_mul_bwd_workspace_floats", "mmu_cbam_gate_fwd", "mmu_cbam_gate_bwd", "mmu_maxpool3s2_fwd", "mmu_maxpool3s2_bwd_codes", "mmu_deferred_begin", "mmu_deferred_pause", "mmu_deferred_end", "mmu_deferred_jobs", "mmu_deferred_launch", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
+    "mmu_gemm_tokens_workspace_bytes", "mmu_gemm_tokens_prepare_batch", "mmu_morph_mix_sample_fwd", "mmu_morph_mix_sample_bwd", "mmu_adamw_multi", "mmu_coords_bwd_workspace_floats", "mmu_channel_sum", "mmu_scatter_stride2", "mmu_dice_bce_fwd", "mmu_dice_bce_bwd", "mmu_dice_bce_workspace_floats", "mmu_gated_mul_bwd_workspace_floats", "mmu_cbam_gate_fwd", "mmu_cbam_gate_bwd", "mmu_maxpool3s2_fwd", "mmu_maxpool3s2_bwd_codes", "mmu_deferred_begin", "mmu_deferred_pause", "mmu_deferred_end", "mmu_deferred_jobs", "mmu_deferred_job_workgroups", "mmu_deferred_launch", "mmu_gemm_nt_splitk", "mmu_gemm_nt_splitk_workspace_floats", "mmu_mamba_pre_small", "mmu_mamba_post_small",
     "mmu_mamba_post_small_workspace_floats", "mmu_norm_fused_workspace_floats", "mmu_norm_fused_fwd", "mmu_norm_fused_bwd",
     "mmu_cbam_stats_fwd", "mmu_cbam_stats_bwd", "mmu_gated_mul_fwd", "mmu_gated_mul_bwd", "mmu_conv7x7_2to1_fwd", "mmu_conv7x7_2to1_bwd", "mmu_conv7x7_2to1_workspace_floats", "mmu_maxpool3s2_bwd", "mmu_sum_parts", "mmu_conv1x1_one_fwd", "mmu_conv1x1_one_bwd", "mmu_conv1x1_one_workspace_floats",
     "mmu_mamba_small_supported", "mmu_mamba_small_parts", "mmu_mamba_small_bwd_workspace_floats",
@@ -339,6 +339,8 @@ def lib():
     L.mmu_deferred_end.argtypes = []
     L.mmu_deferred_jobs.restype = ctypes.c_int
     L.mmu_deferred_jobs.argtypes = [_vp, ctypes.c_int]
+    L.mmu_deferred_job_workgroups.restype = ctypes.c_int
+    L.mmu_deferred_job_workgroups.argtypes = [_vp]
     L.mmu_deferred_launch.restype = ctypes.c_int
     L.mmu_deferred_launch.argtypes = [_vp, _vp, ctypes.c_int, _vp]
     L.mmu_gemm_tokens_prepare_batch.restype = ctypes.c_int

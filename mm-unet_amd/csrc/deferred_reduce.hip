@@ -21,7 +21,7 @@ bool g_active = false;
 std::vector<long> g_rows;   // 8 per job
 
 constexpr int ROW = 8;
-#define MMU_DEFER_REP 8   /* mirrored by deferred.py (REP) */
+#define MMU_DEFER_REP 8
 
 // The kinds with 64 results per block of 1,024 threads (0, 1, 3, 6) take REP consecutive blocks per workgroup and load
 // for all of them before reducing any: at one block per workgroup the launch was 86,000 workgroups each waiting for one
@@ -462,6 +462,29 @@ extern "C" int mmu_deferred_jobs(int64_t *rows_out, int max_jobs) {
         for (long i = 0; i < (long)m * ROW; ++i) rows_out[i] = g_rows[i];
     }
     return n;
+}
+
+// Workgroups deferred_reduce_kernel needs for one recorded job (its row as mmu_deferred_jobs returns it): the block
+// decomposition of each kind lives HERE, next to the job_* bodies that index by it -- the host builds its (job, block)
+// work list from this, not from a copy of the formulas.
+extern "C" int mmu_deferred_job_workgroups(const int64_t *r) {
+    if (r == nullptr) return 0;
+    long nb;
+    switch ((int)r[0]) {
+        case 0: nb = (r[4] + 63) / 64; break;                                  // gemm_nt slab sums: 64 results per block
+        case 1: nb = (r[4] * ((r[6] * 10 + 3) & ~3L) + 63) / 64; break;        // conv3x3_small: padded rows of 10 taps
+        case 2: nb = (r[5] + 15) / 16; break;                                  // conv1d-style: 16 channels per workgroup
+        case 4: case 5: nb = r[6] & 0xffffffffL; break;                        // scan parameters: a workgroup per channel
+        case 6: {                                                              // conv tile partials: a thread per element
+            const long tco = r[7] & 0xffffffffL, tci = r[7] >> 32;
+            nb = (r[5] * ((r[3] >> 32) / tco) * tco * tci * (r[4] ? 4 : 9) + 1023) / 1024;
+            break;
+        }
+        case 7: nb = (r[4] + 15) / 16; break;                                  // wave rows
+        default: nb = (r[7] + 63) / 64; break;                                 // (3) row sums
+    }
+    if (r[0] == 0 || r[0] == 1 || r[0] == 3) nb = (nb + REP - 1) / REP;        // REP blocks of 64 results per workgroup
+    return (int)nb;
 }
 
 extern "C" int mmu_deferred_launch(const int64_t *table, const int32_t *work, int n_work, void *stream) {

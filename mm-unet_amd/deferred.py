@@ -112,7 +112,6 @@ class paused:
 
 class Scope:
     MAX_JOBS = 1024
-    REP = 8
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -152,24 +151,8 @@ class Scope:
         L.mmu_deferred_jobs(ctypes.cast(buf, ctypes.c_void_p), n)
         rows = [[buf[8 * j + k] for k in range(8)] for j in range(n)]
         work = []
-        for j, r in enumerate(rows):
-            if r[0] == 0:
-                nb = (r[4] + 63) // 64
-            elif r[0] == 1:
-                nb = (r[4] * ((r[6] * 10 + 3) & ~3) + 63) // 64
-            elif r[0] == 2:
-                nb = (r[5] + 15) // 16
-            elif r[0] in (4, 5):
-                nb = r[6] & 0xffffffff          # a workgroup per channel
-            elif r[0] == 6:     # one thread per element of the partial tiles: n_cic * (Cout / TCO) * TCO * TCI * S
-                tco, tci = r[7] & 0xffffffff, r[7] >> 32
-                nb = (r[5] * ((r[3] >> 32) // tco) * tco * tci * (4 if r[4] else 9) + 1023) // 1024
-            elif r[0] == 7:
-                nb = (r[4] + 15) // 16
-            else:
-                nb = (r[7] + 63) // 64
-            if r[0] in (0, 1, 3):               # REP blocks of 64 results per workgroup (MMU_DEFER_REP)
-                nb = (nb + self.REP - 1) // self.REP
+        for j in range(n):      # (the block decomposition of each kind is the library's: csrc/deferred_reduce.hip)
+            nb = L.mmu_deferred_job_workgroups(ctypes.byref(buf, 8 * 8 * j))
             work += [[j, b] for b in range(nb)]
         if len(work) > self.work.shape[0]:
             raise RuntimeError(f"deferred.Scope: {len(work)} workgroups, work list holds {self.work.shape[0]}")

@@ -163,6 +163,27 @@ def test_mamba_type_resolution():
         Mamba(8, bimamba_type="v9")
 
 
+def test_deferred_job_workgroups_come_from_the_library():
+    """mmu_deferred_job_workgroups: the block decomposition of every job kind is computed where the kernel that indexes
+    by it lives (csrc/deferred_reduce.hip), no GPU needed.  Spot values: 64 results per block and 8 blocks per workgroup
+    for the gemm_nt slab sums; 16 channels per workgroup for the conv1d-style sums; a workgroup per channel for the scan."""
+    import ctypes
+    from mm_unet_amd import _lib
+    L = _lib.lib()
+
+    def wg(row):
+        buf = (ctypes.c_int64 * 8)(*row)
+        return L.mmu_deferred_job_workgroups(ctypes.cast(buf, ctypes.c_void_p))
+
+    assert wg([0, 0, 0, 0, 128 * 64, 5, 0, 0]) == 16          # 8,192 results / 64 / 8
+    assert wg([0, 0, 0, 0, 36 * 128, 5, 0, 0]) == 9
+    assert wg([2, 0, 0, 0, 0, 128, 0, 0]) == 8                # 128 channels / 16
+    assert wg([4, 0, 0, 0, 0, 0, 128 | (7 << 32), 0]) == 128  # low word of field 6: channels
+    assert wg([7, 0, 0, 0, 98, 0, 0, 0]) == 7
+    assert wg([6, 0, 0, (64 << 32) | 64, 0, 2, 16, 64 | (32 << 32)]) == 36    # 2 x 1 x 64 x 32 x 9 / 1,024
+    assert L.mmu_deferred_job_workgroups(None) == 0
+
+
 def test_deferred_scope_rejects_results_that_are_not_parameter_gradients():
     """deferred.Scope.verify_destinations (TrainStep runs it on what the capture recorded): a deferred sum whose result
     is not inside exactly one param.grad -- a non-leaf weight's gradient, a second gradient of the same parameter --
