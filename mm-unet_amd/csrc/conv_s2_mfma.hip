@@ -28,6 +28,7 @@
 // wave = tile row, 2 x 2 tiles of 32 x 32, persistent workgroups, double-buffered LDS stage, loads two chunks ahead).
 #include "mmu_common.h"
 #include "../../include/mmunet_amd.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -53,7 +54,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
     hi = pack_bf16(a, b);
     const float ah = __builtin_bit_cast(float, hi << 16), bh = __builtin_bit_cast(float, hi & 0xffff0000u);
-    lo = pack_bf16(a - ah, b - bh);
+    float la, lb;   // two plain v_sub_f32 (the compiler's v_pk_add_f32 costs more beside MFMAs: conv3x3_mfma.hip)
+    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(ah));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(bh));
+    lo = pack_bf16(la, lb);
 }
 
 // Weight source wsrc[X][Y][K][K] float32.
@@ -294,6 +298,219 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_kernel(S2Args p) {
     }
 }
 
+// ---- the same two forms with the staging and the matrix work on DIFFERENT waves (round 4; conv3x3_mfma.hip has the
+// measurements behind it: with all eight waves staging and then multiplying, the two phases of a chunk ADD).  A chunk here
+// has only 4 shifts (48 MFMAs per wave against the same ~340 staging instructions as the 3 x 3 kernel's 108), so the
+// staging was more than half of the kernel.  Waves 0-3: producers (buffer loads with hardware zero padding two chunks
+// ahead, hi/lo split, LDS stores of the next chunk); waves 4-7: consumers, two tile rows each, the next (shift, row) step's
+// fragments read under the current MFMAs; buffer stores in the epilogue.
+template <int SCATTER>
+__global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
+    using G = Geo<SCATTER>;
+    constexpr int PW = G::PW, NPX = G::NPX, PATCH_BYTES = G::PATCH_BYTES, STAGE_BYTES = G::STAGE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch = p.nch;
+    const long HWi = (long)p.Hi * p.Wi, HWo = (long)p.Ho * p.Wo;
+    const int GD = gridDim.x;
+    const int ntl = (p.total_tiles - (int)blockIdx.x + GD - 1) / GD;   // tiles of this workgroup (>= 1)
+    const int niter = ntl * nch;
+    const int nchp = p.Cin / CK;                                       // chunks per phase (gather)
+    constexpr unsigned OOB = 0x80000000u;
+    auto decode = [&](int tj, int &b, int &cotv, int &y0, int &x0) {
+        int t = (int)blockIdx.x + tj * GD;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        t /= p.tiles_y;
+        cotv = t % p.ncotv;
+        b = t / p.ncotv;
+        y0 = ty * TH;
+        x0 = tx * TW;
+    };
+    if (wv < 4) {
+        // ================= producers
+        constexpr int NITEM = 2 * NPX, PR = (NITEM + 255) / 256, WR = 4;   // 2 x 8,192 B of weights = 1,024 x 16 B
+        int ipr[PR], ipc[PR], ihalf[PR], ioff[PR];
+#pragma unroll
+        for (int k = 0; k < PR; ++k) {
+            int q = tid + 256 * k;
+            const bool live = q < NITEM;
+            q = live ? q : NITEM - 1;
+            ihalf[k] = q / NPX;
+            const int pxi = q - ihalf[k] * NPX;
+            ipr[k] = pxi / PW;
+            ipc[k] = pxi - ipr[k] * PW;
+            ioff[k] = live ? ihalf[k] * (NPX * 16) + pxi * 16 : -1;
+        }
+        unsigned px[PR][8];
+        v4u wr[WR];
+        int l_tj = 0, l_ch = 0, l_b, l_cotv, l_y0, l_x0;
+        decode(0, l_b, l_cotv, l_y0, l_x0);
+        auto prefetch = [&]() {
+            int py = 0, pxx = 0, cbase = l_ch * CK;
+            if (!SCATTER) {   // chunk -> (phase, channel base)
+                const int ph = l_ch / nchp;
+                cbase = (l_ch - ph * nchp) * CK;
+                py = ph >> 1;
+                pxx = ph & 1;
+            }
+            const float *base = p.x + ((long)l_b * p.Cin + cbase) * HWi;
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)OOB, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < PR; ++k) {
+                const int gy = SCATTER ? l_y0 - 1 + ipr[k] : 2 * (l_y0 + ipr[k]) - py;
+                const int gx = SCATTER ? l_x0 - 1 + ipc[k] : 2 * (l_x0 + ipc[k]) - pxx;
+                const bool inb = gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+                const unsigned voff = inb ? ((unsigned)(8 * ihalf[k]) * (unsigned)HWi + (unsigned)(gy * p.Wi + gx)) * 4u : OOB;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) px[k][j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)(j * HWi) * 4u, 0);
+            }
+            const v4u *ws = reinterpret_cast<const v4u *>(p.wp + ((long)l_cotv * nch + l_ch) * (2 * NS * 64 * 16));
+#pragma unroll
+            for (int j = 0; j < WR; ++j) wr[j] = ws[tid + 256 * j];
+            if (l_ch + 1 < nch) {
+                ++l_ch;
+            } else if (l_tj + 1 < ntl) {
+                l_ch = 0;
+                ++l_tj;
+                decode(l_tj, l_b, l_cotv, l_y0, l_x0);
+            }
+        };
+        auto stage = [&](unsigned char *buf) {
+            unsigned char *patch_hi = buf, *patch_lo = buf + PATCH_BYTES, *w_hi = buf + 2 * PATCH_BYTES;
+#pragma unroll
+            for (int k = 0; k < PR; ++k) {
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split2(__uint_as_float(px[k][2 * j]), __uint_as_float(px[k][2 * j + 1]), hw[j], lw[j]);
+                const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+                if (ioff[k] >= 0) {
+                    *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
+                    *reinterpret_cast<v4u *>(patch_lo + ioff[k]) = l;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WR; ++j) *reinterpret_cast<v4u *>(w_hi + (tid + 256 * j) * 16) = wr[j];
+        };
+        prefetch();
+        stage(lds);
+        prefetch();
+        MMU_LDS_BARRIER();
+        for (int it = 0; it < niter; ++it) {
+            stage(lds + ((it + 1) & 1) * STAGE_BYTES);
+            prefetch();
+            MMU_LDS_BARRIER();
+        }
+    } else {
+        // ================= consumers: wave cw owns tile rows 2 cw, 2 cw + 1
+        const int cw = wv - 4;
+        f32x16 acc[2][2][2];   // [row][m][n]
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][m][n][e] = 0.f;
+        const int a_lane = (lane >> 5) * (64 * 16) + (lane & 31) * 16;        // weights: [shift][plane][64 co][8 ci]
+        const int b_lane = (lane >> 5) * (NPX * 16) + (lane & 31) * 16;       // patch:   [plane][pixel][8 ci]
+        MMU_LDS_BARRIER();
+        int c_tj = 0, c_ch = 0;
+        int c_b, c_cotv, c_y0, c_x0;
+        decode(0, c_b, c_cotv, c_y0, c_x0);
+        for (int it = 0; it < niter; ++it) {
+            const unsigned char *cur = lds + (it & 1) * STAGE_BYTES;
+            const unsigned char *patch_hi = cur, *patch_lo = cur + PATCH_BYTES, *w_hi = cur + 2 * PATCH_BYTES;
+            // scatter: the tile's output phase moves the 2 x 2 window inside the (8 + 2) x (64 + 2) patch
+            const int q = SCATTER ? c_cotv / p.ncot : 0;
+            const int qy = q >> 1, qx = q & 1;
+            bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];   // [register set][m or n]
+            auto frag_a = [&](int s, int set) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int off = s * (2 * 64 * 16) + m * (32 * 16) + a_lane;
+                    ah[set][m] = *reinterpret_cast<const bf16x8 *>(w_hi + off);
+                    al[set][m] = *reinterpret_cast<const bf16x8 *>(w_hi + WCH_BYTES + off);
+                }
+            };
+            auto frag_b = [&](int s, int r, int set) {
+                const int dy = s >> 1, dx = s & 1;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int off = ((2 * cw + r + dy + qy) * PW + n * 32 + dx + qx) * 16 + b_lane;
+                    bh[set][n] = *reinterpret_cast<const bf16x8 *>(patch_hi + off);
+                    bl[set][n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
+                }
+            };
+            frag_a(0, 0);
+            frag_b(0, 0, 0);
+#pragma unroll
+            for (int step = 0; step < 2 * NS; ++step) {      // step = (shift, row)
+                const int s = step >> 1, r = step & 1, ca = s & 1, cb = step & 1;
+                if (step + 1 < 2 * NS) {
+                    const int ns = (step + 1) >> 1, nr = (step + 1) & 1;
+                    frag_b(ns, nr, cb ^ 1);
+                    if (nr == 0) frag_a(ns, ca ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);   // the next step's reads are issued before this step's MFMAs
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ca][m], bh[cb][n], acc[r][m][n], 0, 0, 0);
+                        acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][m], bl[cb][n], acc[r][m][n], 0, 0, 0);
+                        acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][m], bh[cb][n], acc[r][m][n], 0, 0, 0);
+                    }
+                if (step + 1 < 2 * NS) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++c_ch == nch) {
+                // tile done: C layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+                const int cot = SCATTER ? c_cotv - q * p.ncot : c_cotv;
+                float bv[2][16];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) bv[m][e] = 0.f;
+                if (p.bias != nullptr) {
+                    const float *bp = p.bias + cot * 64 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) bv[m][e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
+                }
+                float *obase = p.out + ((long)c_b * p.Cout + cot * 64) * HWo;
+                const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)OOB, 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int vy = c_y0 + 2 * cw + r;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int vx = c_x0 + n * 32 + (lane & 31);
+                        const int oy = SCATTER ? 2 * vy + qy : vy, ox = SCATTER ? 2 * vx + qx : vx;
+                        const bool ok = SCATTER ? (vy < p.Hi && vx < p.Wi) : (vy < p.Ho && vx < p.Wo);
+                        const unsigned voff = ok ? ((unsigned)(4 * (lane >> 5)) * (unsigned)HWo + (unsigned)(oy * p.Wo + ox)) * 4u : OOB;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const unsigned soff = (unsigned)((m * 32 + (e & 3) + 8 * (e >> 2)) * HWo) * 4u;
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r][m][n][e] + bv[m][e]), ors, voff, soff, 0);
+                                acc[r][m][n][e] = 0.f;
+                            }
+                    }
+                }
+                c_ch = 0;
+                ++c_tj;
+                if (c_tj < ntl) decode(c_tj, c_b, c_cotv, c_y0, c_x0);
+            }
+            MMU_LDS_BARRIER();
+        }
+    }
+}
+
 int check(const mmu_conv_s2_params *p, const char *name) {
     MMU_CHECK(p != nullptr, "%s: null params", name);
     MMU_CHECK(p->batch > 0 && p->in_height > 0 && p->in_width > 0, "%s: empty tensor", name);
@@ -341,12 +558,21 @@ int launch(const mmu_conv_s2_params *p, hipStream_t st, const char *name) {
     conv_s2_prep_kernel<SCATTER><<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->weight, (unsigned short *)p->workspace, X,
                                                                                Y, K);
     MMU_HIP_LAUNCH_CHECK(name);
-    static unsigned long long attr_mask = 0;  // per device
-    if (hipError_t e = mmu_set_lds_once(conv_s2_mfma_kernel<SCATTER>, G::LDS_BYTES, attr_mask); e != hipSuccess)
+    // MMU_CONV_S2_WS=0: the kernel whose eight waves all stage and multiply (A/B); the producer / consumer kernel's buffer
+    // addressing keeps 9 input rows-of-channels and a 64-channel output tile of one batch item within 32-bit byte offsets
+    static const bool ws_on = []() { const char *e = getenv("MMU_CONV_S2_WS"); return !e || e[0] != '0'; }();
+    const bool ws = ws_on && 9L * a.Hi * a.Wi * 4 < (1L << 31) && 64L * a.Ho * a.Wo * 4 < (1L << 31);
+    static unsigned long long attr_mask = 0, attr_mask_ws = 0;  // per device
+    if (hipError_t e = ws ? mmu_set_lds_once(conv_s2_mfma_ws_kernel<SCATTER>, G::LDS_BYTES, attr_mask_ws)
+                          : mmu_set_lds_once(conv_s2_mfma_kernel<SCATTER>, G::LDS_BYTES, attr_mask);
+        e != hipSuccess)
         return mmu_fail("%s: LDS attribute: %s", name, hipGetErrorString(e));
     const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;
-    conv_s2_mfma_kernel<SCATTER><<<grid, 512, G::LDS_BYTES, st>>>(a);
+    if (ws)
+        conv_s2_mfma_ws_kernel<SCATTER><<<grid, 512, G::LDS_BYTES, st>>>(a);
+    else
+        conv_s2_mfma_kernel<SCATTER><<<grid, 512, G::LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK(name);
     return 0;
 }
