@@ -853,6 +853,48 @@ def test_conv_s2_mfma_vs_conv2d_fp64(case):
     assert float((b.grad.double() - bd.grad).abs().max()) < 1e-4 * sc(bd.grad), "d bias"
 
 
+def test_eight_wave_convolution_kernels_still_agree_with_fp64():
+    """The kernels the producer / consumer ones replaced stay in the library as the route for maps whose byte offsets do not
+    fit the buffer-resource addressing (64 channels x H x W x 4 >= 2 GiB) and as the A/B partner (MMU_CONV3_WS=0,
+    MMU_CONV_S2_WS=0 -- read once per process, hence a child process): 3 x 3, stride-2 and transposed convolution, forward
+    and input gradient, ragged tiles, float32 and bfloat16, against float64."""
+    import os, subprocess, sys
+    code = r"""
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+from mm_unet_amd import conv3x3_mfma, conv_s2
+torch.manual_seed(7)
+rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max())
+x = torch.randn(2, 64, 40, 132, device="cuda", requires_grad=True)
+w = (torch.randn(128, 64, 3, 3, device="cuda") / 24).requires_grad_()
+b = torch.randn(128, device="cuda")
+o = conv3x3_mfma.conv3x3_mfma(x, w, b); o.square().sum().backward()
+xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+r = F.conv2d(xd, wd, b.double(), padding=1); r.square().sum().backward()
+assert rel(o, r.detach()) < 1e-4 and rel(x.grad, xd.grad) < 1e-4, "3x3"
+with torch.autocast("cuda", dtype=torch.bfloat16):
+    ob = conv3x3_mfma.conv3x3_mfma(x.detach().to(torch.bfloat16), w.detach(), b)
+assert ob.dtype == torch.bfloat16 and rel(ob, F.conv2d(x.detach().to(torch.bfloat16).double(), wd.detach(), b.double(), padding=1)) < 6e-3, "3x3 bf16"
+for k in (3, 4):
+    x = torch.randn(3, 64, 10, 130, device="cuda", requires_grad=True)
+    w = (torch.randn(64, 64, k, k, device="cuda") / (8 * k)).requires_grad_()
+    o = conv_s2.conv_s2(x, w, None); o.square().sum().backward()
+    xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    r = F.conv2d(xd, wd, None, stride=2, padding=1); r.square().sum().backward()
+    assert rel(o, r.detach()) < 1e-4 and rel(x.grad, xd.grad) < 1e-4, "stride 2"
+x = torch.randn(2, 32, 9, 20, device="cuda", requires_grad=True)
+w = (torch.randn(32, 64, 4, 4, device="cuda") / 24).requires_grad_()
+o = conv_s2.conv_transpose_s2(x, w, None); o.square().sum().backward()
+xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+r = F.conv_transpose2d(xd, wd, None, stride=2, padding=1); r.square().sum().backward()
+assert rel(o, r.detach()) < 1e-4 and rel(x.grad, xd.grad) < 1e-4, "transposed"
+print("eight-wave kernels ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMU_CONV3_WS="0", MMU_CONV_S2_WS="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "eight-wave kernels ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 16, 32), (1, 64, 64, 64, 64), (2, 32, 64, 9, 20), (1, 128, 128, 6, 70)])
 def test_conv_transpose_s2_mfma_vs_fp64(case):
     """csrc/conv_s2_mfma.hip, transposed form: ConvTranspose2d(4, stride 2, padding 1) (MMUNet.py:360) forward, input
