@@ -52,7 +52,7 @@ extern "C" {
  * a binding must refuse a library whose mmu_abi_version() differs from the header it was written against.
  *   1: round 1;  2: round 2 appended conv1d_bwd.workspace, morph.in_dtype, resize.dtype, conv3x3s.{in_dtype,
  *   dinput_addend, weight_native}, tri.dtype, norm.{x_dtype, act_dtype};  3: round 3 (fused small-map entry points). */
-#define MMU_ABI_VERSION 11
+#define MMU_ABI_VERSION 12
 int mmu_abi_version(void);
 const char *mmu_last_error(void);
 
@@ -502,11 +502,15 @@ int mmu_conv3x3_wgrad_mfma(const mmu_conv3x3_mfma_params *p, void *stream);
  *            mmu_conv_s2_wgrad_workspace_floats() floats.  Deterministic (no atomics). */
 typedef struct {
     int32_t batch, in_channels, out_channels, in_height, in_width, out_height, out_width, kernel;
-    const float *input;
-    const float *weight;
+    const void *input;      /* io_dtype */
+    const void *weight;     /* float32 weight; mmu_conv_s2_wgrad_mfma: dout, io_dtype */
     const float *bias;      /* [out_channels] or NULL */
-    float *out;
+    void *out;              /* io_dtype; mmu_conv_s2_wgrad_mfma: dweight, float32 */
     void *workspace;
+    int32_t io_dtype;       /* ABI 12: MMU_DTYPE_F32 (0, a zeroed struct) or MMU_DTYPE_BF16 -- bfloat16 activations under
+                             * autocast: input / out bfloat16 with float32 weights and bias, two MFMAs per product, float32
+                             * accumulation (maps within 32-bit byte offsets); weight gradient: x AND dout bfloat16 (dout
+                             * 8-byte aligned), one MFMA per product, dweight float32 */
 } mmu_conv_s2_params;
 
 size_t mmu_conv_s2_workspace_bytes(int in_channels, int out_channels);

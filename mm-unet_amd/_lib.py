@@ -224,7 +224,7 @@ class CoordsParams(ctypes.Structure):
 class ConvS2Params(ctypes.Structure):
     _fields_ = ([(n, _i32) for n in ("batch", "in_channels", "out_channels", "in_height", "in_width", "out_height",
                                      "out_width", "kernel")]
-                + [(n, _vp) for n in ("input", "weight", "bias", "out", "workspace")])
+                + [(n, _vp) for n in ("input", "weight", "bias", "out", "workspace")] + [("io_dtype", _i32)])
 
 
 class MambaSmallParams(ctypes.Structure):
@@ -257,7 +257,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 11   # = MMU_ABI_VERSION of include/mmunet_amd.h
+ABI_VERSION = 12   # = MMU_ABI_VERSION of include/mmunet_amd.h
 
 
 def lib():

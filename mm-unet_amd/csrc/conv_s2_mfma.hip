@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void conv_s2_prep_kernel(const float *__restri
 }
 
 struct S2Args {
-    const float *x;
+    const void *x;            // float32 (bfloat16 in the XB instantiations of the producer / consumer kernel)
     const unsigned short *wp;
     const float *bias;
-    float *out;
+    void *out;                // same type as x
     // Cin / Cout of this operation; Hi x Wi = input map, Ho x Wo = output map; tiles over the Ho x Wo map (gather) or
     // over the Hi x Wi map (scatter: a tile covers one output phase of 8 x 64 positions)
     int B, Cin, Cout, Hi, Wi, Ho, Wo, tiles_x, tiles_y, ncot, ncotv, nch, total_tiles;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_kernel(S2Args p) {
             const int gx = SCATTER ? l_x0 - 1 + ipc[k] : 2 * (l_x0 + ipc[k]) - pxx;
             const bool inb = gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
             pmask[k] = inb ? 1.f : 0.f;
-            const float *s = p.x + ((long)l_b * p.Cin + cbase + 8 * ihalf[k]) * HWi + (inb ? (long)gy * p.Wi + gx : 0);
+            const float *s = (const float *)p.x + ((long)l_b * p.Cin + cbase + 8 * ihalf[k]) * HWi + (inb ? (long)gy * p.Wi + gx : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) px[k][j] = s[j * HWi];
         }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_kernel(S2Args p) {
                     const int oy = SCATTER ? 2 * vy + qy : vy, ox = SCATTER ? 2 * vx + qx : vx;
                     const bool ok = SCATTER ? (vy < p.Hi && vx < p.Wi) : (vy < p.Ho && vx < p.Wo);
                     if (ok) {
-                        float *op = p.out + ((long)c_b * p.Cout + cot * 64 + m * 32 + 4 * (lane >> 5)) * HWo + (long)oy * p.Wo + ox;
+                        float *op = (float *)p.out + ((long)c_b * p.Cout + cot * 64 + m * 32 + 4 * (lane >> 5)) * HWo + (long)oy * p.Wo + ox;
 #pragma unroll
                         for (int e = 0; e < 16; ++e) op[((e & 3) + 8 * (e >> 2)) * HWo] = acc[m][n][e] + bv[m][e];
                     }
@@ -304,8 +304,11 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_kernel(S2Args p) {
 // staging was more than half of the kernel.  Waves 0-3: producers (buffer loads with hardware zero padding two chunks
 // ahead, hi/lo split, LDS stores of the next chunk); waves 4-7: consumers, two tile rows each, the next (shift, row) step's
 // fragments read under the current MFMAs; buffer stores in the epilogue.
-template <int SCATTER>
+// XB: bfloat16 activations (autocast): a bf16 value is its own hi part -- no lo image of the patch, two MFMAs per product
+// (W lo x X, W hi x X), bf16 stores (conv3x3_mfma.hip's XB form).
+template <int SCATTER, bool XB>
 __global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
+    constexpr unsigned ES = XB ? 2 : 4;
     using G = Geo<SCATTER>;
     constexpr int PW = G::PW, NPX = G::NPX, PATCH_BYTES = G::PATCH_BYTES, STAGE_BYTES = G::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -356,16 +359,21 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
                 py = ph >> 1;
                 pxx = ph & 1;
             }
-            const float *base = p.x + ((long)l_b * p.Cin + cbase) * HWi;
-            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)OOB, 0x00020000);
+            const char *base = (const char *)p.x + ((long)l_b * p.Cin + cbase) * HWi * ES;
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, (int)OOB, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PR; ++k) {
                 const int gy = SCATTER ? l_y0 - 1 + ipr[k] : 2 * (l_y0 + ipr[k]) - py;
                 const int gx = SCATTER ? l_x0 - 1 + ipc[k] : 2 * (l_x0 + ipc[k]) - pxx;
                 const bool inb = gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
-                const unsigned voff = inb ? ((unsigned)(8 * ihalf[k]) * (unsigned)HWi + (unsigned)(gy * p.Wi + gx)) * 4u : OOB;
+                const unsigned voff = inb ? ((unsigned)(8 * ihalf[k]) * (unsigned)HWi + (unsigned)(gy * p.Wi + gx)) * ES : OOB;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) px[k][j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)(j * HWi) * 4u, 0);
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (XB)
+                        px[k][j] = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, (unsigned)(j * HWi) * ES, 0);
+                    else
+                        px[k][j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)(j * HWi) * ES, 0);
+                }
             }
             const v4u *ws = reinterpret_cast<const v4u *>(p.wp + ((long)l_cotv * nch + l_ch) * (2 * NS * 64 * 16));
 #pragma unroll
@@ -383,12 +391,18 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
 #pragma unroll
             for (int k = 0; k < PR; ++k) {
                 unsigned hw[4], lw[4];
+                if constexpr (XB) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) split2(__uint_as_float(px[k][2 * j]), __uint_as_float(px[k][2 * j + 1]), hw[j], lw[j]);
-                const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
-                if (ioff[k] >= 0) {
-                    *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
-                    *reinterpret_cast<v4u *>(patch_lo + ioff[k]) = l;
+                    for (int j = 0; j < 4; ++j) hw[j] = px[k][2 * j] | (px[k][2 * j + 1] << 16);
+                    if (ioff[k] >= 0) *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = v4u{hw[0], hw[1], hw[2], hw[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) split2(__uint_as_float(px[k][2 * j]), __uint_as_float(px[k][2 * j + 1]), hw[j], lw[j]);
+                    const v4u h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+                    if (ioff[k] >= 0) {
+                        *reinterpret_cast<v4u *>(patch_hi + ioff[k]) = h;
+                        *reinterpret_cast<v4u *>(patch_lo + ioff[k]) = l;
+                    }
                 }
             }
 #pragma unroll
@@ -442,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
                 for (int n = 0; n < 2; ++n) {
                     const int off = ((2 * cw + r + dy + qy) * PW + n * 32 + dx + qx) * 16 + b_lane;
                     bh[set][n] = *reinterpret_cast<const bf16x8 *>(patch_hi + off);
-                    bl[set][n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
+                    if constexpr (!XB) bl[set][n] = *reinterpret_cast<const bf16x8 *>(patch_lo + off);
                 }
             };
             frag_a(0, 0);
@@ -461,7 +475,8 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ca][m], bh[cb][n], acc[r][m][n], 0, 0, 0);
-                        acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][m], bl[cb][n], acc[r][m][n], 0, 0, 0);
+                        if constexpr (!XB)
+                            acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][m], bl[cb][n], acc[r][m][n], 0, 0, 0);
                         acc[r][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca][m], bh[cb][n], acc[r][m][n], 0, 0, 0);
                     }
                 if (step + 1 < 2 * NS) __builtin_amdgcn_sched_barrier(0);
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) bv[m][e] = bp[m * 32 + (e & 3) + 8 * (e >> 2)];
                 }
-                float *obase = p.out + ((long)c_b * p.Cout + cot * 64) * HWo;
+                char *obase = (char *)p.out + ((long)c_b * p.Cout + cot * 64) * HWo * ES;
                 const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)OOB, 0x00020000);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -491,13 +506,17 @@ __global__ __launch_bounds__(512, 2) void conv_s2_mfma_ws_kernel(S2Args p) {
                         const int vx = c_x0 + n * 32 + (lane & 31);
                         const int oy = SCATTER ? 2 * vy + qy : vy, ox = SCATTER ? 2 * vx + qx : vx;
                         const bool ok = SCATTER ? (vy < p.Hi && vx < p.Wi) : (vy < p.Ho && vx < p.Wo);
-                        const unsigned voff = ok ? ((unsigned)(4 * (lane >> 5)) * (unsigned)HWo + (unsigned)(oy * p.Wo + ox)) * 4u : OOB;
+                        const unsigned voff = ok ? ((unsigned)(4 * (lane >> 5)) * (unsigned)HWo + (unsigned)(oy * p.Wo + ox)) * ES : OOB;
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
-                                const unsigned soff = (unsigned)((m * 32 + (e & 3) + 8 * (e >> 2)) * HWo) * 4u;
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r][m][n][e] + bv[m][e]), ors, voff, soff, 0);
+                                const unsigned soff = (unsigned)((m * 32 + (e & 3) + 8 * (e >> 2)) * HWo) * ES;
+                                const float v = acc[r][m][n][e] + bv[m][e];
+                                if constexpr (XB)
+                                    __builtin_amdgcn_raw_buffer_store_b16(from_f32<bf16_t>(v).bits, ors, voff, soff, 0);
+                                else
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, voff, soff, 0);
                                 acc[r][m][n][e] = 0.f;
                             }
                     }
@@ -555,22 +574,32 @@ int launch(const mmu_conv_s2_params *p, hipStream_t st, const char *name) {
     // X, Y of the weight source: gather reads [Cout][Cin], scatter [Cin][Cout]
     const int X = SCATTER ? a.Cin : a.Cout, Y = SCATTER ? a.Cout : a.Cin;
     const long nw = (long)a.ncotv * a.nch * NS * 64 * CK;
-    conv_s2_prep_kernel<SCATTER><<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->weight, (unsigned short *)p->workspace, X,
+    conv_s2_prep_kernel<SCATTER><<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float *)p->weight, (unsigned short *)p->workspace, X,
                                                                                Y, K);
     MMU_HIP_LAUNCH_CHECK(name);
     // MMU_CONV_S2_WS=0: the kernel whose eight waves all stage and multiply (A/B); the producer / consumer kernel's buffer
     // addressing keeps 9 input rows-of-channels and a 64-channel output tile of one batch item within 32-bit byte offsets
     static const bool ws_on = []() { const char *e = getenv("MMU_CONV_S2_WS"); return !e || e[0] != '0'; }();
-    const bool ws = ws_on && 9L * a.Hi * a.Wi * 4 < (1L << 31) && 64L * a.Ho * a.Wo * 4 < (1L << 31);
-    static unsigned long long attr_mask = 0, attr_mask_ws = 0;  // per device
-    if (hipError_t e = ws ? mmu_set_lds_once(conv_s2_mfma_ws_kernel<SCATTER>, G::LDS_BYTES, attr_mask_ws)
-                          : mmu_set_lds_once(conv_s2_mfma_kernel<SCATTER>, G::LDS_BYTES, attr_mask);
-        e != hipSuccess)
-        return mmu_fail("%s: LDS attribute: %s", name, hipGetErrorString(e));
+    const bool fits = 9L * a.Hi * a.Wi * 4 < (1L << 31) && 64L * a.Ho * a.Wo * 4 < (1L << 31);
+    const bool xb = p->io_dtype == MMU_DTYPE_BF16;
+    MMU_CHECK(xb || p->io_dtype == MMU_DTYPE_F32, "%s: io_dtype must be float32 or bfloat16 (got %d)", name, p->io_dtype);
+    MMU_CHECK(!xb || fits, "%s: bfloat16 activations need maps within 32-bit byte offsets", name);
+    const bool ws = xb || (ws_on && fits);
+    static unsigned long long attr_mask = 0, attr_mask_ws = 0, attr_mask_xb = 0;  // per device
+    hipError_t e;
+    if (xb)
+        e = mmu_set_lds_once(conv_s2_mfma_ws_kernel<SCATTER, true>, G::LDS_BYTES, attr_mask_xb);
+    else if (ws)
+        e = mmu_set_lds_once(conv_s2_mfma_ws_kernel<SCATTER, false>, G::LDS_BYTES, attr_mask_ws);
+    else
+        e = mmu_set_lds_once(conv_s2_mfma_kernel<SCATTER>, G::LDS_BYTES, attr_mask);
+    if (e != hipSuccess) return mmu_fail("%s: LDS attribute: %s", name, hipGetErrorString(e));
     const int n_cu = mmu_cu_count();
     const int grid = total < n_cu ? (int)total : n_cu;
-    if (ws)
-        conv_s2_mfma_ws_kernel<SCATTER><<<grid, 512, G::LDS_BYTES, st>>>(a);
+    if (xb)
+        conv_s2_mfma_ws_kernel<SCATTER, true><<<grid, 512, G::LDS_BYTES, st>>>(a);
+    else if (ws)
+        conv_s2_mfma_ws_kernel<SCATTER, false><<<grid, 512, G::LDS_BYTES, st>>>(a);
     else
         conv_s2_mfma_kernel<SCATTER><<<grid, 512, G::LDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK(name);
@@ -625,12 +654,16 @@ constexpr int WDOUT_IMG = WCO * WDROW;              // 33,792 B
 constexpr int WLDS_BYTES = 2 * WPATCH_IMG + 2 * WDOUT_IMG;   // 150,784 B
 
 struct S2WgArgs {
-    const float *x, *g;      // x: high-resolution [B, Cin, Hi, Wi]; g: low-resolution [B, Cout, Ho, Wo]
+    const void *x, *g;       // x: high-resolution [B, Cin, Hi, Wi]; g: low-resolution [B, Cout, Ho, Wo]; float32, or (XB)
+                             // both bfloat16: exact bf16 operands, ONE MFMA per product
     float *ws;
     int B, Cin, Cout, Hi, Wi, Ho, Wo, tiles_x, tiles_y, n_cic, n_cot, wg_per_cc;
 };
 
+template <bool XB>
 __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
+    using px_t = typename std::conditional<XB, unsigned short, float>::type;   // raw activations as loaded
+    using dv_t = typename std::conditional<XB, v2u, float4>::type;            // four dout pixels as loaded
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *patch_hi = lds, *patch_lo = lds + WPATCH_IMG;
     unsigned char *dout_hi = lds + 2 * WPATCH_IMG, *dout_lo = dout_hi + WDOUT_IMG;
@@ -667,8 +700,9 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
         d_off[k] = d_co[k] * WDROW + d_px[k] * 2;
     }
 
-    float px[PR][8], pm[PR];
-    float4 dv[8];
+    px_t px[PR][8];
+    float pm[PR];
+    dv_t dv[8];
     auto prefetch = [&](int t) {
         t = t < ntiles ? t : ntiles - 1;
         const int b = t / tiles_img, r = t - b * tiles_img;
@@ -679,7 +713,7 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
             const int gy = 2 * (y0 + p_pr[k]) - py, gx = 2 * (x0 + p_pc[k]) - pxx;
             const bool inb = gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
             pm[k] = inb ? 1.f : 0.f;
-            const float *s = p.x + ((long)b * p.Cin + c0 + 8 * p_cg[k]) * HWi + (inb ? (long)gy * p.Wi + gx : 0);
+            const px_t *s = (const px_t *)p.x + ((long)b * p.Cin + c0 + 8 * p_cg[k]) * HWi + (inb ? (long)gy * p.Wi + gx : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) px[k][j] = s[j * HWi];
         }
@@ -687,11 +721,14 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
         for (int k = 0; k < 8; ++k) {
             const int gy = y0 + (d_px[k] >> 6), gx = x0 + (d_px[k] & 63);
             const bool inb = gy < p.Ho && gx < p.Wo;   // Wo % 4 == 0: a group of 4 is in or out as a whole
-            const float4 v = *reinterpret_cast<const float4 *>(
-                p.g + ((long)b * p.Cout + cot * WCO + d_co[k]) * HWo + (inb ? (long)gy * p.Wo + gx : 0));
-            const float m = inb ? 1.f : 0.f;
-            dv[k] = make_float4(inb ? v.x : 0.f, inb ? v.y : 0.f, inb ? v.z : 0.f, inb ? v.w : 0.f);
-            (void)m;
+            const long go = ((long)b * p.Cout + cot * WCO + d_co[k]) * HWo + (inb ? (long)gy * p.Wo + gx : 0);
+            if constexpr (XB) {
+                const v2u v = *reinterpret_cast<const v2u *>((const unsigned short *)p.g + go);
+                dv[k] = inb ? v : v2u{0u, 0u};
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>((const float *)p.g + go);
+                dv[k] = make_float4(inb ? v.x : 0.f, inb ? v.y : 0.f, inb ? v.z : 0.f, inb ? v.w : 0.f);
+            }
         }
     };
     auto stage = [&]() {
@@ -699,20 +736,28 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
         for (int k = 0; k < PR; ++k) {
             unsigned hw[4], lw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                split2(pm[k] != 0.f ? px[k][2 * j] : 0.f, pm[k] != 0.f ? px[k][2 * j + 1] : 0.f, hw[j], lw[j]);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (XB)
+                    hw[j] = pm[k] != 0.f ? (unsigned)px[k][2 * j] | ((unsigned)px[k][2 * j + 1] << 16) : 0u;
+                else
+                    split2(pm[k] != 0.f ? px[k][2 * j] : 0.f, pm[k] != 0.f ? px[k][2 * j + 1] : 0.f, hw[j], lw[j]);
+            }
             if (p_off[k] >= 0) {
                 *reinterpret_cast<v4u *>(patch_hi + p_off[k]) = v4u{hw[0], hw[1], hw[2], hw[3]};
-                *reinterpret_cast<v4u *>(patch_lo + p_off[k]) = v4u{lw[0], lw[1], lw[2], lw[3]};
+                if constexpr (!XB) *reinterpret_cast<v4u *>(patch_lo + p_off[k]) = v4u{lw[0], lw[1], lw[2], lw[3]};
             }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            unsigned h0, l0, h1, l1;
-            split2(dv[k].x, dv[k].y, h0, l0);
-            split2(dv[k].z, dv[k].w, h1, l1);
-            *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = v2u{h0, h1};
-            *reinterpret_cast<v2u *>(dout_lo + d_off[k]) = v2u{l0, l1};
+            if constexpr (XB) {
+                *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = dv[k];
+            } else {
+                unsigned h0, l0, h1, l1;
+                split2(dv[k].x, dv[k].y, h0, l0);
+                split2(dv[k].z, dv[k].w, h1, l1);
+                *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = v2u{h0, h1};
+                *reinterpret_cast<v2u *>(dout_lo + d_off[k]) = v2u{l0, l1};
+            }
         }
     };
 
@@ -745,7 +790,7 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
             for (int m = 0; m < 2; ++m) {
                 const int off = m * 32 * WDROW + (row * WTW + xk) * 2 + a_lane;
                 ah[m] = *reinterpret_cast<const bf16x8 *>(dout_hi + off);
-                al[m] = *reinterpret_cast<const bf16x8 *>(dout_lo + off);
+                if constexpr (!XB) al[m] = *reinterpret_cast<const bf16x8 *>(dout_lo + off);
             }
             const int poff = ((row + sa) * WPW + xk + sb) * WROW + b_lane;
             auto tr = [&](const unsigned char *img, int o) {
@@ -753,14 +798,19 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
                     (__attribute__((address_space(3))) s4 *)(uintptr_t)(unsigned)(uintptr_t)(img + o));
             };
             const s4 h0 = tr(patch_hi, poff), h1 = tr(patch_hi, poff + 4 * WROW);
-            const s4 l0 = tr(patch_lo, poff), l1 = tr(patch_lo, poff + 4 * WROW);
             const bf16x8 bh = __builtin_bit_cast(bf16x8, s8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, s8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+            if constexpr (XB) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+            } else {
+                const s4 l0 = tr(patch_lo, poff), l1 = tr(patch_lo, poff + 4 * WROW);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, s8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
+                }
             }
         }
     }
@@ -837,10 +887,14 @@ extern "C" int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream)
               p->out_height, p->out_width);
     MMU_CHECK(Wo % 4 == 0, "conv_s2_wgrad_mfma: the output width must be a multiple of 4 (got %d)", Wo);
     MMU_CHECK(p->input && p->weight && p->out && p->workspace, "conv_s2_wgrad_mfma: input, dout, dweight, workspace required");
-    MMU_CHECK(((uintptr_t)p->weight & 15) == 0, "conv_s2_wgrad_mfma: dout must be 16-byte aligned");
+    const bool xb = p->io_dtype == MMU_DTYPE_BF16;
+    MMU_CHECK(xb || p->io_dtype == MMU_DTYPE_F32, "conv_s2_wgrad_mfma: io_dtype must be float32 or bfloat16 (got %d)", p->io_dtype);
+    MMU_CHECK(((uintptr_t)p->weight & (xb ? 7 : 15)) == 0, "conv_s2_wgrad_mfma: dout must be %d-byte aligned", xb ? 8 : 16);
     hipStream_t st = (hipStream_t)stream;
-    static unsigned long long attr_mask = 0;  // per device
-    if (hipError_t e = mmu_set_lds_once(conv_s2_wgrad_kernel, WLDS_BYTES, attr_mask); e != hipSuccess)
+    static unsigned long long attr_mask = 0, attr_mask_xb = 0;  // per device
+    if (hipError_t e = xb ? mmu_set_lds_once(conv_s2_wgrad_kernel<true>, WLDS_BYTES, attr_mask_xb)
+                          : mmu_set_lds_once(conv_s2_wgrad_kernel<false>, WLDS_BYTES, attr_mask);
+        e != hipSuccess)
         return mmu_fail("conv_s2_wgrad_mfma: LDS attribute: %s", hipGetErrorString(e));
     S2WgArgs a;
     a.x = p->input; a.g = p->weight; a.ws = (float *)p->workspace;
@@ -850,7 +904,10 @@ extern "C" int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream)
     a.n_cic = 4 * p->in_channels / WCI; a.n_cot = p->out_channels / WCO;
     a.wg_per_cc = s2_wg_per_cc(p->batch, p->in_channels, p->out_channels, Ho, Wo);
     const int grid = a.wg_per_cc * a.n_cic * a.n_cot;
-    conv_s2_wgrad_kernel<<<grid, WNT, WLDS_BYTES, st>>>(a);
+    if (xb)
+        conv_s2_wgrad_kernel<true><<<grid, WNT, WLDS_BYTES, st>>>(a);
+    else
+        conv_s2_wgrad_kernel<false><<<grid, WNT, WLDS_BYTES, st>>>(a);
     MMU_HIP_LAUNCH_CHECK("conv_s2_wgrad_mfma");
     const long n = (long)p->out_channels * p->in_channels * p->kernel * p->kernel;
     {   // inside a deferred scope: with the other weight-gradient sums of the pass (deferred_reduce.hip, kind 6)
@@ -858,7 +915,7 @@ extern "C" int mmu_conv_s2_wgrad_mfma(const mmu_conv_s2_params *p, void *stream)
                              a.n_cic, a.wg_per_cc, (long)WCO | ((long)WCI << 32)};
         if (mmu_defer_job(job)) return 0;
     }
-    conv_s2_wgrad_sum_kernel<<<(unsigned)((n + 15) / 16), 256, 0, st>>>(a.ws, p->out, p->in_channels, p->out_channels,
+    conv_s2_wgrad_sum_kernel<<<(unsigned)((n + 15) / 16), 256, 0, st>>>(a.ws, (float *)p->out, p->in_channels, p->out_channels,
                                                                          p->kernel, a.n_cic, a.wg_per_cc);
     MMU_HIP_LAUNCH_CHECK("conv_s2_wgrad_mfma(sum)");
     return 0;

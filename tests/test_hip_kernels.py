@@ -853,6 +853,40 @@ def test_conv_s2_mfma_vs_conv2d_fp64(case):
     assert float((b.grad.double() - bd.grad).abs().max()) < 1e-4 * sc(bd.grad), "d bias"
 
 
+@pytest.mark.parametrize("case", [("conv", 2, 64, 64, 32, 64, 4), ("conv", 1, 64, 128, 16, 24, 3), ("conv", 3, 64, 64, 10, 130, 4),
+                                  ("convt", 2, 64, 64, 16, 32, 4), ("convt", 1, 128, 128, 6, 70, 4)])
+def test_conv_s2_bfloat16_activations_vs_fp64(case):
+    """csrc/conv_s2_mfma.hip under bf16 autocast (XB forms of the producer / consumer kernel: bf16 input / output, float32
+    weights, two MFMAs per product; weight gradient: both operands exact bf16, ONE MFMA per product): strided and
+    transposed convolution, output and input gradient within bf16 rounding of float64 on the SAME bf16 inputs, weight
+    and bias gradient to float32 accuracy."""
+    import torch.nn.functional as F
+    from mm_unet_amd import conv_s2
+    kind, B, cin, cout, H, W, k = case
+    gen = torch.Generator().manual_seed(B + cin + H)
+    x = torch.randn(B, cin, H, W, generator=gen).to(torch.bfloat16)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    w = torch.randn(wshape, generator=gen) / (k * cin ** 0.5)
+    b = torch.randn(cout, generator=gen)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride=2, padding=1) if kind == "conv" else F.conv_transpose2d(xr, wr, br, stride=2, padding=1)
+    g = torch.randn(ref.shape, generator=gen).to(torch.bfloat16)
+    ref.backward(g.double())
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert (conv_s2.conv_supported if kind == "conv" else conv_s2.convt_supported)(xg, wg)
+        out = (conv_s2.conv_s2 if kind == "conv" else conv_s2.conv_transpose_s2)(xg, wg, bg)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    out.backward(g.to(DEV))
+    rel = lambda a, r: float((a.detach().double().cpu() - r).abs().max() / r.abs().max())   # noqa: E731
+    assert rel(out, ref.detach()) < 6e-3, rel(out, ref.detach())
+    assert xg.grad.dtype == torch.bfloat16 and rel(xg.grad, xr.grad) < 8e-3, rel(xg.grad, xr.grad)
+    low_w = ref.shape[3] if kind == "conv" else W      # width of the low-resolution tensor of the pair
+    own = cin % 64 == 0 and cout % 64 == 0 and low_w % 4 == 0    # the kernel's weight gradient; else ATen's, in bf16
+    assert wg.grad.dtype == torch.float32 and rel(wg.grad, wr.grad) < (3e-5 if own else 1e-2), rel(wg.grad, wr.grad)
+    assert bg.grad.dtype == torch.float32 and rel(bg.grad, br.grad) < 1e-5
+
+
 def test_eight_wave_convolution_kernels_still_agree_with_fp64():
     """The kernels the producer / consumer ones replaced stay in the library as the route for maps whose byte offsets do not
     fit the buffer-resource addressing (64 channels x H x W x 4 >= 2 GiB) and as the A/B partner (MMU_CONV3_WS=0,
