@@ -131,21 +131,21 @@ class ConvS2Fn(torch.autograd.Function):
         cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
         lowp = x.dtype != torch.float32          # bf16 activations (autocast): the kernels' XB forms
         g = (dout.to(x.dtype) if lowp else dout.float()).contiguous()
-        wa = weight.to(g.dtype) if lowp else weight     # (the ATen routes below only)
+        wa = lambda: weight.to(g.dtype) if lowp else weight   # noqa: E731  (the ATen routes below only)
         dx = dw = db = None
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[0]:
             if cout % 16 == 0 and cin % 64 == 0:     # the transposed kernel on the weight as it is
                 dx = _run(True, g, weight, None, cout, cin, k, (x.shape[2], x.shape[3]))
             else:
-                dx = torch.ops.aten.convolution_backward(g, x, wa, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                dx = torch.ops.aten.convolution_backward(g, x, wa(), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             if _wgrad_ok(cin, cout, g.shape[3], g):
                 with deferred.guard(ctx.may_defer):
                     dw = _wgrad(x, g, k)
             else:
-                dw = torch.ops.aten.convolution_backward(g, x, wa, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                dw = torch.ops.aten.convolution_backward(g, x, wa(), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1].float()
         if need_b:
             with deferred.guard(ctx.may_defer):
@@ -178,19 +178,19 @@ class ConvT2Fn(torch.autograd.Function):
         cin, cout = weight.shape[0], weight.shape[1]
         lowp = x.dtype != torch.float32
         g = (dout.to(x.dtype) if lowp else dout.float()).contiguous()
-        wa = weight.to(g.dtype) if lowp else weight     # (the ATen routes below only)
+        wa = lambda: weight.to(g.dtype) if lowp else weight   # noqa: E731  (the ATen routes below only)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if cout % 16 == 0 and cin % 64 == 0:     # the strided kernel on the weight as it is: [Cin_T][Cout_T] = [out][in]
                 dx = _run(False, g, weight, None, cout, cin, 4, (x.shape[2], x.shape[3]))
             else:
-                dx = torch.nn.functional.conv2d(g, wa, None, stride=2, padding=1)
+                dx = torch.nn.functional.conv2d(g, wa(), None, stride=2, padding=1)
         if ctx.needs_input_grad[1]:
             if _wgrad_ok(cout, cin, x.shape[3], x):
                 with deferred.guard(ctx.may_defer):
                     dw = _wgrad(g, x, 4)            # [C_low = Cin_T][C_high = Cout_T][4][4]
             else:
-                dw = torch.ops.aten.convolution_backward(g, x, wa, None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1,
+                dw = torch.ops.aten.convolution_backward(g, x, wa(), None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1,
                                                          [False, True, False])[1].float()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             with deferred.guard(ctx.may_defer):
