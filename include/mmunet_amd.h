@@ -726,13 +726,15 @@ int mmu_conv7x7_2to1_bwd(const mmu_conv7x7_params *p, void *stream);
 typedef struct {
     int64_t planes;                       /* batch * channels */
     int32_t height, width, out_height, out_width;
-    const float *dout;                    /* [planes, out_height, out_width] */
+    const void *dout;                     /* [planes, out_height, out_width], io_dtype */
     const void *indices;                  /* int64, same shape as dout */
-    float *dinput;                        /* [planes, height, width] */
-    const float *input;                   /* fwd: [planes, height, width] */
-    float *out;                           /* fwd: [planes, out_height, out_width] */
+    void *dinput;                         /* [planes, height, width], io_dtype */
+    const void *input;                    /* fwd: [planes, height, width], io_dtype */
+    void *out;                            /* fwd: [planes, out_height, out_width], io_dtype */
     uint8_t *codes;                       /* fwd (written) / bwd_codes (read): arg-max position 3 * dy + dx inside the window */
-    const float *dinput_addend;           /* bwd_codes, optional: added to the gathered gradient (may be dinput itself) */
+    const void *dinput_addend;            /* bwd_codes, optional: added to the gathered gradient (may be dinput itself) */
+    int32_t io_dtype;                     /* ABI 12: MMU_DTYPE_F32 (0, a zeroed struct) or, for fwd / bwd_codes on maps with
+                                           * width % 8 == 0 and even height, MMU_DTYPE_BF16 (comparisons and sums in float32) */
 } mmu_maxpool_params;
 
 int mmu_maxpool3s2_bwd(const mmu_maxpool_params *p, void *stream);

@@ -189,7 +189,7 @@ class Conv7x7Params(ctypes.Structure):
 
 class MaxPoolParams(ctypes.Structure):
     _fields_ = [("planes", _i64)] + [(n, _i32) for n in ("height", "width", "out_height", "out_width")] + \
-               [(n, _vp) for n in ("dout", "indices", "dinput", "input", "out", "codes", "dinput_addend")]
+               [(n, _vp) for n in ("dout", "indices", "dinput", "input", "out", "codes", "dinput_addend")] + [("io_dtype", _i32)]
 
 
 class SumPartsParams(ctypes.Structure):

@@ -139,7 +139,55 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_code_kernel(const float *_
 // The same two for W % 8 == 0 and even H (the stem: 256 x 256), vector loads and stores.
 // Forward: thread = four neighbouring outputs of one row; per input row two float4 (columns 8q .. 8q+7) and the column left
 // of them.
-__global__ __launch_bounds__(256) void maxpool3s2_fwd_v4_kernel(const float *__restrict__ x, float *__restrict__ out,
+// io_t = float or bf16_t (activations under autocast: read and written natively; comparisons and gradient sums in float32)
+template <typename io_t>
+__device__ __forceinline__ void ld8(const io_t *p, float (&o)[8]) {
+    if constexpr (sizeof(io_t) == 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(w[i] << 16);
+            o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+}
+template <typename io_t>
+__device__ __forceinline__ void ld4(const io_t *p, float (&o)[4]) {
+    if constexpr (sizeof(io_t) == 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(p);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    return (unsigned)from_f32<bf16_t>(a).bits | ((unsigned)from_f32<bf16_t>(b).bits << 16);
+}
+template <typename io_t>
+__device__ __forceinline__ void st4(io_t *p, const float (&v)[4]) {
+    if constexpr (sizeof(io_t) == 4)
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+        *reinterpret_cast<uint2 *>(p) = make_uint2(pk2(v[0], v[1]), pk2(v[2], v[3]));
+}
+template <typename io_t>
+__device__ __forceinline__ void st8(io_t *p, const float (&v)[8]) {
+    if constexpr (sizeof(io_t) == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        *reinterpret_cast<uint4 *>(p) = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+    }
+}
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_v4_kernel(const io_t *__restrict__ x, io_t *__restrict__ out,
                                                                 unsigned char *__restrict__ code, int H, int W, int OH,
                                                                 unsigned total) {
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
@@ -149,17 +197,17 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_v4_kernel(const float *__r
     const unsigned r = t / (unsigned)oq;
     const int oy = (int)(r % (unsigned)OH);
     const long plane = r / (unsigned)OH;
-    const float *xp = x + plane * H * W + 8 * q;
+    const io_t *xp = x + plane * H * W + 8 * q;
     float v[3][9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int y = min(max(2 * oy - 1 + dy, 0), H - 1);       // (clamped: the row above the image is masked below)
-        const float *row = xp + (long)y * W;
-        const float4 a = *reinterpret_cast<const float4 *>(row);
-        const float4 b = *reinterpret_cast<const float4 *>(row + 4);
-        v[dy][0] = row[q > 0 ? -1 : 0];
-        v[dy][1] = a.x; v[dy][2] = a.y; v[dy][3] = a.z; v[dy][4] = a.w;
-        v[dy][5] = b.x; v[dy][6] = b.y; v[dy][7] = b.z; v[dy][8] = b.w;
+        const io_t *row = xp + (long)y * W;
+        float r8[8];
+        ld8(row, r8);
+        v[dy][0] = to_f32(row[q > 0 ? -1 : 0]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[dy][1 + i] = r8[i];
     }
     float best[4];
     unsigned codes = 0;
@@ -186,14 +234,15 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_v4_kernel(const float *__r
         codes |= (unsigned)bc << (8 * j);
     }
     const long o = ((plane * OH + oy) * OW) + 4 * q;
-    *reinterpret_cast<float4 *>(out + o) = make_float4(best[0], best[1], best[2], best[3]);
+    st4(out + o, best);
     *reinterpret_cast<unsigned *>(code + o) = codes;
 }
 
 // Backward: thread = input rows 2r, 2r+1, columns 8q .. 8q+7; it needs gradient rows r, r+1 at columns 4q .. 4q+4.
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_code_v8_kernel(const float *__restrict__ g,
+template <typename io_t>
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_code_v8_kernel(const io_t *__restrict__ g,
                                                                      const unsigned char *__restrict__ code,
-                                                                     float *dx, const float *addend, int H, int W,
+                                                                     io_t *dx, const io_t *addend, int H, int W,
                                                                      unsigned total) {
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -208,12 +257,13 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_code_v8_kernel(const float
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const long o = (plane * OH + min(r + a, OH - 1)) * OW + 4 * q;
-        const float4 g4 = *reinterpret_cast<const float4 *>(g + o);
+        float g4[4];
+        ld4(g + o, g4);
         const unsigned c4 = *reinterpret_cast<const unsigned *>(code + o);
-        const float g1 = g[o + (col4 ? 4 : 0)];
+        const float g1 = to_f32(g[o + (col4 ? 4 : 0)]);
         const int c1 = code[o + (col4 ? 4 : 0)];
         const bool ok = a == 0 || row1;
-        gv[a][0] = g4.x; gv[a][1] = g4.y; gv[a][2] = g4.z; gv[a][3] = g4.w; gv[a][4] = g1;
+        gv[a][0] = g4[0]; gv[a][1] = g4[1]; gv[a][2] = g4[2]; gv[a][3] = g4[3]; gv[a][4] = g1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) cv[a][i] = ok ? (int)((c4 >> (8 * i)) & 255u) : 255;
         cv[a][4] = ok && col4 ? c1 : 255;
@@ -234,18 +284,20 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_code_v8_kernel(const float
         if (i & 1) s += cv[1][o1] == 0 ? gv[1][o1] : 0.f;
         bot[i] = s;
     }
-    float *dst = dx + (plane * H + 2 * r) * W + 8 * q;
+    io_t *dst = dx + (plane * H + 2 * r) * W + 8 * q;
     if (addend) {
-        const float *ad = addend + (plane * H + 2 * r) * W + 8 * q;
-        const float4 a0 = *reinterpret_cast<const float4 *>(ad), a1 = *reinterpret_cast<const float4 *>(ad + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(ad + W), b1 = *reinterpret_cast<const float4 *>(ad + W + 4);
-        top[0] += a0.x; top[1] += a0.y; top[2] += a0.z; top[3] += a0.w; top[4] += a1.x; top[5] += a1.y; top[6] += a1.z; top[7] += a1.w;
-        bot[0] += b0.x; bot[1] += b0.y; bot[2] += b0.z; bot[3] += b0.w; bot[4] += b1.x; bot[5] += b1.y; bot[6] += b1.z; bot[7] += b1.w;
+        const io_t *ad = addend + (plane * H + 2 * r) * W + 8 * q;
+        float a8[8], b8[8];
+        ld8(ad, a8);
+        ld8(ad + W, b8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            top[i] += a8[i];
+            bot[i] += b8[i];
+        }
     }
-    *reinterpret_cast<float4 *>(dst) = make_float4(top[0], top[1], top[2], top[3]);
-    *reinterpret_cast<float4 *>(dst + 4) = make_float4(top[4], top[5], top[6], top[7]);
-    *reinterpret_cast<float4 *>(dst + W) = make_float4(bot[0], bot[1], bot[2], bot[3]);
-    *reinterpret_cast<float4 *>(dst + W + 4) = make_float4(bot[4], bot[5], bot[6], bot[7]);
+    st8(dst, top);
+    st8(dst + W, bot);
 }
 
 inline bool maxpool_vector_ok(const mmu_maxpool_params *p) {
@@ -263,16 +315,24 @@ extern "C" int mmu_maxpool3s2_fwd(const mmu_maxpool_params *p, void *stream) {
     MMU_CHECK(p->input && p->out && p->codes, "maxpool3s2_fwd: input, out, codes are required");
     const long total = (long)p->planes * p->out_height * p->out_width;
     MMU_CHECK(total < (1L << 40), "maxpool3s2_fwd: tensor too large");
-    if (maxpool_vector_ok(p) && total / 4 < (1L << 32) && ((uintptr_t)p->input & 15) == 0 && ((uintptr_t)p->out & 15) == 0 &&
-        ((uintptr_t)p->codes & 3) == 0) {
+    const bool xb = p->io_dtype == MMU_DTYPE_BF16;
+    MMU_CHECK(xb || p->io_dtype == MMU_DTYPE_F32, "maxpool3s2_fwd: io_dtype must be float32 or bfloat16 (got %d)", p->io_dtype);
+    const bool vec = maxpool_vector_ok(p) && total / 4 < (1L << 32) && ((uintptr_t)p->input & 15) == 0 &&
+                     ((uintptr_t)p->out & (xb ? 7 : 15)) == 0 && ((uintptr_t)p->codes & 3) == 0;
+    MMU_CHECK(!xb || vec, "maxpool3s2_fwd: bfloat16 maps need width %% 8 == 0, even height, 16-byte aligned input");
+    if (vec) {
         const unsigned n = (unsigned)(total / 4);
-        maxpool3s2_fwd_v4_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(p->input, p->out, p->codes, p->height,
-                                                                                   p->width, p->out_height, n);
+        if (xb)
+            maxpool3s2_fwd_v4_kernel<bf16_t><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+                (const bf16_t *)p->input, (bf16_t *)p->out, p->codes, p->height, p->width, p->out_height, n);
+        else
+            maxpool3s2_fwd_v4_kernel<float><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+                (const float *)p->input, (float *)p->out, p->codes, p->height, p->width, p->out_height, n);
         MMU_HIP_LAUNCH_CHECK("maxpool3s2_fwd");
         return 0;
     }
     maxpool3s2_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        p->input, p->out, p->codes, p->height, p->width, p->out_height, p->out_width, p->planes);
+        (const float *)p->input, (float *)p->out, p->codes, p->height, p->width, p->out_height, p->out_width, p->planes);
     MMU_HIP_LAUNCH_CHECK("maxpool3s2_fwd");
     return 0;
 }
@@ -286,16 +346,25 @@ extern "C" int mmu_maxpool3s2_bwd_codes(const mmu_maxpool_params *p, void *strea
     MMU_CHECK(((uintptr_t)p->dinput & 15) == 0, "maxpool3s2_bwd_codes: dinput must be 16-byte aligned");
     const long total = (long)p->planes * p->height * ((p->width + 3) / 4);
     MMU_CHECK(total < (1L << 32), "maxpool3s2_bwd_codes: tensor too large");
-    if (maxpool_vector_ok(p) && ((uintptr_t)p->dout & 15) == 0 && ((uintptr_t)p->codes & 3) == 0 &&
-        ((uintptr_t)p->dinput_addend & 15) == 0) {
+    const bool xb = p->io_dtype == MMU_DTYPE_BF16;
+    MMU_CHECK(xb || p->io_dtype == MMU_DTYPE_F32, "maxpool3s2_bwd_codes: io_dtype must be float32 or bfloat16 (got %d)", p->io_dtype);
+    const bool vec = maxpool_vector_ok(p) && ((uintptr_t)p->dout & (xb ? 7 : 15)) == 0 && ((uintptr_t)p->codes & 3) == 0 &&
+                     ((uintptr_t)p->dinput_addend & 15) == 0;
+    MMU_CHECK(!xb || vec, "maxpool3s2_bwd_codes: bfloat16 maps need width %% 8 == 0, even height, aligned gradients");
+    if (vec) {
         const unsigned n = (unsigned)((long)p->planes * (p->height / 2) * (p->width / 8));
-        maxpool3s2_bwd_code_v8_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(
-            p->dout, p->codes, p->dinput, p->dinput_addend, p->height, p->width, n);
+        if (xb)
+            maxpool3s2_bwd_code_v8_kernel<bf16_t><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+                (const bf16_t *)p->dout, p->codes, (bf16_t *)p->dinput, (const bf16_t *)p->dinput_addend, p->height, p->width, n);
+        else
+            maxpool3s2_bwd_code_v8_kernel<float><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+                (const float *)p->dout, p->codes, (float *)p->dinput, (const float *)p->dinput_addend, p->height, p->width, n);
         MMU_HIP_LAUNCH_CHECK("maxpool3s2_bwd_codes");
         return 0;
     }
     maxpool3s2_bwd_code_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        p->dout, p->codes, p->dinput, p->dinput_addend, p->height, p->width, p->out_height, p->out_width, (unsigned)total);
+        (const float *)p->dout, p->codes, (float *)p->dinput, (const float *)p->dinput_addend, p->height, p->width,
+        p->out_height, p->out_width, (unsigned)total);
     MMU_HIP_LAUNCH_CHECK("maxpool3s2_bwd_codes");
     return 0;
 }
@@ -310,8 +379,10 @@ extern "C" int mmu_maxpool3s2_bwd(const mmu_maxpool_params *p, void *stream) {
     MMU_CHECK(((uintptr_t)p->dinput & 15) == 0, "maxpool3s2_bwd: dinput must be 16-byte aligned");
     const long total = (long)p->planes * p->height * ((p->width + 3) / 4);
     MMU_CHECK(total < (1L << 40), "maxpool3s2_bwd: tensor too large");
+    MMU_CHECK(p->io_dtype == MMU_DTYPE_F32, "maxpool3s2_bwd: float32 only (bfloat16: mmu_maxpool3s2_bwd_codes)");
     maxpool3s2_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        p->dout, (const long *)p->indices, p->dinput, p->height, p->width, p->out_height, p->out_width, p->planes);
+        (const float *)p->dout, (const long *)p->indices, (float *)p->dinput, p->height, p->width, p->out_height, p->out_width,
+        p->planes);
     MMU_HIP_LAUNCH_CHECK("maxpool3s2_bwd");
     return 0;
 }

@@ -1642,6 +1642,33 @@ def test_max_pool3s2_vs_module(shape):
     assert torch.equal(torch.nan_to_num(maxpool.pool_module(m, xn), nan=12345.0), torch.nan_to_num(m(xn), nan=12345.0))
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 64, 64), (1, 3, 10, 24), (2, 4, 256, 256)])
+def test_max_pool3s2_bfloat16_vs_module(shape):
+    """The bf16 form of the max-pool kernels (autocast: maps read / written natively, W % 8 == 0, even H): output equal to
+    nn.MaxPool2d on the same bf16 map; the gather backward against float64 accumulation of the same arg-max routing,
+    within one bf16 rounding (ATen's own bf16 backward rounds the same sums); NaN / -inf as in ATen."""
+    from mm_unet_amd import maxpool
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = ((torch.randn(*shape, device=DEV, generator=gen) * 4).round() / 4).to(torch.bfloat16)     # ties
+    m = torch.nn.MaxPool2d(3, 2, 1)
+    assert maxpool.module_supported(m, x) and not maxpool.module_supported(m, x[..., :-4])
+    xo = x.clone().requires_grad_()
+    out = maxpool.pool_module(m, xo)
+    xr = x.double().requires_grad_()
+    ref = m(xr)
+    assert out.dtype == torch.bfloat16 and torch.equal(out.double(), ref.detach())
+    g = torch.randn(ref.shape, device=DEV, generator=gen).to(torch.bfloat16)
+    out.backward(g)
+    ref.backward(g.double())
+    assert xo.grad.dtype == torch.bfloat16
+    err = (xo.grad.double() - xr.grad).abs().max() / xr.grad.abs().max()
+    assert float(err) < 4e-3, float(err)
+    xn = x.clone()
+    xn.view(-1)[::7] = float("nan")
+    xn[0, 0] = float("-inf")
+    assert torch.equal(torch.nan_to_num(maxpool.pool_module(m, xn).float(), nan=12345.0), torch.nan_to_num(m(xn).float(), nan=12345.0))
+
+
 @pytest.mark.parametrize("shape", [(8, 1, 512, 512), (2, 1, 33, 17), (1, 3, 5, 7)])
 def test_fused_dice_bce_loss_vs_aten_and_fixture(shape):
     """loss.DICE_BCE_Loss on the GPU (csrc/dice_bce.hip: two launches forward, one backward) against the same formula in
