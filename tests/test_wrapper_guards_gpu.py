@@ -280,8 +280,11 @@ def test_pointwise_maxpool_gemm_nt_sum_parts_guards():
         with pytest.raises(RuntimeError):
             pointwise.GatedMulFn.apply(*args)
     assert pointwise._gate_mode(x.bfloat16(), gate_c) is None and pointwise._gate_mode(x, _rnd(2, 4, 1, 1)) is None
+    with pytest.raises(RuntimeError):      # bfloat16 maps: W % 8 == 0 and even H only (the vector kernels' bf16 forms)
+        maxpool.max_pool3s2(x.bfloat16()[..., :6].contiguous())
     with pytest.raises(RuntimeError):
-        maxpool.max_pool3s2(x.bfloat16())
+        maxpool.max_pool3s2(x.bfloat16()[:, :, :7].contiguous())
+    assert torch.equal(maxpool.max_pool3s2(x.bfloat16()), torch.nn.functional.max_pool2d(x.bfloat16(), 3, 2, 1))
     with pytest.raises(RuntimeError):
         maxpool.max_pool3s2(x[0])
     a, b = _rnd(8, 256), _rnd(4, 256, seed=3)
