@@ -731,7 +731,14 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
             }
         }
     };
-    auto stage = [&]() {
+    // The conversion (hi/lo split: the vector work of the staging) runs on the prefetched registers INSIDE the k-loop of the
+    // current tile, beside the MFMAs; between the two barriers only the LDS stores are left.  MMU_S2WG_EARLY=0: the
+    // conversion between the barriers, as before (A/B).
+#ifndef MMU_S2WG_EARLY
+#define MMU_S2WG_EARLY 1
+#endif
+    // (converted in place: the packed hi / lo words take the registers of the raw values they came from)
+    auto convert = [&]() {
 #pragma unroll
         for (int k = 0; k < PR; ++k) {
             unsigned hw[4], lw[4];
@@ -742,21 +749,50 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
                 else
                     split2(pm[k] != 0.f ? px[k][2 * j] : 0.f, pm[k] != 0.f ? px[k][2 * j + 1] : 0.f, hw[j], lw[j]);
             }
-            if (p_off[k] >= 0) {
-                *reinterpret_cast<v4u *>(patch_hi + p_off[k]) = v4u{hw[0], hw[1], hw[2], hw[3]};
-                if constexpr (!XB) *reinterpret_cast<v4u *>(patch_lo + p_off[k]) = v4u{lw[0], lw[1], lw[2], lw[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (XB) {
+                    px[k][2 * j] = (px_t)(hw[j] & 0xffffu);
+                    px[k][2 * j + 1] = (px_t)(hw[j] >> 16);
+                } else {
+                    px[k][j] = __uint_as_float(hw[j]);
+                    px[k][4 + j] = __uint_as_float(lw[j]);
+                }
             }
         }
+        if constexpr (!XB) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned h0, l0, h1, l1;
+                split2(dv[k].x, dv[k].y, h0, l0);
+                split2(dv[k].z, dv[k].w, h1, l1);
+                dv[k] = make_float4(__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(l0), __uint_as_float(l1));
+            }
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int k = 0; k < PR; ++k)
+            if (p_off[k] >= 0) {
+                if constexpr (XB) {
+                    unsigned hw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hw[j] = (unsigned)px[k][2 * j] | ((unsigned)px[k][2 * j + 1] << 16);
+                    *reinterpret_cast<v4u *>(patch_hi + p_off[k]) = v4u{hw[0], hw[1], hw[2], hw[3]};
+                } else {
+                    *reinterpret_cast<v4u *>(patch_hi + p_off[k]) = v4u{__float_as_uint(px[k][0]), __float_as_uint(px[k][1]),
+                                                                        __float_as_uint(px[k][2]), __float_as_uint(px[k][3])};
+                    *reinterpret_cast<v4u *>(patch_lo + p_off[k]) = v4u{__float_as_uint(px[k][4]), __float_as_uint(px[k][5]),
+                                                                        __float_as_uint(px[k][6]), __float_as_uint(px[k][7])};
+                }
+            }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if constexpr (XB) {
                 *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = dv[k];
             } else {
-                unsigned h0, l0, h1, l1;
-                split2(dv[k].x, dv[k].y, h0, l0);
-                split2(dv[k].z, dv[k].w, h1, l1);
-                *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = v2u{h0, h1};
-                *reinterpret_cast<v2u *>(dout_lo + d_off[k]) = v2u{l0, l1};
+                *reinterpret_cast<v2u *>(dout_hi + d_off[k]) = v2u{__float_as_uint(dv[k].x), __float_as_uint(dv[k].y)};
+                *reinterpret_cast<v2u *>(dout_lo + d_off[k]) = v2u{__float_as_uint(dv[k].z), __float_as_uint(dv[k].w)};
             }
         }
     };
@@ -774,16 +810,9 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
     const int li = lane & 15, bq = li >> 2, bp = li & 3;
     const int b_lane = bq * WROW + (half * 32 + ((lane >> 4) & 1) * 16 + 4 * bp) * 2 + (lane >> 5) * 8 * WROW;
 
-    int t = wl;
-    prefetch(t);
-    for (; t < ntiles; t += p.wg_per_cc) {
-        __syncthreads();
-        stage();
-        __syncthreads();
-        prefetch(t + p.wg_per_cc);
-        __builtin_amdgcn_sched_barrier(0);
+    auto ksteps = [&](int k0, int k1) {
 #pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = k0; ks < k1; ++ks) {
             const int row = ks >> 2, xk = (ks & 3) * 16;
             bf16x8 ah[2], al[2];
 #pragma unroll
@@ -812,6 +841,25 @@ __global__ __launch_bounds__(WNT, 1) void conv_s2_wgrad_kernel(S2WgArgs p) {
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m], 0, 0, 0);
                 }
             }
+        }
+    };
+    int t = wl;
+    prefetch(t);
+    if (MMU_S2WG_EARLY) convert();
+    for (; t < ntiles; t += p.wg_per_cc) {
+        __syncthreads();
+        if (!MMU_S2WG_EARLY) convert();
+        store();
+        __syncthreads();
+        prefetch(t + p.wg_per_cc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MMU_S2WG_EARLY) {
+            ksteps(0, 8);
+            convert();       // (the loads have had half a tile's MFMAs to arrive; the other half runs beside the split.
+                             //  Spread over the eight remaining steps instead: 256 VGPRs, spills, no faster)
+            ksteps(8, 16);
+        } else {
+            ksteps(0, 16);
         }
     }
     // partial of this workgroup: ws[wg][co 64][vci 64][4 shifts]
