@@ -164,13 +164,23 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wgrad_mfma_kernel(WgArgs p) {
     const int li = lane & 15, bq = li >> 2, bp = li & 3;
     const int b_lane = bq * (CI * 2) + (((lane >> 4) & 1) * 16 + 4 * bp) * 2 + (lane >> 5) * 8 * (CI * 2);
 
-    int t = wl;
+    // XCD-aware tile walk (workgroup ids go round-robin over the 8 XCDs; blockIdx = cc * wg_per_cc + wl): XCD k takes the
+    // k-th contiguous eighth of the tile list, so the halo rows of x that neighbouring tiles share (6 patch rows per 4
+    // output rows) and the dout tile the two ci chunks read are fetched into one L2.  MMU_C3WG_XCD=0: plain strided walk.
+#ifndef MMU_C3WG_XCD
+#define MMU_C3WG_XCD 1
+#endif
+    const bool xcd_walk = MMU_C3WG_XCD && (p.wg_per_cc & 7) == 0;
+    const int per_xcd = (ntiles + 7) >> 3;
+    int t = xcd_walk ? (wl & 7) * per_xcd + (wl >> 3) : wl;
+    const int t_step = xcd_walk ? p.wg_per_cc >> 3 : p.wg_per_cc;
+    const int t_end = xcd_walk ? min(((wl & 7) + 1) * per_xcd, ntiles) : ntiles;
     prefetch(t);
-    for (; t < ntiles; t += p.wg_per_cc) {
+    for (; t < t_end; t += t_step) {
         __syncthreads();                 // the previous tile's fragments have been read
         stage();
         __syncthreads();
-        prefetch(t + p.wg_per_cc);       // in flight during the MFMAs
+        prefetch(t + t_step);            // in flight during the MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 4
         for (int ks = 0; ks < 16; ++ks) {
