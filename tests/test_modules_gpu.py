@@ -241,6 +241,67 @@ def test_mmnet_forward_parity_full_size_vs_oracle():
     assert split <= 1e-3, split
 
 
+def test_mmnet_at_the_reference_training_resolution_608():
+    """config.yml:26 trains at 608 x 608: maps of 304 / 152 / 76 / 38 / 19 pixels -- none a multiple of the 64-pixel tiles,
+    19 x 19 odd.  Eval forward of MM_Net on 1 x 3 x 608 x 608 against the CPU oracle (north-star bound 1e-3), and the
+    training-step gradients of the fused route against the SAME model on the plain ATen route (fused_paths.plain_aten:
+    library convolutions / GEMMs, reference-shaped modules): every parameter gradient present, finite, and the two routes
+    apart by no more than two float32 evaluations of this network are (population bound as the 128 x 128 fixture test)."""
+    from oracle import model_ref
+    import mm_unet_amd.mmunet as pm
+    from mm_unet_amd import fused_paths
+    from mm_unet_amd.loss import DICE_BCE_Loss
+    torch.manual_seed(51)
+    model = pm.MM_Net(num_classes=1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    gen = torch.Generator().manual_seed(8)
+    img = torch.randn(1, 3, 608, 608, generator=gen)
+    with torch.no_grad():
+        logits = model(img.to(DEV)).cpu()
+        ref = model_ref.mm_net(sd, img, training=False)
+    err = float((logits - ref).abs().max())
+    print(f"MM_Net 608x608 eval logits max abs err vs oracle: {err:.3e} (|ref| max {float(ref.abs().max()):.3f})")
+    assert logits.shape == (1, 1, 608, 608) and err <= 1e-3, err
+    # one training step each way (dropout off: the two routes draw different masks otherwise)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    model.train()
+    tgt = (torch.rand(1, 1, 608, 608, generator=gen) > 0.9).float().to(DEV)
+
+    def grads(x):
+        model.zero_grad(set_to_none=True)
+        loss = DICE_BCE_Loss()(model(x.to(DEV)), tgt)
+        loss.backward()
+        return float(loss.detach()), {n: q.grad.detach().clone() for n, q in model.named_parameters() if q.grad is not None}
+
+    def spread(ga, gb):
+        rels = []
+        for n in ga:
+            den = float(gb[n].abs().sum())
+            if den > 1e-6:
+                rels.append(float((ga[n] - gb[n]).abs().sum()) / den)
+        return np.sort(np.array(rels))
+
+    l_f, g_f = grads(img)
+    with fused_paths.plain_aten():
+        l_p, g_p = grads(img)
+        # the yardstick: the plain route's own response to float32-rounding-sized input noise (2^-16 relative) -- at batch
+        # 1 the train-mode network (BatchNorm statistics of ONE image, 44 scans deep) amplifies rounding by orders of
+        # magnitude, which is what separates two float32 implementations of it
+        _, g_n = grads(img * (1 + 2.0 ** -16 * torch.randn(img.shape, generator=gen)))
+    assert np.isfinite(l_f) and abs(l_f - l_p) <= 1e-3 * max(1.0, abs(l_p)), (l_f, l_p)
+    assert set(g_f) == set(g_p) and len(g_f) > 1000
+    assert all(bool(torch.isfinite(g).all()) for g in g_f.values())
+    r_f, r_n = spread(g_f, g_p), spread(g_n, g_p)
+    p90 = lambda r: r[int(0.9 * len(r))]   # noqa: E731
+    print(f"608x608 train step, fused vs plain ATen route: median rel. gradient difference {np.median(r_f):.2e}, p90 "
+          f"{p90(r_f):.2e}; plain route under 2^-16 input noise: median {np.median(r_n):.2e}, p90 {p90(r_n):.2e} "
+          f"({len(r_f)} tensors)")
+    assert np.median(r_f) <= 3 * np.median(r_n) + 1e-3 and p90(r_f) <= 3 * p90(r_n) + 1e-2, (np.median(r_f), np.median(r_n))
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_mmnet_fwd_bwd_vs_reference(mode):
     """Dice+BCE training-step parity; tolerances tied to the reference's own response to a 1e-6 input
